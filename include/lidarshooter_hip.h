@@ -1,0 +1,217 @@
+/*
+ * lidarshooter_hip.h -- C ABI of the MI355X (gfx950) LiDAR ray-casting backend.
+ *
+ * Drop-in boundary: the reference's tracer plugin surface `lidarshooter::ITracer`
+ * (ros_ws/src/lidarshooter/src/ITracer.hpp:29-152) as implemented by EmbreeTracer (CPU) and
+ * OptixTracer (CUDA).  The reference has no FFI for this path -- its backends are compiled in --
+ * so the entry points below are exactly what a `HipTracer : public ITracer` adapter binds, one
+ * call per virtual (INTEGRATION.md shows that adapter).  Plain pointers and sizes only; no
+ * exceptions cross this boundary; every mutator returns 0 / a non-negative id on success and a
+ * negative ls_status on failure, and ls_last_error() holds the message.
+ *
+ * Threading (ITracer callers: ROS spinner thread for update/commit/trace, Qt thread for
+ * add/remove, unsynchronised -- mainwindow.cpp:153,320 vs MeshProjector.cpp:446-464): every call
+ * takes the handle's internal mutex.  Buffers returned by ls_trace_scene stay valid until the
+ * next call on the same handle.
+ *
+ * All paths in comments are relative to /root/reference/ros_ws/src/lidarshooter/src/.
+ */
+#ifndef LIDARSHOOTER_HIP_H
+#define LIDARSHOOTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS_ABI_VERSION 1
+
+typedef struct ls_tracer ls_tracer;
+
+typedef enum ls_status {
+    LS_OK = 0,
+    LS_ERR_INVALID_ARGUMENT = -2,
+    LS_ERR_UNKNOWN_GEOMETRY = -3, /* name not registered (EmbreeTracer.cpp:224-225 returns -1 for remove) */
+    LS_ERR_DUPLICATE_GEOMETRY = -4,
+    LS_ERR_UNSUPPORTED_TYPE = -5, /* only triangles (EmbreeTracer.cpp:200-201 returns 0/false there) */
+    LS_ERR_HIP = -6,              /* a HIP runtime call failed; message in ls_last_error */
+    LS_ERR_NO_DEVICE = -7,        /* no usable gfx950 device: the product never falls back to the CPU */
+    LS_ERR_NOT_COMMITTED = -8,
+    LS_ERR_OUT_OF_RANGE = -9
+    /* -1 is reserved for the reference's own "empty scene" / "unknown name" return value */
+} ls_status;
+
+/* Geometry element types; values follow Embree's RTCGeometryType so the adapter can pass the
+ * enum it receives through ITracer::addGeometry (ITracer.hpp:50) unchanged. */
+#define LS_GEOMETRY_TYPE_TRIANGLE 0 /* RTC_GEOMETRY_TYPE_TRIANGLE */
+#define LS_GEOMETRY_TYPE_QUAD 1     /* RTC_GEOMETRY_TYPE_QUAD: rejected */
+
+/* Sensor description = what LidarDevice holds after loadConfiguration()
+ * (LidarDevice.cpp:482-633, :758-822).  The adapter fills it from its LidarDevice; the repo's own
+ * host mirror (lidarshooter_amd/host/LidarDevice.hpp) fills it from the same JSON files. */
+typedef struct ls_sensor_desc {
+    const float *vertical_deg; /* channels.vertical[]: degrees above the horizon, channel order   */
+    uint32_t n_vertical;       /* V                                                                */
+    float h_begin;             /* channels.horizontal.range.begin (degrees)                        */
+    float h_end;               /* channels.horizontal.range.end                                    */
+    uint32_t h_count;          /* channels.horizontal.count = H; step = (end-begin)/(H-1) (:611)   */
+    float Rinv[9];             /* sensorToBase.Rinv, row-major (:813)                              */
+    float t[3];                /* (baseToOrigin.tx, baseToOrigin.ty, sensorToBase.tz) (:383-388)   */
+} ls_sensor_desc;
+
+/* One hit, 16 bytes.  Points and hit records are emitted in ray-index order (r = v*H + h,
+ * LidarDevice.cpp:824-845), one record per point. */
+typedef struct ls_hit {
+    uint32_t ray;   /* global ray index r; channel (ring) = r / H, azimuth column = r % H */
+    uint32_t geom;  /* geomID as returned by ls_add_geometry                               */
+    uint32_t prim;  /* triangle index within that geometry (Embree primID)                 */
+    float t;        /* hit distance along the unit ray direction                           */
+} ls_hit;
+
+/* Result of one traceScene().  points32 is the PointCloud2 `data` payload: n_points records of
+ * 32 bytes, x f32@0 y f32@4 z f32@8 0@12 intensity f32@16 ring i32@20 0@24..31
+ * (XYZIRBytes.cpp:24-40); the adapter sets cloud.width = n_points (EmbreeTracer.cpp:364). */
+typedef struct ls_frame {
+    const uint8_t *points32; /* pinned host memory, 32*n_points bytes              */
+    const ls_hit *hits;      /* pinned host memory, n_points records               */
+    uint32_t n_points;
+    uint32_t n_rays;         /* rays traced by this handle's shard (V * shard width) */
+    uint32_t frame;          /* echo of the frame index (PointCloud2 header.seq, LidarDevice.cpp:108) */
+    const void *d_points32;  /* the same data in device memory (for RCCL gathers)  */
+    const void *d_hits;
+    const uint32_t *d_n_points; /* device word holding n_points                    */
+} ls_frame;
+
+/* ---- lifetime: EmbreeTracer::create / ~EmbreeTracer (EmbreeTracer.cpp:10-70),
+ *      OptixTracer::create (OptixTracer.hpp:91) --------------------------------------------- */
+int ls_tracer_create(const ls_sensor_desc *sensor, int hip_device, ls_tracer **out);
+void ls_tracer_destroy(ls_tracer *tr);
+
+/* ---- ITracer::addGeometry (ITracer.hpp:50; EmbreeTracer.cpp:115-218; OptixTracer.cpp:63-133).
+ * Returns the geomID (>= 0, lowest free id like rtcAttachGeometry) or a negative ls_status. */
+int ls_add_geometry(ls_tracer *tr, const char *name, int geometry_type, int n_vertices, int n_elements);
+
+/* ---- ITracer::removeGeometry (ITracer.hpp:59; EmbreeTracer.cpp:220-260).
+ * Returns the removed geomID, or -1 if the name is unknown (Embree behaviour). */
+int ls_remove_geometry(ls_tracer *tr, const char *name);
+
+/* ---- ITracer::updateGeometry(name, Eigen::Affine3f, mesh) (ITracer.hpp:69; EmbreeTracer.cpp:262-274;
+ * MeshTransformer.cpp:142-205).  affine3x4: row-major [linear | translation].  verts: n_vertices
+ * records of vert_stride bytes whose first 12 bytes are x,y,z float32 (pcl cloud.data with
+ * point_step, MeshTransformer.cpp:176-181).  tri_idx: 3*n_elements vertex indices (polygons[i].vertices,
+ * MeshTransformer.cpp:512-518); NULL keeps the indices of the previous update.  Host pointers. */
+int ls_update_geometry(ls_tracer *tr, const char *name, const float affine3x4[12], const void *verts,
+                       uint32_t vert_stride, const uint32_t *tri_idx);
+
+/* ---- ITracer::updateGeometry(name, translation, rotation, mesh) (ITracer.hpp:80;
+ * EmbreeTracer.cpp:276-288): T = Translation(lin)*Rz(ang.z)*Ry(ang.y)*Rx(ang.x)
+ * (MeshTransformer.cpp:467-477). */
+int ls_update_geometry_components(ls_tracer *tr, const char *name, const float lin[3], const float ang[3],
+                                  const void *verts, uint32_t vert_stride, const uint32_t *tri_idx);
+
+/* Same as ls_update_geometry with verts / tri_idx already resident in HBM on the tracer's device
+ * (no PCIe in the frame loop; used by bench.py).  The copies are stream-ordered. */
+int ls_update_geometry_device(ls_tracer *tr, const char *name, const float affine3x4[12], const void *d_verts,
+                              uint32_t vert_stride, const uint32_t *d_tri_idx);
+
+/* Only the rigid transform of an already uploaded mesh changes (AffineMesh pose integration,
+ * AffineMesh.cpp:108-128): no vertex traffic at all. */
+int ls_update_geometry_transform(ls_tracer *tr, const char *name, const float affine3x4[12]);
+
+/* ---- ITracer::commitScene (ITracer.hpp:87; EmbreeTracer.cpp:290-295 rtcCommitScene;
+ * OptixTracer.cpp:263-275, :517-571).  Transforms every geometry into the sensor frame and builds
+ * the BVH on the device.  Returns 0, or -1 on an empty scene (OptixTracer.cpp:266-267). */
+int ls_commit_scene(ls_tracer *tr);
+
+/* ---- ITracer::traceScene (ITracer.hpp:94; EmbreeTracer.cpp:297-367; OptixTracer.cpp:277-358).
+ * Ray generation + closest hit + packing.  Returns 0, or -1 on an empty scene with a zero-point
+ * frame (OptixTracer.cpp:280-288). */
+int ls_trace_scene(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
+
+/* As ls_trace_scene but leaves the results on the device (out->points32 / hits are NULL,
+ * n_points is not read back): nothing in it blocks the host. */
+int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
+
+/* ---- ITracer::getGeometryCount (ITracer.hpp:101) */
+long ls_geometry_count(ls_tracer *tr);
+
+/* Per-name getters of EmbreeTracer (EmbreeTracer.cpp:369-439); negative status if unknown. */
+int ls_geometry_id(ls_tracer *tr, const char *name);
+long ls_vertex_count(ls_tracer *tr, const char *name);
+long ls_element_count(ls_tracer *tr, const char *name);
+
+/* LidarDevice::getTotalRays / getTotalChannels (LidarDevice.cpp:411-419) for this handle. */
+uint32_t ls_total_rays(ls_tracer *tr);
+uint32_t ls_total_channels(ls_tracer *tr);
+
+const char *ls_last_error(ls_tracer *tr);
+int ls_abi_version(void);
+
+/* ---- multi-GPU: restrict this handle to the azimuth columns [first_az, first_az + n_az) of every
+ * channel.  Ray indices in ls_hit stay global.  Default: the full revolution. */
+int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az);
+
+/* Run all device work of this handle on `hip_stream` (a hipStream_t; NULL = the handle's own
+ * stream).  Lets the caller order its collectives after ls_trace_scene_async. */
+int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream);
+int ls_tracer_synchronize(ls_tracer *tr);
+
+/* Write packed points / hit records into caller-owned device buffers (capacity in records,
+ * >= ls_total_rays of the shard) instead of the handle's own; NULL restores the default. */
+int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, uint32_t *d_n_points,
+                                 uint32_t capacity);
+
+/* ---- options */
+#define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1..8), default 2; takes effect at next commit  */
+#define LS_OPT_TIMING 2         /* 1: bracket every stage with hipEvents (ls_get_timings)                 */
+#define LS_OPT_COUNT_VISITS 3   /* 1: trace kernel also counts node fetches / triangle tests              */
+#define LS_OPT_REFIT 4          /* 1: commit refits the BVH when the geometry set is unchanged
+                                 *    (OptixTracer.cpp:532-535 OPERATION_UPDATE); 0 (default): full rebuild */
+int ls_tracer_set_option(ls_tracer *tr, int option, int value);
+
+/* Stage timings of the last commit + trace, milliseconds from hipEvents on the handle's stream. */
+#define LS_T_TRANSFORM 0
+#define LS_T_MORTON 1
+#define LS_T_SORT 2
+#define LS_T_LEAVES 3
+#define LS_T_RANGE_TREE 4
+#define LS_T_HIERARCHY 5
+#define LS_T_TRACE 6
+#define LS_T_PACK 7
+#define LS_T_COUNT 8
+int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT]);
+
+/* Totals of the last trace when LS_OPT_COUNT_VISITS is on: {node fetches, triangle tests}. */
+int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[2]);
+
+/* ---- ray generation on its own: LidarDevice::allRaysGPU (LidarDeviceKernels.cu:25-126).
+ * Writes the shard's rays as SoA float arrays of n = ls_total_rays() entries each, in device
+ * memory owned by the caller: dir_x, dir_y, dir_z (origins are all zero, LidarDevice.cpp:320). */
+int ls_generate_rays(ls_tracer *tr, float *d_dir_x, float *d_dir_y, float *d_dir_z);
+
+/* ---- test / measurement hooks (used by tests/ and bench.py only) ---------------------------- */
+
+/* Dense per-ray results of the last trace, host buffers of n_rays entries (shard-local order
+ * q = v*n_az + (h-first_az)): t (< 0 = miss) and global triangle id (0xFFFFFFFF = miss). */
+int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid);
+
+/* Exhaustive closest hit on the device (every ray against every triangle, same triangle test):
+ * the full-size checker for the BVH path. */
+int ls_debug_trace_bruteforce(ls_tracer *tr, float *t, uint32_t *gid);
+
+/* Transformed (sensor-frame) vertices and rebased indices of the committed scene. */
+int ls_debug_scene_size(ls_tracer *tr, uint32_t *n_verts, uint32_t *n_tris, uint32_t *n_node_slots,
+                        uint32_t *leaf_size);
+int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx);
+
+/* BVH arrays: node slots (32 B each) and triangle records (48 B each), layouts in DESIGN.md:
+ *   node slot s: float lo[3]; uint32 left; float hi[3]; uint32 skip
+ *     even s = leaf s/2 (left = number of records, first record = (s/2)*leaf_size); odd s = internal
+ *   triangle record: float v0[3]; uint32 gid; float e1[3]; float NgC; float e2[3]; uint32 pad */
+int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARSHOOTER_HIP_H */

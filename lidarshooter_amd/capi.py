@@ -1,0 +1,303 @@
+"""ctypes binding of the C ABI in include/lidarshooter_hip.h (liblidarshooter_hip.so).
+
+Used by tests/, bench.py and __graft_entry__.py to drive the HIP library exactly the way the
+reference's C++ adapter would (one call per ITracer virtual, ITracer.hpp:50-94).  This module
+holds no algorithm: if the shared library is missing it raises, it never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblidarshooter_hip.so")
+INVALID = 0xFFFFFFFF
+
+LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_REFIT = 1, 2, 3, 4
+STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "pack")
+
+# every symbol include/lidarshooter_hip.h declares (tests/test_abi.py checks the .so exports them all)
+SYMBOLS = (
+    "ls_abi_version", "ls_tracer_create", "ls_tracer_destroy", "ls_add_geometry", "ls_remove_geometry",
+    "ls_update_geometry", "ls_update_geometry_components", "ls_update_geometry_device",
+    "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
+    "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
+    "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
+    "ls_tracer_synchronize", "ls_tracer_set_output_buffers", "ls_tracer_set_option", "ls_get_timings",
+    "ls_get_visit_counts", "ls_generate_rays", "ls_debug_dense_hits", "ls_debug_trace_bruteforce",
+    "ls_debug_scene_size", "ls_debug_download_scene", "ls_debug_download_bvh",
+)
+
+
+class SensorDesc(C.Structure):
+    _fields_ = [("vertical_deg", C.POINTER(C.c_float)), ("n_vertical", C.c_uint32), ("h_begin", C.c_float),
+                ("h_end", C.c_float), ("h_count", C.c_uint32), ("Rinv", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("points32", C.POINTER(C.c_uint8)), ("hits", C.c_void_p), ("n_points", C.c_uint32),
+                ("n_rays", C.c_uint32), ("frame", C.c_uint32), ("d_points32", C.c_void_p),
+                ("d_hits", C.c_void_p), ("d_n_points", C.c_void_p)]
+
+
+HIT_DTYPE = np.dtype([("ray", "<u4"), ("geom", "<u4"), ("prim", "<u4"), ("t", "<f4")])
+NODE_DTYPE = np.dtype([("lo", "<f4", 3), ("left", "<u4"), ("hi", "<f4", 3), ("skip", "<u4")])
+TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("gid", "<u4"), ("e1", "<f4", 3), ("NgC", "<f4"), ("e2", "<f4", 3),
+                      ("pad", "<u4")])
+
+_lib = None
+
+
+class LidarShooterHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LidarShooterHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C lidarshooter_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32, f32p, u32p = C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.ls_abi_version.restype = i32
+    L.ls_tracer_create.argtypes = [C.POINTER(SensorDesc), i32, C.POINTER(vp)]
+    L.ls_tracer_destroy.argtypes = [vp]
+    L.ls_tracer_destroy.restype = None
+    L.ls_add_geometry.argtypes = [vp, C.c_char_p, i32, i32, i32]
+    L.ls_remove_geometry.argtypes = [vp, C.c_char_p]
+    L.ls_update_geometry.argtypes = [vp, C.c_char_p, f32p, vp, u32, vp]
+    L.ls_update_geometry_components.argtypes = [vp, C.c_char_p, f32p, f32p, vp, u32, vp]
+    L.ls_update_geometry_device.argtypes = [vp, C.c_char_p, f32p, vp, u32, vp]
+    L.ls_update_geometry_transform.argtypes = [vp, C.c_char_p, f32p]
+    L.ls_commit_scene.argtypes = [vp]
+    L.ls_trace_scene.argtypes = [vp, u32, C.POINTER(Frame)]
+    L.ls_trace_scene_async.argtypes = [vp, u32, C.POINTER(Frame)]
+    L.ls_geometry_count.argtypes = [vp]
+    L.ls_geometry_count.restype = C.c_long
+    L.ls_geometry_id.argtypes = [vp, C.c_char_p]
+    L.ls_vertex_count.argtypes = [vp, C.c_char_p]
+    L.ls_vertex_count.restype = C.c_long
+    L.ls_element_count.argtypes = [vp, C.c_char_p]
+    L.ls_element_count.restype = C.c_long
+    L.ls_total_rays.argtypes = [vp]
+    L.ls_total_rays.restype = u32
+    L.ls_total_channels.argtypes = [vp]
+    L.ls_total_channels.restype = u32
+    L.ls_last_error.argtypes = [vp]
+    L.ls_last_error.restype = C.c_char_p
+    L.ls_tracer_set_shard.argtypes = [vp, u32, u32]
+    L.ls_tracer_set_stream.argtypes = [vp, vp]
+    L.ls_tracer_synchronize.argtypes = [vp]
+    L.ls_tracer_set_output_buffers.argtypes = [vp, vp, vp, vp, u32]
+    L.ls_tracer_set_option.argtypes = [vp, i32, i32]
+    L.ls_get_timings.argtypes = [vp, f32p]
+    L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ls_generate_rays.argtypes = [vp, vp, vp, vp]
+    L.ls_debug_dense_hits.argtypes = [vp, f32p, u32p]
+    L.ls_debug_trace_bruteforce.argtypes = [vp, f32p, u32p]
+    L.ls_debug_scene_size.argtypes = [vp, u32p, u32p, u32p, u32p]
+    L.ls_debug_download_scene.argtypes = [vp, vp, vp]
+    L.ls_debug_download_bvh.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+IDENTITY_AFFINE = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+
+
+class Tracer:
+    """Thin object wrapper over an ls_tracer handle; method names follow ITracer."""
+
+    def __init__(self, vertical_deg, h_begin, h_end, h_count, Rinv, t, device: int = 0):
+        self.L = load()
+        self._vert = np.ascontiguousarray(vertical_deg, np.float32)
+        sd = SensorDesc()
+        sd.vertical_deg = _f32p(self._vert)
+        sd.n_vertical = self._vert.shape[0]
+        sd.h_begin, sd.h_end, sd.h_count = float(h_begin), float(h_end), int(h_count)
+        sd.Rinv = (C.c_float * 9)(*[float(x) for x in np.asarray(Rinv, np.float32).reshape(9)])
+        sd.t = (C.c_float * 3)(*[float(x) for x in np.asarray(t, np.float32).reshape(3)])
+        self.V, self.H = int(sd.n_vertical), int(h_count)
+        self.az0, self.naz = 0, self.H
+        h = C.c_void_p()
+        rc = self.L.ls_tracer_create(C.byref(sd), device, C.byref(h))
+        if rc != 0:
+            raise LidarShooterHipError(f"ls_tracer_create failed with status {rc} (no HIP device / bad sensor)")
+        self.h = h
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ls_tracer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0 and rc != -1:
+            raise LidarShooterHipError(f"{what}: status {rc}: {self.last_error()}")
+        return rc
+
+    def last_error(self) -> str:
+        return (self.L.ls_last_error(self.h) or b"").decode()
+
+    # ---- ITracer surface
+    def addGeometry(self, name: str, n_vertices: int, n_elements: int, geometry_type: int = 0) -> int:
+        return self.L.ls_add_geometry(self.h, name.encode(), geometry_type, int(n_vertices), int(n_elements))
+
+    def removeGeometry(self, name: str) -> int:
+        return self.L.ls_remove_geometry(self.h, name.encode())
+
+    def updateGeometry(self, name: str, affine, verts: np.ndarray, tris: np.ndarray | None, stride: int | None = None):
+        A = np.ascontiguousarray(affine, np.float32).reshape(12)
+        verts = np.ascontiguousarray(verts)
+        if stride is None:
+            verts = np.ascontiguousarray(verts, np.float32)
+            stride = 12
+        tp = None
+        if tris is not None:
+            tris = np.ascontiguousarray(tris, np.uint32)
+            tp = tris.ctypes.data
+        return self._check(self.L.ls_update_geometry(self.h, name.encode(), _f32p(A), verts.ctypes.data, stride, tp),
+                           "ls_update_geometry")
+
+    def updateGeometryComponents(self, name: str, lin, ang, verts: np.ndarray, tris: np.ndarray | None):
+        lin = np.ascontiguousarray(lin, np.float32)
+        ang = np.ascontiguousarray(ang, np.float32)
+        verts = np.ascontiguousarray(verts, np.float32)
+        tp = None
+        if tris is not None:
+            tris = np.ascontiguousarray(tris, np.uint32)
+            tp = tris.ctypes.data
+        return self._check(self.L.ls_update_geometry_components(self.h, name.encode(), _f32p(lin), _f32p(ang),
+                                                                verts.ctypes.data, 12, tp),
+                           "ls_update_geometry_components")
+
+    def updateGeometryDevice(self, name: str, affine, d_verts: int, stride: int, d_tris: int | None):
+        A = np.ascontiguousarray(affine, np.float32).reshape(12)
+        return self._check(self.L.ls_update_geometry_device(self.h, name.encode(), _f32p(A), d_verts, stride, d_tris),
+                           "ls_update_geometry_device")
+
+    def updateGeometryTransform(self, name: str, affine):
+        A = np.ascontiguousarray(affine, np.float32).reshape(12)
+        return self._check(self.L.ls_update_geometry_transform(self.h, name.encode(), _f32p(A)),
+                           "ls_update_geometry_transform")
+
+    def commitScene(self) -> int:
+        return self._check(self.L.ls_commit_scene(self.h), "ls_commit_scene")
+
+    def traceScene(self, frame_index: int = 0):
+        """-> (rc, points uint8[n,32], hits HIT_DTYPE[n]) copied out of the handle's pinned buffers."""
+        fr = Frame()
+        rc = self._check(self.L.ls_trace_scene(self.h, frame_index, C.byref(fr)), "ls_trace_scene")
+        n = int(fr.n_points)
+        if n:
+            pts = np.ctypeslib.as_array(fr.points32, shape=(n * 32,)).reshape(n, 32).copy()
+            hits = np.frombuffer(C.string_at(fr.hits, n * 16), dtype=HIT_DTYPE).copy()
+        else:
+            pts = np.zeros((0, 32), np.uint8)
+            hits = np.zeros(0, HIT_DTYPE)
+        self.last_frame = fr
+        return rc, pts, hits
+
+    def traceSceneAsync(self, frame_index: int = 0) -> Frame:
+        fr = Frame()
+        self._check(self.L.ls_trace_scene_async(self.h, frame_index, C.byref(fr)), "ls_trace_scene_async")
+        return fr
+
+    def getGeometryCount(self) -> int:
+        return int(self.L.ls_geometry_count(self.h))
+
+    def getGeometryId(self, name: str) -> int:
+        return self.L.ls_geometry_id(self.h, name.encode())
+
+    def getVertexCount(self, name: str) -> int:
+        return int(self.L.ls_vertex_count(self.h, name.encode()))
+
+    def getElementCount(self, name: str) -> int:
+        return int(self.L.ls_element_count(self.h, name.encode()))
+
+    def getTotalRays(self) -> int:
+        return int(self.L.ls_total_rays(self.h))
+
+    # ---- extensions
+    def setShard(self, first_az: int, n_az: int):
+        rc = self._check(self.L.ls_tracer_set_shard(self.h, first_az, n_az), "ls_tracer_set_shard")
+        self.az0, self.naz = first_az, n_az
+        return rc
+
+    def setStream(self, stream_ptr: int | None):
+        return self._check(self.L.ls_tracer_set_stream(self.h, stream_ptr), "ls_tracer_set_stream")
+
+    def synchronize(self):
+        return self._check(self.L.ls_tracer_synchronize(self.h), "ls_tracer_synchronize")
+
+    def setOutputBuffers(self, d_points: int | None, d_hits: int | None, d_n: int | None, capacity: int):
+        return self._check(self.L.ls_tracer_set_output_buffers(self.h, d_points, d_hits, d_n, capacity),
+                           "ls_tracer_set_output_buffers")
+
+    def setOption(self, option: int, value: int):
+        return self._check(self.L.ls_tracer_set_option(self.h, option, value), "ls_tracer_set_option")
+
+    def timings(self) -> dict:
+        ms = np.zeros(len(STAGES), np.float32)
+        self._check(self.L.ls_get_timings(self.h, _f32p(ms)), "ls_get_timings")
+        return dict(zip(STAGES, [float(x) for x in ms]))
+
+    def visitCounts(self):
+        c = (C.c_uint64 * 2)()
+        self._check(self.L.ls_get_visit_counts(self.h, c), "ls_get_visit_counts")
+        return int(c[0]), int(c[1])
+
+    def generateRays(self, d_dx: int, d_dy: int, d_dz: int):
+        return self._check(self.L.ls_generate_rays(self.h, d_dx, d_dy, d_dz), "ls_generate_rays")
+
+    # ---- test hooks
+    def denseHits(self):
+        n = self.getTotalRays()
+        t = np.zeros(n, np.float32)
+        gid = np.zeros(n, np.uint32)
+        self._check(self.L.ls_debug_dense_hits(self.h, _f32p(t), gid.ctypes.data_as(C.POINTER(C.c_uint32))),
+                    "ls_debug_dense_hits")
+        return t, gid
+
+    def bruteForce(self):
+        n = self.getTotalRays()
+        t = np.zeros(n, np.float32)
+        gid = np.zeros(n, np.uint32)
+        self._check(self.L.ls_debug_trace_bruteforce(self.h, _f32p(t), gid.ctypes.data_as(C.POINTER(C.c_uint32))),
+                    "ls_debug_trace_bruteforce")
+        return t, gid
+
+    def sceneSize(self):
+        v = [C.c_uint32() for _ in range(4)]
+        self._check(self.L.ls_debug_scene_size(self.h, *[C.byref(x) for x in v]), "ls_debug_scene_size")
+        return dict(n_verts=v[0].value, n_tris=v[1].value, n_slots=v[2].value, leaf_size=v[3].value)
+
+    def downloadScene(self):
+        s = self.sceneSize()
+        verts = np.zeros((s["n_verts"], 3), np.float32)
+        tris = np.zeros((s["n_tris"], 3), np.uint32)
+        self._check(self.L.ls_debug_download_scene(self.h, verts.ctypes.data, tris.ctypes.data), "ls_debug_download_scene")
+        return verts, tris
+
+    def downloadBvh(self):
+        s = self.sceneSize()
+        nodes = np.zeros(s["n_slots"], NODE_DTYPE)
+        tri = np.zeros(s["n_tris"], TRI_DTYPE)
+        self._check(self.L.ls_debug_download_bvh(self.h, nodes.ctypes.data, tri.ctypes.data), "ls_debug_download_bvh")
+        return nodes, tri, s["leaf_size"]

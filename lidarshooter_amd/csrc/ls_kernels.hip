@@ -1,0 +1,659 @@
+// ls_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LiDAR tracer hot path.
+//
+// Compiled with -ffp-contract=off: every float operation rounds once and fused multiply-adds are
+// explicit fmaf() calls, so the arithmetic below is the same operation sequence as the CPU oracle
+// (oracle/ls_oracle.c) and ids/t can be compared bit for bit.
+//
+// Reference functions replaced (paths relative to /root/reference/ros_ws/src/lidarshooter/src/):
+//   k_transform ........ MeshTransformer::transformIntoBuffer (MeshTransformer.cpp:142-205) +
+//                        LidarDevice::originToSensor (LidarDevice.cpp:383-391)
+//   k_morton/k_leaves/k_range_*/k_hierarchy ... rtcCommitScene (EmbreeTracer.cpp:290-295) /
+//                        OptixTracer::buildAccelStructure (OptixTracer.cpp:517-571)
+//   k_trace ............ LidarDevice::nextRay16 (LidarDevice.cpp:294-342) + rtcIntersect16
+//                        (EmbreeTracer.cpp:472-480) / allRaysGPUKernel + __raygen__rg
+//                        (LidarDeviceKernels.cu:25-52, OptixTracerModules.cu:26-72)
+//   k_pack ............. XYZIRBytes::addToCloud (XYZIRBytes.cpp:24-40) / addPointsToCloud
+//                        (OptixTracer.cpp:895-942)
+#include "ls_kernels.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace ls {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kSlabPad = 1.0000004f;  // 1 + 3 ulp on the far slab distance (robust traversal)
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+// Embree common/math/vec3.h: cross = (msub(a.y,b.z,a.z*b.y), msub(a.z,b.x,a.x*b.z), msub(a.x,b.y,a.y*b.x))
+__device__ __forceinline__ V3 cross_fma(V3 a, V3 b)
+{
+    return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+}
+// dot = madd(a.x,b.x,madd(a.y,b.y,a.z*b.z))
+__device__ __forceinline__ float dot_fma(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ float xor_sign(float f, uint32_t s) { return __uint_as_float(__float_as_uint(f) ^ s); }
+
+__device__ __forceinline__ float safe_inv(float d)
+{
+    // |d| < 1e-30 -> +-1e-30 keeps 1/d finite (azimuth 0 has dir.y == 0 exactly)
+    return 1.0f / (fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d);
+}
+
+// Embree 3.13.4 Moeller-Trumbore test (triangle_intersector_moeller.h) for a ray from the origin,
+// against a record holding v0, e1 = v0-v1, e2 = v2-v0 and NgC = dot(cross(e2,e1), v0).
+// tnear = 0 (strict), no upper bound here: the caller keeps the closest.
+__device__ __forceinline__ bool tri_test(V3 d, V3 v0, V3 e1, V3 e2, float NgC, float &t)
+{
+    const V3 Ng = cross_fma(e2, e1);
+    const V3 R = cross_fma(v0, d);
+    const float den = dot_fma(Ng, d);
+    const float absDen = fabsf(den);
+    const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    const float U = xor_sign(dot_fma(R, e2), sgn);
+    const float V = xor_sign(dot_fma(R, e1), sgn);
+    const float T = xor_sign(NgC, sgn);
+    const bool ok = (den != 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= absDen) & (0.0f < T);
+    if (ok) t = T / absDen;
+    return ok;
+}
+
+struct Affine { float a[12]; float rinv[9]; float t[3]; };
+
+// ------------------------------------------------------------------------------------------
+// Vertex transform into the sensor frame:  p' = Rinv * ((A * v) - t).  One thread per vertex;
+// also folds max |coordinate| of the scene into *maxabs (bits of a non-negative float).
+// Algorithmic bytes per vertex: stride (read) + 12 (write).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_transform(const uint8_t *__restrict__ raw, uint32_t stride, uint32_t n,
+                                                      Affine m, float *__restrict__ out,
+                                                      uint32_t *__restrict__ maxabs)
+{
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    float mx = 0.0f;
+    if (j < n) {
+        const float *p = reinterpret_cast<const float *>(raw + (size_t)j * stride);
+        const float x = p[0], y = p[1], z = p[2];
+        float q[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            q[i] = ((m.a[4 * i + 0] * x + m.a[4 * i + 1] * y) + m.a[4 * i + 2] * z) + m.a[4 * i + 3];
+        const float a = q[0] - m.t[0], b = q[1] - m.t[1], c = q[2] - m.t[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float o = (m.rinv[3 * i + 0] * a + m.rinv[3 * i + 1] * b) + m.rinv[3 * i + 2] * c;
+            out[3 * (size_t)j + i] = o;
+            mx = fmaxf(mx, fabsf(o));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(maxabs, __float_as_uint(mx));
+}
+
+__global__ __launch_bounds__(kBlock) void k_rebase(const uint32_t *__restrict__ idx, uint32_t n, uint32_t vbase,
+                                                   uint32_t *__restrict__ out)
+{
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j < n) out[j] = idx[j] + vbase;
+}
+
+// ------------------------------------------------------------------------------------------
+// Sensor-centred sign-magnitude Morton keys (30 bits): [sx sy sz | 9-bit |x|,|y|,|z| interleaved].
+// Every ray starts at the sensor origin, so (a) a ray stays inside one sign octant and (b) inside
+// an octant the Morton order of |coordinate| is front-to-back for EVERY ray: the left-to-right
+// depth-first order of the radix tree is the traversal order, which is what lets the trace
+// kernel run stackless on skip links.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_morton(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
+                                                   uint32_t ntris, const uint32_t *__restrict__ maxabs,
+                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ntris) return;
+    const float m = __uint_as_float(*maxabs);
+    const float scale = m > 0.0f ? 512.0f / m : 0.0f;
+    const uint32_t i0 = tris[3 * (size_t)k + 0], i1 = tris[3 * (size_t)k + 1], i2 = tris[3 * (size_t)k + 2];
+    uint32_t key = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float p0 = verts[3 * (size_t)i0 + a], p1 = verts[3 * (size_t)i1 + a], p2 = verts[3 * (size_t)i2 + a];
+        const float c = 0.5f * (fminf(p0, fminf(p1, p2)) + fmaxf(p0, fmaxf(p1, p2)));
+        const uint32_t q = min(511u, (uint32_t)(fabsf(c) * scale));
+        key |= expand_bits(q) << (2 - a);
+        key |= (c < 0.0f ? 1u : 0u) << (29 - a);
+    }
+    keys[k] = key;
+    vals[k] = k;
+}
+
+// ------------------------------------------------------------------------------------------
+// Triangle records + leaf boxes, one thread per Morton-sorted position.
+// Leaf k = records [k*g, k*g+g); its box (padded, see below) goes to node slot 2k.
+// Bytes per triangle: 4 (sorted id) + 12 (indices) + 36 (vertices) read, 48 written, + 32/g.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_leaves(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
+                                                   const uint32_t *__restrict__ sorted_vals, uint32_t ntris,
+                                                   uint32_t g, TriRecord *__restrict__ records,
+                                                   Node *__restrict__ nodes)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (p < ntris) {
+        const uint32_t gid = sorted_vals[p];
+        const uint32_t i0 = tris[3 * (size_t)gid + 0], i1 = tris[3 * (size_t)gid + 1], i2 = tris[3 * (size_t)gid + 2];
+        const V3 v0 = {verts[3 * (size_t)i0], verts[3 * (size_t)i0 + 1], verts[3 * (size_t)i0 + 2]};
+        const V3 v1 = {verts[3 * (size_t)i1], verts[3 * (size_t)i1 + 1], verts[3 * (size_t)i1 + 2]};
+        const V3 v2 = {verts[3 * (size_t)i2], verts[3 * (size_t)i2 + 1], verts[3 * (size_t)i2 + 2]};
+        const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
+        const V3 Ng = cross_fma(e2, e1);
+        const float NgC = dot_fma(Ng, v0);
+        float4 *r = reinterpret_cast<float4 *>(records + p);
+        r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
+        r[1] = make_float4(e1.x, e1.y, e1.z, NgC);
+        r[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        // The triangle test accepts rays that miss the exact triangle by rounding error, so boxes
+        // are fattened by 2^-16 of the largest |coordinate|: BVH result == exhaustive result.
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v1.x))),
+                              fmaxf(fmaxf(fmaxf(fabsf(v1.y), fabsf(v1.z)), fmaxf(fabsf(v2.x), fabsf(v2.y))),
+                                    fabsf(v2.z)));
+        const float pad = m * 0x1p-16f;
+        lo[0] = fminf(v0.x, fminf(v1.x, v2.x)) - pad; hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x)) + pad;
+        lo[1] = fminf(v0.y, fminf(v1.y, v2.y)) - pad; hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y)) + pad;
+        lo[2] = fminf(v0.z, fminf(v1.z, v2.z)) - pad; hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z)) + pad;
+    }
+    for (uint32_t off = 1; off < g; off <<= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+    }
+    if (p < ntris && (p % g) == 0) {
+        const uint32_t k = p / g;
+        const uint32_t cnt = min(g, ntris - p);
+        float4 *nd = reinterpret_cast<float4 *>(nodes + 2 * (size_t)k);
+        nd[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(cnt));
+        nd[1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(kInvalid));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Aligned-range tree: entry j of level l bounds leaves [j<<l, (j+1)<<l).  Level 0 is the leaf
+// node slots.  k_range_bottom builds levels 1..9 for 512 leaves per block in LDS; k_range_top
+// finishes the (few) remaining levels in one block.  No atomics, no cross-workgroup hand-off.
+// ------------------------------------------------------------------------------------------
+struct Box { float lo[3], hi[3]; };
+
+__device__ __forceinline__ Box box_empty() { return {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}}; }
+__device__ __forceinline__ void box_merge(Box &a, const Box &b)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a.lo[i] = fminf(a.lo[i], b.lo[i]); a.hi[i] = fmaxf(a.hi[i], b.hi[i]); }
+}
+__device__ __forceinline__ Box load_leaf_box(const Node *nodes, uint32_t k)
+{
+    const float4 *nd = reinterpret_cast<const float4 *>(nodes + 2 * (size_t)k);
+    const float4 a = nd[0], b = nd[1];
+    return {{a.x, a.y, a.z}, {b.x, b.y, b.z}};
+}
+__device__ __forceinline__ Box load_level_box(const float4 *boxes, uint32_t e)
+{
+    const float4 a = boxes[2 * (size_t)e], b = boxes[2 * (size_t)e + 1];
+    return {{a.x, a.y, a.z}, {b.x, b.y, b.z}};
+}
+__device__ __forceinline__ void store_level_box(float4 *boxes, uint32_t e, const Box &b)
+{
+    boxes[2 * (size_t)e] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.0f);
+    boxes[2 * (size_t)e + 1] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.0f);
+}
+
+constexpr int kBottomLevels = 9;  // 512 leaves per block
+
+__global__ __launch_bounds__(kBlock) void k_range_bottom(const Node *__restrict__ nodes, RangeTree rt,
+                                                         float4 *__restrict__ boxes)
+{
+    __shared__ float s[6][kBlock];
+    const uint32_t t = threadIdx.x;
+    const uint32_t base0 = blockIdx.x * 512u;
+    Box b = box_empty();
+    {
+        const uint32_t k0 = base0 + 2 * t;
+        if (k0 < rt.count[0]) b = load_leaf_box(nodes, k0);
+        if (k0 + 1 < rt.count[0]) { const Box c = load_leaf_box(nodes, k0 + 1); box_merge(b, c); }
+    }
+    for (uint32_t l = 1; l <= (uint32_t)kBottomLevels && l < rt.levels; ++l) {
+        const uint32_t n = 512u >> l;  // entries of this level owned by the block
+        if (t < n) {
+            const uint32_t j = (base0 >> l) + t;
+            if (j < rt.count[l]) store_level_box(boxes, rt.offset[l] + j, b);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { s[i][t] = b.lo[i]; s[3 + i][t] = b.hi[i]; }
+        }
+        __syncthreads();
+        if (t < (n >> 1)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                b.lo[i] = fminf(s[i][2 * t], s[i][2 * t + 1]);
+                b.hi[i] = fmaxf(s[3 + i][2 * t], s[3 + i][2 * t + 1]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_range_top(RangeTree rt, float4 *__restrict__ boxes)
+{
+    for (uint32_t l = kBottomLevels + 1; l < rt.levels; ++l) {
+        for (uint32_t j = threadIdx.x; j < rt.count[l]; j += kBlock) {
+            Box b = load_level_box(boxes, rt.offset[l - 1] + 2 * j);
+            if (2 * j + 1 < rt.count[l - 1]) { const Box c = load_level_box(boxes, rt.offset[l - 1] + 2 * j + 1); box_merge(b, c); }
+            store_level_box(boxes, rt.offset[l] + j, b);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Radix-tree hierarchy (Karras 2012) over the leaf keys, one thread per leaf index i:
+//   internal node i (i < L-1) lives in slot 2i+1, leaf i in slot 2i, so a subtree over leaves
+//   [l,r] occupies the contiguous slots [2l, 2r].  Each thread finds its node's range and split
+//   from the keys alone, takes the node's box from the aligned-range tree (no bottom-up pass, no
+//   atomics) and derives the skip link locally: the subtree that follows range [.,r] in
+//   depth-first order starts at leaf r+1 and is internal node r+1 iff that node's range starts
+//   there (direction +1), else leaf r+1.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int delta(const uint32_t *__restrict__ keys, uint32_t g, int L, int i, uint32_t ki, int j)
+{
+    if (j < 0 || j >= L) return -1;
+    const uint32_t x = ki ^ keys[(size_t)j * g];
+    return x ? __clz(x) : 32 + __clz((uint32_t)i ^ (uint32_t)j);
+}
+
+__device__ __forceinline__ uint32_t skip_after(const uint32_t *__restrict__ keys, uint32_t g, int L, int r)
+{
+    if (r >= L - 1) return kInvalid;
+    const int q = r + 1;
+    if (q <= L - 2) {
+        const uint32_t kq = keys[(size_t)q * g];
+        if (delta(keys, g, L, q, kq, q + 1) > delta(keys, g, L, q, kq, q - 1)) return 2u * (uint32_t)q + 1u;
+    }
+    return 2u * (uint32_t)q;
+}
+
+__global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict__ keys, uint32_t L_, uint32_t g,
+                                                      RangeTree rt, const float4 *__restrict__ boxes,
+                                                      Node *__restrict__ nodes)
+{
+    const int L = (int)L_;
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= L) return;
+    // leaf i: skip link only (box and count were written by k_leaves)
+    nodes[2 * (size_t)i].skip = skip_after(keys, g, L, i);
+    if (i >= L - 1) return;
+
+    const uint32_t ki = keys[(size_t)i * g];
+    const int d = delta(keys, g, L, i, ki, i + 1) > delta(keys, g, L, i, ki, i - 1) ? 1 : -1;
+    const int dmin = delta(keys, g, L, i, ki, i - d);
+    int lmax = 2;
+    while (delta(keys, g, L, i, ki, i + lmax * d) > dmin) lmax <<= 1;
+    int len = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, g, L, i, ki, i + (len + t) * d) > dmin) len += t;
+    const int j = i + len * d;
+    const int dnode = delta(keys, g, L, i, ki, j);
+    int s = 0, t = len;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, g, L, i, ki, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int l = min(i, j), r = max(i, j);
+    const uint32_t left = (l == gamma) ? 2u * (uint32_t)gamma : 2u * (uint32_t)gamma + 1u;
+
+    // box of leaves [l, r] from the aligned-range tree
+    Box b = box_empty();
+    uint32_t a = (uint32_t)l, e = (uint32_t)r + 1u, lev = 0;
+    while (a < e) {
+        if (a & 1u) {
+            const Box c = lev ? load_level_box(boxes, rt.offset[lev] + a) : load_leaf_box(nodes, a);
+            box_merge(b, c);
+            ++a;
+        }
+        if (e & 1u) {
+            --e;
+            const Box c = lev ? load_level_box(boxes, rt.offset[lev] + e) : load_leaf_box(nodes, e);
+            box_merge(b, c);
+        }
+        a >>= 1; e >>= 1; ++lev;
+    }
+    float4 *nd = reinterpret_cast<float4 *>(nodes + 2 * (size_t)i + 1);
+    nd[0] = make_float4(b.lo[0], b.lo[1], b.lo[2], __uint_as_float(left));
+    nd[1] = make_float4(b.hi[0], b.hi[1], b.hi[2], __uint_as_float(skip_after(keys, g, L, r)));
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused ray generation + closest-hit traversal.  One lane per ray; a wave is 64 consecutive
+// azimuth columns of one channel (coherent rays -> its node fetches share cache lines); a block
+// is 4 adjacent channels.  Blocks are dealt to XCDs round-robin by the hardware, so the tile
+// index is remapped to give each XCD a contiguous azimuth sector (its L2 then holds that sector's
+// part of the BVH).  Traversal is stackless: follow `left` on a box hit, `skip` otherwise.
+// Outputs (padded row layout, row = channel*n_az_blocks + az_block, 64 entries per row):
+//   t_out / gid_out per ray, row_counts[row] = hits in the row (feeds the ordered pack).
+// ------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, const Node *__restrict__ nodes,
+                                                  const TriRecord *__restrict__ records, uint32_t nslots,
+                                                  uint32_t g, float *__restrict__ t_out,
+                                                  uint32_t *__restrict__ gid_out, uint32_t *__restrict__ row_counts,
+                                                  unsigned long long *__restrict__ visit_counts)
+{
+    const uint32_t n_cg = (tb.V + 3u) >> 2;  // channel groups of 4
+    const uint32_t n_tiles = tb.n_az_blocks * n_cg;
+    uint32_t tile = blockIdx.x;
+    if ((n_tiles & 7u) == 0) tile = (blockIdx.x & 7u) * (n_tiles >> 3) + (blockIdx.x >> 3);
+    const uint32_t ab = tile / n_cg, cg = tile - ab * n_cg;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t v = __builtin_amdgcn_readfirstlane(cg * 4u + (threadIdx.x >> 6));
+    if (v >= tb.V) return;
+    const uint32_t hl = ab * 64u + lane;  // shard-local azimuth column
+    const bool active = hl < tb.naz;
+    const uint32_t h = tb.az0 + (active ? hl : 0u);
+
+    // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
+    const float st = tb.sin_theta[v], ct = tb.cos_theta[v];
+    const V3 d = {st * tb.cos_phi[h], st * tb.sin_phi[h], ct};
+    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+
+    float best = INFINITY;
+    uint32_t bid = kInvalid;
+    uint32_t n = active && nslots ? (nslots > 1u ? 1u : 0u) : kInvalid;
+    uint32_t cn = 0, ctri = 0;
+    const float4 *nodes4 = reinterpret_cast<const float4 *>(nodes);
+    const float4 *rec4 = reinterpret_cast<const float4 *>(records);
+
+    while (n != kInvalid) {
+        const float4 A = nodes4[2 * (size_t)n], B = nodes4[2 * (size_t)n + 1];
+        if (COUNT) ++cn;
+        const float x1 = A.x * ix, x2 = B.x * ix, y1 = A.y * iy, y2 = B.y * iy, z1 = A.z * iz, z2 = B.z * iz;
+        const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
+        const float tf = fminf(fminf(fmaxf(x1, x2) * kSlabPad, fmaxf(y1, y2) * kSlabPad),
+                               fminf(fmaxf(z1, z2) * kSlabPad, best));
+        const uint32_t skip = __float_as_uint(B.w);
+        if (!(tn <= tf)) { n = skip; continue; }
+        const uint32_t left = __float_as_uint(A.w);
+        if (n & 1u) { n = left; continue; }
+        const uint32_t first = (n >> 1) * g;
+        for (uint32_t s = first; s < first + left; ++s) {
+            const float4 r0 = rec4[3 * (size_t)s], r1 = rec4[3 * (size_t)s + 1], r2 = rec4[3 * (size_t)s + 2];
+            if (COUNT) ++ctri;
+            float t;
+            if (tri_test(d, {r0.x, r0.y, r0.z}, {r1.x, r1.y, r1.z}, {r2.x, r2.y, r2.z}, r1.w, t)) {
+                const uint32_t id = __float_as_uint(r0.w);
+                if (t < best || (t == best && id < bid)) { best = t; bid = id; }
+            }
+        }
+        n = skip;
+    }
+
+    const uint32_t row = v * tb.n_az_blocks + ab;
+    const size_t o = (size_t)row * 64u + lane;
+    t_out[o] = (bid == kInvalid) ? -1.0f : best;
+    gid_out[o] = bid;
+    const unsigned long long hits = __ballot(bid != kInvalid);
+    if (lane == 0) row_counts[row] = (uint32_t)__popcll(hits);
+    if (COUNT) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { cn += __shfl_xor(cn, off); ctri += __shfl_xor(ctri, off); }
+        if (lane == 0) { atomicAdd(&visit_counts[0], (unsigned long long)cn); atomicAdd(&visit_counts[1], (unsigned long long)ctri); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Ordered pack: one thread per padded ray slot; block b owns rows [4b, 4b+4).  Its output offset
+// is the sum of the row counts before it (each block reduces its own prefix: no scan kernel, no
+// cross-block hand-off).  Emits the 32-byte PointCloud2 record and the 16-byte ls_hit, both in
+// ray-index order.  Bytes per hit: 8 (t,gid) + 48 written.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *__restrict__ t_in,
+                                                 const uint32_t *__restrict__ gid_in,
+                                                 const uint32_t *__restrict__ row_counts, GeomTable gt,
+                                                 float4 *__restrict__ points, uint4 *__restrict__ hits,
+                                                 uint32_t *__restrict__ n_points)
+{
+    __shared__ uint32_t s_part[kBlock / 64];
+    __shared__ uint32_t s_rows[4];
+    const uint32_t n_rows = tb.V * tb.n_az_blocks;
+    const uint32_t row0 = blockIdx.x * 4u;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+
+    uint32_t acc = 0;
+    for (uint32_t r = threadIdx.x; r < row0; r += kBlock) acc += row_counts[r];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) s_part[w] = acc;
+    if (threadIdx.x < 4) s_rows[threadIdx.x] = (row0 + threadIdx.x < n_rows) ? row_counts[row0 + threadIdx.x] : 0u;
+    __syncthreads();
+    uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    for (uint32_t k = 0; k < w; ++k) base += s_rows[k];
+
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        uint32_t total = base;  // w == 0 here
+        for (uint32_t k = 0; k < 4; ++k) total += s_rows[k];
+        *n_points = total;
+    }
+
+    const uint32_t row = row0 + w;
+    if (row >= n_rows) return;
+    const size_t o = (size_t)row * 64u + lane;
+    const uint32_t gid = gid_in[o];
+    const bool hit = gid != kInvalid;
+    const unsigned long long m = __ballot(hit);
+    if (!hit) return;
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t dst = base + rank;
+
+    const uint32_t v = row / tb.n_az_blocks, ab = row - v * tb.n_az_blocks;
+    const uint32_t h = tb.az0 + ab * 64u + lane;
+    const float t = t_in[o];
+    const float st = tb.sin_theta[v];
+    const float dx = st * tb.cos_phi[h], dy = st * tb.sin_phi[h], dz = tb.cos_theta[v];
+    // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
+    points[2 * (size_t)dst] = make_float4(t * dx, t * dy, t * dz, 0.0f);
+    points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+    // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
+    uint32_t lo = 0, hi = gt.n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
+    }
+    hits[dst] = make_uint4(v * tb.H + h, gt.geom_ids[lo], gid - gt.tri_first[lo], __float_as_uint(t));
+}
+
+// LidarDevice::allRaysGPU (LidarDeviceKernels.cu:25-52): directions as SoA, shard-compact order.
+__global__ __launch_bounds__(kBlock) void k_raygen(SensorTables tb, float *__restrict__ dx, float *__restrict__ dy,
+                                                   float *__restrict__ dz)
+{
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= tb.V * tb.naz) return;
+    const uint32_t v = q / tb.naz, h = tb.az0 + (q - v * tb.naz);
+    const float st = tb.sin_theta[v];
+    dx[q] = st * tb.cos_phi[h];
+    dy[q] = st * tb.sin_phi[h];
+    dz[q] = tb.cos_theta[v];
+}
+
+// ------------------------------------------------------------------------------------------
+// Exhaustive checker: every ray against every triangle straight from the scene arrays (does not
+// touch the BVH or the triangle records).  Triangles are staged through LDS 256 at a time.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_bruteforce(SensorTables tb, const float *__restrict__ verts,
+                                                       const uint32_t *__restrict__ tris, uint32_t ntris,
+                                                       float *__restrict__ t_out, uint32_t *__restrict__ gid_out)
+{
+    __shared__ float s[kBlock][10];
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t nq = tb.V * tb.naz;
+    const bool active = q < nq;
+    const uint32_t qq = active ? q : 0u;
+    const uint32_t v = qq / tb.naz, h = tb.az0 + (qq - v * tb.naz);
+    const float st = tb.sin_theta[v];
+    const V3 d = {st * tb.cos_phi[h], st * tb.sin_phi[h], tb.cos_theta[v]};
+    float best = INFINITY;
+    uint32_t bid = kInvalid;
+    for (uint32_t base = 0; base < ntris; base += kBlock) {
+        const uint32_t k = base + threadIdx.x;
+        __syncthreads();
+        if (k < ntris) {
+            const uint32_t i0 = tris[3 * (size_t)k], i1 = tris[3 * (size_t)k + 1], i2 = tris[3 * (size_t)k + 2];
+            const V3 v0 = {verts[3 * (size_t)i0], verts[3 * (size_t)i0 + 1], verts[3 * (size_t)i0 + 2]};
+            const V3 v1 = {verts[3 * (size_t)i1], verts[3 * (size_t)i1 + 1], verts[3 * (size_t)i1 + 2]};
+            const V3 v2 = {verts[3 * (size_t)i2], verts[3 * (size_t)i2 + 1], verts[3 * (size_t)i2 + 2]};
+            const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
+            const float NgC = dot_fma(cross_fma(e2, e1), v0);
+            float *o = s[threadIdx.x];
+            o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = e1.x; o[4] = e1.y; o[5] = e1.z;
+            o[6] = e2.x; o[7] = e2.y; o[8] = e2.z; o[9] = NgC;
+        }
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)kBlock, ntris - base);
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const float *o = s[j];
+            float t;
+            if (tri_test(d, {o[0], o[1], o[2]}, {o[3], o[4], o[5]}, {o[6], o[7], o[8]}, o[9], t)) {
+                if (t < best) { best = t; bid = base + j; }  // ascending ids: ties keep the lowest
+            }
+        }
+    }
+    if (active) {
+        t_out[q] = (bid == kInvalid) ? -1.0f : best;
+        gid_out[q] = bid;
+    }
+}
+
+inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+}  // namespace
+
+// ---- launch wrappers -----------------------------------------------------------------------
+void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t n, const float *affine12,
+                      const float *rinv9, const float *t3, float *out_xyz, uint32_t *d_maxabs_bits)
+{
+    if (!n) return;
+    Affine m;
+    for (int i = 0; i < 12; ++i) m.a[i] = affine12[i];
+    for (int i = 0; i < 9; ++i) m.rinv[i] = rinv9[i];
+    for (int i = 0; i < 3; ++i) m.t[i] = t3[i];
+    hipLaunchKernelGGL(k_transform, dim3(blocks_for(n)), dim3(kBlock), 0, s, static_cast<const uint8_t *>(raw),
+                       stride, n, m, out_xyz, d_maxabs_bits);
+}
+
+void launch_rebase(hipStream_t s, const uint32_t *idx, uint32_t n_idx, uint32_t vbase, uint32_t *out)
+{
+    if (!n_idx) return;
+    hipLaunchKernelGGL(k_rebase, dim3(blocks_for(n_idx)), dim3(kBlock), 0, s, idx, n_idx, vbase, out);
+}
+
+void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint32_t ntris,
+                   const uint32_t *d_maxabs_bits, uint32_t *keys, uint32_t *vals)
+{
+    if (!ntris) return;
+    hipLaunchKernelGGL(k_morton, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, ntris, d_maxabs_bits,
+                       keys, vals);
+}
+
+size_t sort_temp_bytes(uint32_t n)
+{
+    size_t bytes = 0;
+    uint32_t *p = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)n, 0u, 30u);
+    return bytes;
+}
+
+void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out,
+                 uint32_t *vals_in, uint32_t *vals_out, uint32_t n)
+{
+    if (!n) return;
+    (void)rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 30u, s);
+}
+
+void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,
+                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, Node *nodes)
+{
+    if (!ntris) return;
+    hipLaunchKernelGGL(k_leaves, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris,
+                       leaf_size, records, nodes);
+}
+
+void launch_range_tree(hipStream_t s, const Node *nodes, const RangeTree &rt, float4 *boxes)
+{
+    if (rt.levels <= 1) return;
+    hipLaunchKernelGGL(k_range_bottom, dim3((rt.count[0] + 511u) / 512u), dim3(kBlock), 0, s, nodes, rt, boxes);
+    if (rt.levels > (uint32_t)kBottomLevels + 1u)
+        hipLaunchKernelGGL(k_range_top, dim3(1), dim3(kBlock), 0, s, rt, boxes);
+}
+
+void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleaves, uint32_t leaf_size,
+                      const RangeTree &rt, const float4 *boxes, Node *nodes)
+{
+    if (!nleaves) return;
+    hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(nleaves)), dim3(kBlock), 0, s, sorted_keys, nleaves, leaf_size,
+                       rt, boxes, nodes);
+}
+
+void launch_trace(hipStream_t s, const SensorTables &tb, const Node *nodes, const TriRecord *records,
+                  uint32_t nslots, uint32_t leaf_size, float *t_out, uint32_t *gid_out, uint32_t *row_counts,
+                  unsigned long long *visit_counts)
+{
+    const uint32_t n_tiles = tb.n_az_blocks * ((tb.V + 3u) >> 2);
+    if (!n_tiles) return;
+    if (visit_counts)
+        hipLaunchKernelGGL(k_trace<true>, dim3(n_tiles), dim3(kBlock), 0, s, tb, nodes, records, nslots, leaf_size,
+                           t_out, gid_out, row_counts, visit_counts);
+    else
+        hipLaunchKernelGGL(k_trace<false>, dim3(n_tiles), dim3(kBlock), 0, s, tb, nodes, records, nslots,
+                           leaf_size, t_out, gid_out, row_counts, visit_counts);
+}
+
+void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
+                 const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
+{
+    const uint32_t n_rows = tb.V * tb.n_az_blocks;
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_pack, dim3((n_rows + 3u) / 4u), dim3(kBlock), 0, s, tb, t, gid, row_counts, gt,
+                       reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);
+}
+
+void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz)
+{
+    const uint32_t n = tb.V * tb.naz;
+    if (!n) return;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n)), dim3(kBlock), 0, s, tb, dx, dy, dz);
+}
+
+void launch_bruteforce(hipStream_t s, const SensorTables &tb, const float *verts, const uint32_t *tris,
+                       uint32_t ntris, float *t_out, uint32_t *gid_out)
+{
+    const uint32_t n = tb.V * tb.naz;
+    if (!n) return;
+    hipLaunchKernelGGL(k_bruteforce, dim3(blocks_for(n)), dim3(kBlock), 0, s, tb, verts, tris, ntris, t_out,
+                       gid_out);
+}
+
+}  // namespace ls

@@ -1,0 +1,822 @@
+// ls_tracer.cpp -- host side of the C ABI in include/lidarshooter_hip.h: the tracer handle, its
+// geometry registry (ITracer semantics, EmbreeTracer.cpp:115-295), device memory and the per-frame
+// launch sequence.  No compute happens on the host: if there is no usable HIP device the create
+// call fails (LS_ERR_NO_DEVICE); there is no CPU fallback anywhere in this library.
+#include "../../include/lidarshooter_hip.h"
+#include "ls_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+struct Geometry {
+    std::string name;
+    int id = -1;
+    uint32_t n_verts = 0, n_tris = 0;
+    void *d_raw = nullptr;      // vertex records as uploaded (n_verts * stride bytes)
+    size_t raw_cap = 0;
+    uint32_t stride = 0;
+    uint32_t *d_idx = nullptr;  // 3*n_tris mesh-local vertex indices
+    bool has_verts = false, has_idx = false, idx_dirty = true;
+    float affine[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+};
+
+}  // namespace
+
+struct ls_tracer {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    // sensor (LidarDevice state needed by the path)
+    std::vector<float> vertical;
+    float h_begin = 0, h_end = 0;
+    uint32_t V = 0, H = 0;
+    float rinv[9], t[3];
+    float *d_tables = nullptr;  // sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H]
+    uint32_t az0 = 0, naz = 0;
+
+    // geometry registry
+    std::map<std::string, Geometry> geoms;
+    long geometry_count = 0;
+    bool layout_dirty = true;
+
+    // committed scene
+    std::vector<int> slot_geom_ids;       // geometry ids in layout order
+    std::vector<uint32_t> slot_tri_first; // [n+1]
+    uint32_t n_verts = 0, n_tris = 0, n_leaves = 0, n_slots = 0, leaf_size = 2, committed_leaf_size = 2;
+    bool committed = false;
+    DevBuf<float> verts;
+    DevBuf<uint32_t> tris, keys_a, keys_b, vals_a, vals_b, geom_table;
+    DevBuf<uint8_t> sort_temp;
+    DevBuf<ls::TriRecord> records;
+    DevBuf<ls::Node> nodes;
+    DevBuf<float4> range_boxes;
+    ls::RangeTree rt{};
+    uint32_t *d_maxabs = nullptr;
+    unsigned long long *d_visits = nullptr;
+
+    // trace outputs
+    DevBuf<float> hit_t;
+    DevBuf<uint32_t> hit_gid, row_counts;
+    DevBuf<uint8_t> points;   // 32 B per ray
+    DevBuf<uint8_t> hits;     // 16 B per ray
+    uint32_t *d_n_points = nullptr;
+    void *ext_points = nullptr, *ext_hits = nullptr;
+    uint32_t *ext_n_points = nullptr;
+    uint32_t ext_capacity = 0;
+    uint8_t *h_points = nullptr;
+    ls_hit *h_hits = nullptr;
+    size_t h_cap = 0;  // records
+    uint32_t *h_n_points = nullptr;
+    bool traced = false;
+
+    // options / measurement
+    bool opt_timing = false, opt_count = false, opt_refit = false;
+    hipEvent_t ev[LS_T_COUNT + 2] = {};
+    bool ev_valid[LS_T_COUNT + 2] = {};
+    float last_ms[LS_T_COUNT] = {};
+    uint64_t last_visits[2] = {0, 0};
+};
+
+namespace {
+
+#define LS_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            tr->err = std::string(#call) + ": " + hipGetErrorString(e_);                             \
+            return LS_ERR_HIP;                                                                       \
+        }                                                                                            \
+    } while (0)
+
+int fail(ls_tracer *tr, int code, const char *msg)
+{
+    tr->err = msg;
+    return code;
+}
+
+template <typename T>
+int ensure(ls_tracer *tr, DevBuf<T> &b, size_t need)
+{
+    if (need <= b.cap) return LS_OK;
+    if (b.p) LS_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t cap = need + need / 8 + 64;
+    LS_HIP(hipMalloc(reinterpret_cast<void **>(&b.p), cap * sizeof(T)));
+    b.cap = cap;
+    return LS_OK;
+}
+
+template <typename T>
+void release(DevBuf<T> &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+ls::SensorTables tables(const ls_tracer *tr)
+{
+    ls::SensorTables tb;
+    tb.sin_theta = tr->d_tables;
+    tb.cos_theta = tr->d_tables + tr->V;
+    tb.sin_phi = tr->d_tables + 2 * (size_t)tr->V;
+    tb.cos_phi = tr->d_tables + 2 * (size_t)tr->V + tr->H;
+    tb.V = tr->V;
+    tb.H = tr->H;
+    tb.az0 = tr->az0;
+    tb.naz = tr->naz;
+    tb.n_az_blocks = (tr->naz + 63u) / 64u;
+    return tb;
+}
+
+uint32_t shard_rays(const ls_tracer *tr) { return tr->V * tr->naz; }
+uint32_t padded_rays(const ls_tracer *tr) { return tr->V * ((tr->naz + 63u) / 64u) * 64u; }
+
+int ensure_outputs(ls_tracer *tr)
+{
+    const size_t pr = padded_rays(tr), nr = shard_rays(tr);
+    int rc;
+    if ((rc = ensure(tr, tr->hit_t, pr))) return rc;
+    if ((rc = ensure(tr, tr->hit_gid, pr))) return rc;
+    if ((rc = ensure(tr, tr->row_counts, pr / 64 + 4))) return rc;
+    if (!tr->ext_points) {
+        if ((rc = ensure(tr, tr->points, nr * 32))) return rc;
+        if ((rc = ensure(tr, tr->hits, nr * 16))) return rc;
+    }
+    return LS_OK;
+}
+
+void mark(ls_tracer *tr, int i)
+{
+    if (!tr->opt_timing) return;
+    if (!tr->ev[i]) {
+        if (hipEventCreate(&tr->ev[i]) != hipSuccess) return;
+    }
+    tr->ev_valid[i] = hipEventRecord(tr->ev[i], tr->stream) == hipSuccess;
+}
+
+// LidarDevice.cpp:306-316 on the host: the V+H distinct angles of a revolution go through libm
+// (sinf/cosf, exactly like the reference's CPU path); the kernels only multiply table entries.
+void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
+{
+    const uint32_t V = tr->V, H = tr->H;
+    tab.resize(2 * (size_t)V + 2 * (size_t)H);
+    const float step = (tr->h_end - tr->h_begin) / static_cast<float>(H - 1u);  // LidarDevice.cpp:611
+    for (uint32_t v = 0; v < V; ++v) {
+        const float preChi = tr->vertical[v];
+        const float theta = static_cast<float>((90.0 - static_cast<double>(preChi)) * M_PI / 180.0);
+        tab[v] = std::sin(theta);
+        tab[V + v] = std::cos(theta);
+    }
+    for (uint32_t h = 0; h < H; ++h) {
+        const float prePhi = tr->h_begin + step * static_cast<float>(h);
+        const float phi = static_cast<float>(static_cast<double>(prePhi) * M_PI / 180.0);
+        tab[2 * (size_t)V + h] = std::sin(phi);
+        tab[2 * (size_t)V + H + h] = std::cos(phi);
+    }
+}
+
+// MeshTransformer.cpp:467-477 (Eigen: ((Translation*Rz)*Ry)*Rx, AngleAxis::toRotationMatrix)
+void angle_axis_unit(float angle, int axis, float *m)
+{
+    float ax[3] = {0.f, 0.f, 0.f};
+    ax[axis] = 1.0f;
+    const float s = std::sin(angle), c = std::cos(angle);
+    const float sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+    const float ca[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
+    float tmp;
+    tmp = ca[0] * ax[1]; m[1] = tmp - sa[2]; m[3] = tmp + sa[2];
+    tmp = ca[0] * ax[2]; m[2] = tmp + sa[1]; m[6] = tmp - sa[1];
+    tmp = ca[1] * ax[2]; m[5] = tmp - sa[0]; m[7] = tmp + sa[0];
+    m[0] = ca[0] * ax[0] + c;
+    m[4] = ca[1] * ax[1] + c;
+    m[8] = ca[2] * ax[2] + c;
+}
+
+void mat3_mul(const float *a, const float *b, float *o)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            o[3 * i + j] = (a[3 * i + 0] * b[0 + j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+
+void affine_from_components(const float *lin, const float *ang, float *A)
+{
+    float rx[9], ry[9], rz[9], zy[9], zyx[9];
+    angle_axis_unit(ang[0], 0, rx);
+    angle_axis_unit(ang[1], 1, ry);
+    angle_axis_unit(ang[2], 2, rz);
+    mat3_mul(rz, ry, zy);
+    mat3_mul(zy, rx, zyx);
+    for (int i = 0; i < 3; ++i) {
+        A[4 * i + 0] = zyx[3 * i + 0];
+        A[4 * i + 1] = zyx[3 * i + 1];
+        A[4 * i + 2] = zyx[3 * i + 2];
+        A[4 * i + 3] = lin[i];
+    }
+}
+
+int update_common(ls_tracer *tr, const char *name, const float *affine, const void *verts, uint32_t stride,
+                  const uint32_t *idx, hipMemcpyKind kind)
+{
+    if (!name || !affine) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
+    auto it = tr->geoms.find(name);
+    if (it == tr->geoms.end()) return fail(tr, LS_ERR_UNKNOWN_GEOMETRY, "geometry key does not exist");
+    Geometry &g = it->second;
+    std::memcpy(g.affine, affine, sizeof(g.affine));
+    if (verts) {
+        if (stride < 12 || (stride & 3u)) return fail(tr, LS_ERR_INVALID_ARGUMENT, "vertex stride must be >= 12 and a multiple of 4");
+        const size_t bytes = (size_t)g.n_verts * stride;
+        if (bytes > g.raw_cap) {
+            if (g.d_raw) LS_HIP(hipFree(g.d_raw));
+            g.d_raw = nullptr;
+            g.raw_cap = 0;
+            LS_HIP(hipMalloc(&g.d_raw, bytes ? bytes : 4));
+            g.raw_cap = bytes;
+        }
+        if (bytes) LS_HIP(hipMemcpyAsync(g.d_raw, verts, bytes, kind, tr->stream));
+        g.stride = stride;
+        if (!g.has_verts) tr->layout_dirty = true;
+        g.has_verts = true;
+    }
+    if (idx) {
+        const size_t bytes = (size_t)g.n_tris * 12;
+        if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), bytes ? bytes : 4));
+        if (bytes) LS_HIP(hipMemcpyAsync(g.d_idx, idx, bytes, kind, tr->stream));
+        if (!g.has_idx) tr->layout_dirty = true;
+        g.has_idx = true;
+        g.idx_dirty = true;
+    }
+    // host memory may be reused by the caller as soon as we return (MeshProjector.cpp:448-461)
+    if (kind == hipMemcpyHostToDevice && (verts || idx)) LS_HIP(hipStreamSynchronize(tr->stream));
+    return LS_OK;
+}
+
+void free_geometry(Geometry &g)
+{
+    if (g.d_raw) (void)hipFree(g.d_raw);
+    if (g.d_idx) (void)hipFree(g.d_idx);
+    g.d_raw = nullptr;
+    g.d_idx = nullptr;
+}
+
+int commit_locked(ls_tracer *tr)
+{
+    tr->committed = false;
+    tr->traced = false;
+    // layout: geometries with data, in geomID order, so that the global triangle id orders
+    // triangles by (geomID, primID) -- the tie-break key of equal-t hits.
+    std::vector<Geometry *> order;
+    for (auto &kv : tr->geoms)
+        if (kv.second.has_verts && kv.second.has_idx && kv.second.n_tris > 0) order.push_back(&kv.second);
+    std::sort(order.begin(), order.end(), [](const Geometry *a, const Geometry *b) { return a->id < b->id; });
+    if (order.empty()) {
+        tr->n_tris = tr->n_verts = tr->n_leaves = tr->n_slots = 0;
+        tr->slot_geom_ids.clear();
+        tr->slot_tri_first.assign(1, 0u);
+        tr->layout_dirty = true;
+        return -1;  // OptixTracer.cpp:266-267
+    }
+    if (order.size() > (size_t)ls::kMaxGeoms) return fail(tr, LS_ERR_OUT_OF_RANGE, "too many geometries");
+
+    std::vector<uint32_t> vfirst(order.size() + 1, 0u), tfirst(order.size() + 1, 0u);
+    std::vector<int> ids(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        vfirst[k + 1] = vfirst[k] + order[k]->n_verts;
+        tfirst[k + 1] = tfirst[k] + order[k]->n_tris;
+        ids[k] = order[k]->id;
+    }
+    const bool relayout = tr->layout_dirty || ids != tr->slot_geom_ids || tfirst != tr->slot_tri_first ||
+                          tr->leaf_size != tr->committed_leaf_size;
+    const uint32_t nv = vfirst.back(), nt = tfirst.back();
+    const uint32_t g = tr->leaf_size;
+    const uint32_t L = (nt + g - 1) / g;
+
+    int rc;
+    if ((rc = ensure(tr, tr->verts, (size_t)nv * 3))) return rc;
+    if ((rc = ensure(tr, tr->tris, (size_t)nt * 3))) return rc;
+    if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
+    if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
+    if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
+    if ((rc = ensure(tr, tr->vals_b, nt))) return rc;
+    if ((rc = ensure(tr, tr->records, (size_t)L * g))) return rc;
+    if ((rc = ensure(tr, tr->nodes, 2 * (size_t)L))) return rc;
+    if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
+
+    if (relayout) {
+        std::vector<uint32_t> table(tfirst);
+        for (int id : ids) table.push_back((uint32_t)id);
+        if ((rc = ensure(tr, tr->geom_table, table.size()))) return rc;
+        LS_HIP(hipMemcpyAsync(tr->geom_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, tr->stream));
+        LS_HIP(hipStreamSynchronize(tr->stream));  // `table` is a stack temporary
+        // aligned-range tree geometry
+        ls::RangeTree &rt = tr->rt;
+        std::memset(&rt, 0, sizeof(rt));
+        uint32_t cnt = L, off = 0, lev = 0;
+        while (true) {
+            rt.count[lev] = cnt;
+            rt.offset[lev] = lev ? off : 0;
+            if (lev) off += cnt;
+            ++lev;
+            if (cnt <= 1) break;
+            cnt = (cnt + 1) / 2;
+        }
+        rt.levels = lev;
+        if ((rc = ensure(tr, tr->range_boxes, 2 * (size_t)off + 2))) return rc;
+    }
+
+    hipStream_t s = tr->stream;
+    mark(tr, 0);
+    LS_HIP(hipMemsetAsync(tr->d_maxabs, 0, 4, s));
+    for (size_t k = 0; k < order.size(); ++k) {
+        Geometry &ge = *order[k];
+        ls::launch_transform(s, ge.d_raw, ge.stride, ge.n_verts, ge.affine, tr->rinv, tr->t,
+                             tr->verts.p + 3 * (size_t)vfirst[k], tr->d_maxabs);
+        if (relayout || ge.idx_dirty) {
+            ls::launch_rebase(s, ge.d_idx, ge.n_tris * 3, vfirst[k], tr->tris.p + 3 * (size_t)tfirst[k]);
+            ge.idx_dirty = false;
+        }
+    }
+    mark(tr, 1);
+    ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
+    mark(tr, 2);
+    ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
+    mark(tr, 3);
+    ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->nodes.p);
+    mark(tr, 4);
+    ls::launch_range_tree(s, tr->nodes.p, tr->rt, tr->range_boxes.p);
+    mark(tr, 5);
+    ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
+    mark(tr, 6);
+    LS_HIP(hipGetLastError());
+
+    tr->n_verts = nv;
+    tr->n_tris = nt;
+    tr->n_leaves = L;
+    tr->n_slots = 2 * L - 1;
+    tr->committed_leaf_size = g;
+    tr->slot_geom_ids = ids;
+    tr->slot_tri_first = tfirst;
+    tr->layout_dirty = false;
+    tr->committed = true;
+    return LS_OK;
+}
+
+int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
+{
+    if (!out) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null frame");
+    std::memset(out, 0, sizeof(*out));
+    out->frame = frame;
+    out->n_rays = shard_rays(tr);
+    tr->traced = false;
+    if (!tr->committed || tr->n_tris == 0) return -1;  // OptixTracer.cpp:280-288: cleared cloud, -1
+    int rc;
+    if ((rc = ensure_outputs(tr))) return rc;
+    if (tr->ext_points && tr->ext_capacity < shard_rays(tr))
+        return fail(tr, LS_ERR_OUT_OF_RANGE, "external output buffers smaller than the shard's ray count");
+
+    hipStream_t s = tr->stream;
+    const ls::SensorTables tb = tables(tr);
+    uint8_t *d_points = tr->ext_points ? static_cast<uint8_t *>(tr->ext_points) : tr->points.p;
+    void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
+    uint32_t *d_n = tr->ext_points ? tr->ext_n_points : tr->d_n_points;
+    if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 16, s));
+    mark(tr, 7);
+    ls::launch_trace(s, tb, tr->nodes.p, tr->records.p, tr->n_slots, tr->committed_leaf_size, tr->hit_t.p,
+                     tr->hit_gid.p, tr->row_counts.p, tr->opt_count ? tr->d_visits : nullptr);
+    mark(tr, 8);
+    ls::GeomTable gt;
+    gt.n = (uint32_t)tr->slot_geom_ids.size();
+    gt.tri_first = tr->geom_table.p;
+    gt.geom_ids = tr->geom_table.p + gt.n + 1;
+    ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n);
+    mark(tr, 9);
+    LS_HIP(hipGetLastError());
+    tr->traced = true;
+    out->d_points32 = d_points;
+    out->d_hits = d_hits;
+    out->d_n_points = d_n;
+    if (!readback) return LS_OK;
+
+    LS_HIP(hipMemcpyAsync(tr->h_n_points, d_n, 4, hipMemcpyDeviceToHost, s));
+    LS_HIP(hipStreamSynchronize(s));
+    const uint32_t n = *tr->h_n_points;
+    if (n > tr->h_cap) {
+        if (tr->h_points) LS_HIP(hipHostFree(tr->h_points));
+        if (tr->h_hits) LS_HIP(hipHostFree(tr->h_hits));
+        tr->h_points = nullptr;
+        tr->h_hits = nullptr;
+        tr->h_cap = 0;
+        const size_t cap = std::max<size_t>(shard_rays(tr), n);
+        LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_points), cap * 32));
+        LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_hits), cap * 16));
+        tr->h_cap = cap;
+    }
+    if (n) {
+        LS_HIP(hipMemcpyAsync(tr->h_points, d_points, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        LS_HIP(hipMemcpyAsync(tr->h_hits, d_hits, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+        LS_HIP(hipStreamSynchronize(s));
+    }
+    out->n_points = n;
+    out->points32 = tr->h_points;
+    out->hits = tr->h_hits;
+    return LS_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int ls_abi_version(void) { return LS_ABI_VERSION; }
+
+int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
+{
+    if (!out) return LS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return LS_ERR_INVALID_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
+        return LS_ERR_NO_DEVICE;
+    if (hipSetDevice(hip_device) != hipSuccess) return LS_ERR_NO_DEVICE;
+    ls_tracer *tr = new ls_tracer();
+    tr->device = hip_device;
+    tr->V = sd->n_vertical;
+    tr->H = sd->h_count;
+    tr->vertical.assign(sd->vertical_deg, sd->vertical_deg + sd->n_vertical);
+    tr->h_begin = sd->h_begin;
+    tr->h_end = sd->h_end;
+    std::memcpy(tr->rinv, sd->Rinv, sizeof(tr->rinv));
+    std::memcpy(tr->t, sd->t, sizeof(tr->t));
+    tr->az0 = 0;
+    tr->naz = tr->H;
+    auto bail = [&](int code) {
+        ls_tracer_destroy(tr);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&tr->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(LS_ERR_HIP);
+    tr->stream = tr->own_stream;
+    std::vector<float> tab;
+    fill_tables(tr, tab);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_tables), tab.size() * 4) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMemcpy(tr->d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_maxabs), 4) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    tr->slot_tri_first.assign(1, 0u);
+    *out = tr;
+    return LS_OK;
+}
+
+void ls_tracer_destroy(ls_tracer *tr)
+{
+    if (!tr) return;
+    (void)hipSetDevice(tr->device);
+    if (tr->stream) (void)hipStreamSynchronize(tr->stream);
+    for (auto &kv : tr->geoms) free_geometry(kv.second);
+    release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
+    release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
+    release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
+    release(tr->row_counts); release(tr->points); release(tr->hits);
+    if (tr->d_tables) (void)hipFree(tr->d_tables);
+    if (tr->d_maxabs) (void)hipFree(tr->d_maxabs);
+    if (tr->d_visits) (void)hipFree(tr->d_visits);
+    if (tr->d_n_points) (void)hipFree(tr->d_n_points);
+    if (tr->h_points) (void)hipHostFree(tr->h_points);
+    if (tr->h_hits) (void)hipHostFree(tr->h_hits);
+    if (tr->h_n_points) (void)hipHostFree(tr->h_n_points);
+    for (auto &e : tr->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (tr->own_stream) (void)hipStreamDestroy(tr->own_stream);
+    delete tr;
+}
+
+#define LS_ENTER(tr)                                   \
+    if (!(tr)) return LS_ERR_INVALID_ARGUMENT;         \
+    std::lock_guard<std::mutex> lock_((tr)->mu);       \
+    if (hipSetDevice((tr)->device) != hipSuccess) return fail((tr), LS_ERR_HIP, "hipSetDevice failed")
+
+int ls_add_geometry(ls_tracer *tr, const char *name, int geometry_type, int n_vertices, int n_elements)
+{
+    LS_ENTER(tr);
+    if (!name || n_vertices < 0 || n_elements < 0) return fail(tr, LS_ERR_INVALID_ARGUMENT, "bad argument");
+    if (geometry_type != LS_GEOMETRY_TYPE_TRIANGLE) return fail(tr, LS_ERR_UNSUPPORTED_TYPE, "only triangle geometries are supported");
+    if (tr->geoms.count(name)) return fail(tr, LS_ERR_DUPLICATE_GEOMETRY, "geometry key already exists");
+    // lowest free id, like rtcAttachGeometry (EmbreeTracer.cpp:205)
+    std::vector<int> used;
+    for (auto &kv : tr->geoms) used.push_back(kv.second.id);
+    std::sort(used.begin(), used.end());
+    int id = 0;
+    for (int u : used) {
+        if (u == id) ++id;
+        else if (u > id) break;
+    }
+    Geometry g;
+    g.name = name;
+    g.id = id;
+    g.n_verts = (uint32_t)n_vertices;
+    g.n_tris = (uint32_t)n_elements;
+    tr->geoms.emplace(name, g);
+    tr->geometry_count += 1;
+    tr->layout_dirty = true;
+    return id;
+}
+
+int ls_remove_geometry(ls_tracer *tr, const char *name)
+{
+    LS_ENTER(tr);
+    if (!name) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null name");
+    auto it = tr->geoms.find(name);
+    if (it == tr->geoms.end()) return -1;  // EmbreeTracer.cpp:224-225
+    const int id = it->second.id;
+    (void)hipStreamSynchronize(tr->stream);
+    free_geometry(it->second);
+    tr->geoms.erase(it);
+    tr->geometry_count -= 1;
+    tr->layout_dirty = true;
+    // EmbreeTracer.cpp:252 commits here; the BVH still references the removed triangles, so the
+    // scene is simply marked uncommitted until the caller's next commitScene (every caller does,
+    // MeshProjector.cpp:458).
+    tr->committed = false;
+    return id;
+}
+
+int ls_update_geometry(ls_tracer *tr, const char *name, const float affine3x4[12], const void *verts,
+                       uint32_t vert_stride, const uint32_t *tri_idx)
+{
+    LS_ENTER(tr);
+    if (!verts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null vertices");
+    return update_common(tr, name, affine3x4, verts, vert_stride, tri_idx, hipMemcpyHostToDevice);
+}
+
+int ls_update_geometry_components(ls_tracer *tr, const char *name, const float lin[3], const float ang[3],
+                                  const void *verts, uint32_t vert_stride, const uint32_t *tri_idx)
+{
+    LS_ENTER(tr);
+    if (!lin || !ang || !verts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
+    float A[12];
+    affine_from_components(lin, ang, A);
+    return update_common(tr, name, A, verts, vert_stride, tri_idx, hipMemcpyHostToDevice);
+}
+
+int ls_update_geometry_device(ls_tracer *tr, const char *name, const float affine3x4[12], const void *d_verts,
+                              uint32_t vert_stride, const uint32_t *d_tri_idx)
+{
+    LS_ENTER(tr);
+    if (!d_verts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null vertices");
+    return update_common(tr, name, affine3x4, d_verts, vert_stride, d_tri_idx, hipMemcpyDeviceToDevice);
+}
+
+int ls_update_geometry_transform(ls_tracer *tr, const char *name, const float affine3x4[12])
+{
+    LS_ENTER(tr);
+    return update_common(tr, name, affine3x4, nullptr, 0, nullptr, hipMemcpyDeviceToDevice);
+}
+
+int ls_commit_scene(ls_tracer *tr)
+{
+    LS_ENTER(tr);
+    return commit_locked(tr);
+}
+
+int ls_trace_scene(ls_tracer *tr, uint32_t frame_index, ls_frame *out)
+{
+    LS_ENTER(tr);
+    return trace_locked(tr, frame_index, out, true);
+}
+
+int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out)
+{
+    LS_ENTER(tr);
+    return trace_locked(tr, frame_index, out, false);
+}
+
+long ls_geometry_count(ls_tracer *tr)
+{
+    if (!tr) return LS_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(tr->mu);
+    return tr->geometry_count;
+}
+
+int ls_geometry_id(ls_tracer *tr, const char *name)
+{
+    LS_ENTER(tr);
+    auto it = tr->geoms.find(name ? name : "");
+    if (it == tr->geoms.end()) return fail(tr, LS_ERR_UNKNOWN_GEOMETRY, "geometry key does not exist");
+    return it->second.id;
+}
+
+long ls_vertex_count(ls_tracer *tr, const char *name)
+{
+    LS_ENTER(tr);
+    auto it = tr->geoms.find(name ? name : "");
+    if (it == tr->geoms.end()) return fail(tr, LS_ERR_UNKNOWN_GEOMETRY, "geometry key does not exist");
+    return (long)it->second.n_verts;
+}
+
+long ls_element_count(ls_tracer *tr, const char *name)
+{
+    LS_ENTER(tr);
+    auto it = tr->geoms.find(name ? name : "");
+    if (it == tr->geoms.end()) return fail(tr, LS_ERR_UNKNOWN_GEOMETRY, "geometry key does not exist");
+    return (long)it->second.n_tris;
+}
+
+uint32_t ls_total_rays(ls_tracer *tr) { return tr ? shard_rays(tr) : 0u; }
+uint32_t ls_total_channels(ls_tracer *tr) { return tr ? tr->V : 0u; }
+
+const char *ls_last_error(ls_tracer *tr) { return tr ? tr->err.c_str() : "null tracer"; }
+
+int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az)
+{
+    LS_ENTER(tr);
+    if (n_az == 0 || first_az >= tr->H || n_az > tr->H - first_az) return fail(tr, LS_ERR_OUT_OF_RANGE, "shard outside [0, H)");
+    tr->az0 = first_az;
+    tr->naz = n_az;
+    tr->traced = false;
+    return LS_OK;
+}
+
+int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream)
+{
+    LS_ENTER(tr);
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    tr->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : tr->own_stream;
+    return LS_OK;
+}
+
+int ls_tracer_synchronize(ls_tracer *tr)
+{
+    LS_ENTER(tr);
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    return LS_OK;
+}
+
+int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, uint32_t *d_n_points, uint32_t capacity)
+{
+    LS_ENTER(tr);
+    if (!d_points32) {
+        tr->ext_points = tr->ext_hits = nullptr;
+        tr->ext_n_points = nullptr;
+        tr->ext_capacity = 0;
+        return LS_OK;
+    }
+    if (!d_hits || !d_n_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "all three output buffers are required");
+    tr->ext_points = d_points32;
+    tr->ext_hits = d_hits;
+    tr->ext_n_points = d_n_points;
+    tr->ext_capacity = capacity;
+    return LS_OK;
+}
+
+int ls_tracer_set_option(ls_tracer *tr, int option, int value)
+{
+    LS_ENTER(tr);
+    switch (option) {
+    case LS_OPT_LEAF_SIZE:
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(tr, LS_ERR_INVALID_ARGUMENT, "leaf size must be 1, 2, 4 or 8");
+        tr->leaf_size = (uint32_t)value;
+        return LS_OK;
+    case LS_OPT_TIMING: tr->opt_timing = value != 0; return LS_OK;
+    case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
+    case LS_OPT_REFIT: tr->opt_refit = value != 0; return LS_OK;
+    default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown option");
+    }
+}
+
+int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT])
+{
+    LS_ENTER(tr);
+    if (!ms) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    // events: 0..6 bracket the six commit stages, 7..9 bracket trace and pack
+    static const int first[LS_T_COUNT] = {0, 1, 2, 3, 4, 5, 7, 8};
+    for (int i = 0; i < LS_T_COUNT; ++i) {
+        ms[i] = 0.0f;
+        const int a = first[i], b = a + 1;
+        if (tr->ev[a] && tr->ev[b] && tr->ev_valid[a] && tr->ev_valid[b]) {
+            float v = 0.0f;
+            if (hipEventElapsedTime(&v, tr->ev[a], tr->ev[b]) == hipSuccess) ms[i] = v;
+        }
+    }
+    return LS_OK;
+}
+
+int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[2])
+{
+    LS_ENTER(tr);
+    if (!counts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    LS_HIP(hipMemcpy(counts, tr->d_visits, 16, hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
+int ls_generate_rays(ls_tracer *tr, float *dx, float *dy, float *dz)
+{
+    LS_ENTER(tr);
+    if (!dx || !dy || !dz) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    ls::launch_raygen(tr->stream, tables(tr), dx, dy, dz);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid)
+{
+    LS_ENTER(tr);
+    if (!t || !gid) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    const uint32_t nab = (tr->naz + 63u) / 64u;
+    if (!tr->traced) {
+        for (uint32_t q = 0; q < shard_rays(tr); ++q) { t[q] = -1.0f; gid[q] = ls::kInvalid; }
+        return LS_OK;
+    }
+    const size_t pr = padded_rays(tr);
+    std::vector<float> pt(pr);
+    std::vector<uint32_t> pg(pr);
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    LS_HIP(hipMemcpy(pt.data(), tr->hit_t.p, pr * 4, hipMemcpyDeviceToHost));
+    LS_HIP(hipMemcpy(pg.data(), tr->hit_gid.p, pr * 4, hipMemcpyDeviceToHost));
+    for (uint32_t v = 0; v < tr->V; ++v)
+        for (uint32_t hl = 0; hl < tr->naz; ++hl) {
+            const size_t o = ((size_t)v * nab + hl / 64u) * 64u + (hl & 63u);
+            t[(size_t)v * tr->naz + hl] = pt[o];
+            gid[(size_t)v * tr->naz + hl] = pg[o];
+        }
+    return LS_OK;
+}
+
+int ls_debug_trace_bruteforce(ls_tracer *tr, float *t, uint32_t *gid)
+{
+    LS_ENTER(tr);
+    if (!t || !gid) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
+    const uint32_t n = shard_rays(tr);
+    float *dt = nullptr;
+    uint32_t *dg = nullptr;
+    LS_HIP(hipMalloc(reinterpret_cast<void **>(&dt), (size_t)n * 4));
+    LS_HIP(hipMalloc(reinterpret_cast<void **>(&dg), (size_t)n * 4));
+    ls::launch_bruteforce(tr->stream, tables(tr), tr->verts.p, tr->tris.p, tr->n_tris, dt, dg);
+    hipError_t e = hipStreamSynchronize(tr->stream);
+    if (e == hipSuccess) e = hipMemcpy(t, dt, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(gid, dg, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dt);
+    (void)hipFree(dg);
+    if (e != hipSuccess) return fail(tr, LS_ERR_HIP, hipGetErrorString(e));
+    return LS_OK;
+}
+
+int ls_debug_scene_size(ls_tracer *tr, uint32_t *n_verts, uint32_t *n_tris, uint32_t *n_node_slots, uint32_t *leaf_size)
+{
+    LS_ENTER(tr);
+    if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
+    if (n_verts) *n_verts = tr->n_verts;
+    if (n_tris) *n_tris = tr->n_tris;
+    if (n_node_slots) *n_node_slots = tr->n_slots;
+    if (leaf_size) *leaf_size = tr->committed_leaf_size;
+    return LS_OK;
+}
+
+int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx)
+{
+    LS_ENTER(tr);
+    if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    if (verts_xyz) LS_HIP(hipMemcpy(verts_xyz, tr->verts.p, (size_t)tr->n_verts * 12, hipMemcpyDeviceToHost));
+    if (tri_idx) LS_HIP(hipMemcpy(tri_idx, tr->tris.p, (size_t)tr->n_tris * 12, hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
+int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records)
+{
+    LS_ENTER(tr);
+    if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    if (nodes) LS_HIP(hipMemcpy(nodes, tr->nodes.p, (size_t)tr->n_slots * sizeof(ls::Node), hipMemcpyDeviceToHost));
+    if (tri_records) LS_HIP(hipMemcpy(tri_records, tr->records.p, (size_t)tr->n_tris * sizeof(ls::TriRecord), hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,656 @@
+/*
+ * ls_oracle.c -- CPU ORACLE for the lidarshooter tracer hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (lidarshooter_amd/)
+ * never links, imports or calls anything in this directory.
+ *
+ * It restates, in plain scalar C, the arithmetic of the reference's per-frame path
+ * (paths relative to /root/reference/ros_ws/src/lidarshooter/src/):
+ *   - sensor pose            LidarDevice.cpp:758-822 (quaternion -> R, Rinv via Eigen 3.4)
+ *   - ray tables/directions  LidarDevice.cpp:294-342, :587-618, :824-845
+ *   - vertex transform       MeshTransformer.cpp:142-205, :467-477; LidarDevice.cpp:383-391
+ *   - closest hit            EmbreeTracer.cpp:297-367, :472-480 (rtcIntersect16)
+ *   - hit -> 32-byte point   EmbreeTracer.cpp:338-352; XYZIRBytes.cpp:24-40
+ *
+ * Third-party arithmetic that is NOT under /root/reference: the BVH build, traversal and
+ * ray/triangle test live in Embree 3.13.4 (upstream binary tarball, .devcontainer/Dockerfile:24-27).
+ * Embree is absent from this image, so its *published* triangle test is restated here from the
+ * Embree 3 sources as recalled (kernels/geometry/triangle_intersector_moeller.h,
+ * MoellerTrumboreIntersectorK; kernels/geometry/trianglev.h / triangle.h for e1,e2,Ng):
+ *     e1 = v0-v1, e2 = v2-v0, Ng = cross(e2,e1)
+ *     C = v0-org, R = cross(C,dir), den = dot(Ng,dir), absDen = |den|, sgn = signbit(den)
+ *     U = dot(R,e2)^sgn, V = dot(R,e1)^sgn, T = dot(Ng,C)^sgn
+ *     hit  <=>  den != 0, U >= 0, V >= 0, U+V <= absDen, absDen*tnear < T <= absDen*tfar
+ *     t = T/absDen      (Embree uses a Newton-refined rcp; an exact IEEE divide is used here)
+ *   with Embree's AVX2 vector helpers  cross(a,b) = (msub(a.y,b.z,a.z*b.y), ...)  and
+ *   dot(a,b) = madd(a.x,b.x,madd(a.y,b.y,a.z*b.z)), i.e. fused multiply-adds.
+ * Closest hit: minimum t over all triangles of all geometries; equal-t ties are broken by the
+ * lowest (geomID, primID) -- Embree's winner there is traversal-order dependent and cannot be
+ * known offline, so the rule is ours.  Independent of any BVH.
+ *
+ * PARITY PINNING: the reference's own tests pin only counts (98/162 mesh, 4800 rays,
+ * 1668 / 1781 / 0 hit points); tests/test_oracle.py checks this oracle against all of them.
+ * Hit t / XYZ / triangle ids are NOT pinned by any reference-owned vector ("parity unpinned"
+ * beyond hit counts).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma).  All float arithmetic below is
+ * written so that every operation rounds exactly once (explicit fmaf where Embree fuses);
+ * the HIP kernels use the same operation sequence, which is what makes bit-exact id parity
+ * testable.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define LSO_INVALID 0xFFFFFFFFu
+
+/* ------------------------------------------------------------------------------------------
+ * a-1  Sensor pose.  LidarDevice.cpp:800-813: q = (qw,qx,qy,qz) is used as given (NOT
+ * normalised); R = q.toRotationMatrix(); Rinv = R.inverse() (Eigen general 3x3 inverse,
+ * cofactor form, float).  Matrices are row-major float[9].
+ * ------------------------------------------------------------------------------------------ */
+void lso_pose_from_quat(float qw, float qx, float qy, float qz, float *R, float *Rinv)
+{
+    /* Eigen/src/Geometry/Quaternion.h, QuaternionBase::toRotationMatrix() */
+    const float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
+    const float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz;          R[2] = txz + twy;
+    R[3] = txy + twz;          R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = 1.0f - (txx + tyy);
+
+    /* Eigen/src/LU/InverseImpl.h, compute_inverse<Matrix3f>: cofactor expansion */
+#define M(i, j) R[3 * (i) + (j)]
+#define COF(i, j) (M(((i) + 1) % 3, ((j) + 1) % 3) * M(((i) + 2) % 3, ((j) + 2) % 3) - \
+                   M(((i) + 1) % 3, ((j) + 2) % 3) * M(((i) + 2) % 3, ((j) + 1) % 3))
+    const float c00 = COF(0, 0), c10 = COF(1, 0), c20 = COF(2, 0);
+    const float det = (c00 * M(0, 0) + c10 * M(1, 0)) + c20 * M(2, 0);
+    const float invdet = 1.0f / det;
+    Rinv[0] = c00 * invdet;       Rinv[1] = c10 * invdet;       Rinv[2] = c20 * invdet;
+    Rinv[3] = COF(0, 1) * invdet; Rinv[4] = COF(1, 1) * invdet; Rinv[5] = COF(2, 1) * invdet;
+    Rinv[6] = COF(0, 2) * invdet; Rinv[7] = COF(1, 2) * invdet; Rinv[8] = COF(2, 2) * invdet;
+#undef COF
+#undef M
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-2  Ray tables.  LidarDevice.cpp:611  step = (end-begin)/(count-1)  (float / unsigned->float)
+ * LidarDevice.cpp:306-316 per ray (channel-major, r = v*H + h):
+ *     prePhi = begin + step*float(h)                    (float)
+ *     theta  = float((90.0 - chi_v) * M_PI / 180.0)     (double expression, rounded once)
+ *     phi    = float(prePhi * M_PI / 180.0)
+ *     d      = (sinf(theta)*cosf(phi), sinf(theta)*sinf(phi), cosf(theta))
+ * Only V+H distinct angles exist, so the four tables below hold every libm value a frame needs.
+ * ------------------------------------------------------------------------------------------ */
+float lso_azimuth_step(float begin, float end, uint32_t count)
+{
+    return (end - begin) / (float)(count - 1u);
+}
+
+void lso_ray_tables(const float *vertical_deg, uint32_t V, float begin, float end, uint32_t count,
+                    float *sin_theta, float *cos_theta, float *sin_phi, float *cos_phi)
+{
+    const float step = lso_azimuth_step(begin, end, count);
+    for (uint32_t v = 0; v < V; ++v) {
+        const float preChi = vertical_deg[v];
+        const float theta = (float)((90.0 - (double)preChi) * M_PI / 180.0);
+        sin_theta[v] = sinf(theta);
+        cos_theta[v] = cosf(theta);
+    }
+    for (uint32_t h = 0; h < count; ++h) {
+        const float prePhi = begin + step * (float)h;
+        const float phi = (float)((double)prePhi * M_PI / 180.0);
+        sin_phi[h] = sinf(phi);
+        cos_phi[h] = cosf(phi);
+    }
+}
+
+/* dirs: float[3*V*H], channel-major */
+void lso_ray_dirs(const float *vertical_deg, uint32_t V, float begin, float end, uint32_t count,
+                  float *dirs)
+{
+    float *st = (float *)malloc(sizeof(float) * (2 * (size_t)V + 2 * (size_t)count));
+    float *ct = st + V, *sp = ct + V, *cp = sp + count;
+    lso_ray_tables(vertical_deg, V, begin, end, count, st, ct, sp, cp);
+    for (uint32_t v = 0; v < V; ++v)
+        for (uint32_t h = 0; h < count; ++h) {
+            float *d = dirs + 3 * ((size_t)v * count + h);
+            d[0] = st[v] * cp[h];
+            d[1] = st[v] * sp[h];
+            d[2] = ct[v];
+        }
+    free(st);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-4  Vertex transform.
+ * MeshTransformer.cpp:467-477: T = Translation(lin) * Rz(ang.z) * Ry(ang.y) * Rx(ang.x), built
+ * by Eigen as ((Tr*Rz)*Ry)*Rx with each AngleAxis turned into a matrix by
+ * AngleAxis::toRotationMatrix() (Eigen/src/Geometry/AngleAxis.h).  A[12] is row-major 3x4.
+ * ------------------------------------------------------------------------------------------ */
+static void angle_axis_unit(float angle, int axis, float *m)
+{
+    float ax[3] = {0.f, 0.f, 0.f};
+    ax[axis] = 1.0f;
+    const float s = sinf(angle), c = cosf(angle);
+    const float sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+    const float ca[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
+    float tmp;
+    tmp = ca[0] * ax[1]; m[1] = tmp - sa[2]; m[3] = tmp + sa[2];
+    tmp = ca[0] * ax[2]; m[2] = tmp + sa[1]; m[6] = tmp - sa[1];
+    tmp = ca[1] * ax[2]; m[5] = tmp - sa[0]; m[7] = tmp + sa[0];
+    m[0] = ca[0] * ax[0] + c;
+    m[4] = ca[1] * ax[1] + c;
+    m[8] = ca[2] * ax[2] + c;
+}
+
+static void mat3_mul(const float *a, const float *b, float *o)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            o[3 * i + j] = (a[3 * i + 0] * b[0 + j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+
+void lso_affine_from_components(const float *lin, const float *ang, float *A)
+{
+    float rx[9], ry[9], rz[9], zy[9], zyx[9];
+    angle_axis_unit(ang[0], 0, rx);
+    angle_axis_unit(ang[1], 1, ry);
+    angle_axis_unit(ang[2], 2, rz);
+    mat3_mul(rz, ry, zy);
+    mat3_mul(zy, rx, zyx);
+    for (int i = 0; i < 3; ++i) {
+        A[4 * i + 0] = zyx[3 * i + 0];
+        A[4 * i + 1] = zyx[3 * i + 1];
+        A[4 * i + 2] = zyx[3 * i + 2];
+        A[4 * i + 3] = lin[i];
+    }
+}
+
+/* MeshTransformer.cpp:176-195: p = T*v (linear*v + translation), then
+ * LidarDevice.cpp:383-391: p' = Rinv * (p - (tx,ty,tz)).
+ * verts: records of `stride` bytes whose first 12 bytes are x,y,z (float LE). */
+void lso_transform_vertices(const void *verts, uint32_t stride, uint32_t n, const float *A,
+                            const float *Rinv, const float *t, float *out)
+{
+    const uint8_t *base = (const uint8_t *)verts;
+    for (uint32_t j = 0; j < n; ++j) {
+        float p[3], q[3];
+        memcpy(p, base + (size_t)j * stride, 12);
+        for (int i = 0; i < 3; ++i)
+            q[i] = ((A[4 * i + 0] * p[0] + A[4 * i + 1] * p[1]) + A[4 * i + 2] * p[2]) + A[4 * i + 3];
+        const float a = q[0] - t[0], b = q[1] - t[1], c = q[2] - t[2];
+        for (int i = 0; i < 3; ++i)
+            out[3 * (size_t)j + i] = (Rinv[3 * i + 0] * a + Rinv[3 * i + 1] * b) + Rinv[3 * i + 2] * c;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-6  Ray/triangle test (Embree 3.13.4 Moeller-Trumbore, see header) and closest hit.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+/* embree common/math/vec3.h: cross = (msub(a.y,b.z,a.z*b.y), msub(a.z,b.x,a.x*b.z), msub(a.x,b.y,a.y*b.x)) */
+static inline v3 v3_cross(v3 a, v3 b)
+{
+    v3 r = {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+    return r;
+}
+/* dot = madd(a.x,b.x,madd(a.y,b.y,a.z*b.z)) */
+static inline float v3_dot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+
+static inline float xor_sign(float f, uint32_t sgn)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u ^= sgn;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* returns 1 and *t_out on a hit with  tnear < t <= tfar */
+static inline int tri_test(v3 org, v3 dir, v3 v0, v3 v1, v3 v2, float tnear, float tfar, float *t_out)
+{
+    const v3 e1 = v3_sub(v0, v1);
+    const v3 e2 = v3_sub(v2, v0);
+    const v3 Ng = v3_cross(e2, e1);
+    const v3 C = v3_sub(v0, org);
+    const v3 R = v3_cross(C, dir);
+    const float den = v3_dot(Ng, dir);
+    const float absDen = fabsf(den);
+    uint32_t sgn;
+    memcpy(&sgn, &den, 4);
+    sgn &= 0x80000000u;
+    const float U = xor_sign(v3_dot(R, e2), sgn);
+    const float V = xor_sign(v3_dot(R, e1), sgn);
+    const float T = xor_sign(v3_dot(Ng, C), sgn);
+    if (!(den != 0.0f)) return 0;
+    if (!(U >= 0.0f)) return 0;
+    if (!(V >= 0.0f)) return 0;
+    if (!(U + V <= absDen)) return 0;
+    if (!(absDen * tnear < T)) return 0;
+    if (!(T <= absDen * tfar)) return 0;
+    *t_out = T / absDen;
+    return 1;
+}
+
+int lso_tri_intersect(const float *org, const float *dir, const float *a, const float *b,
+                      const float *c, float *t_out)
+{
+    v3 o = {org[0], org[1], org[2]}, d = {dir[0], dir[1], dir[2]};
+    v3 v0 = {a[0], a[1], a[2]}, v1 = {b[0], b[1], b[2]}, v2 = {c[0], c[1], c[2]};
+    return tri_test(o, d, v0, v1, v2, 0.0f, INFINITY, t_out);
+}
+
+/* Brute-force closest hit of one ray (origin 0, LidarDevice.cpp:320) over triangles [0,ntris).
+ * verts: float[3*nverts] (sensor frame); tris: uint32[3*ntris] indices into verts (already
+ * rebased so that the global triangle id `gid` orders triangles by (geomID, primID)). */
+static void closest_brute(const float *dir, const float *verts, const uint32_t *tris, uint32_t ntris,
+                          float *t_best, uint32_t *gid_best)
+{
+    const v3 o = {0.f, 0.f, 0.f};
+    const v3 d = {dir[0], dir[1], dir[2]};
+    float best = INFINITY;
+    uint32_t bid = LSO_INVALID;
+    for (uint32_t k = 0; k < ntris; ++k) {
+        const float *a = verts + 3 * (size_t)tris[3 * k + 0];
+        const float *b = verts + 3 * (size_t)tris[3 * k + 1];
+        const float *c = verts + 3 * (size_t)tris[3 * k + 2];
+        v3 v0 = {a[0], a[1], a[2]}, v1 = {b[0], b[1], b[2]}, v2 = {c[0], c[1], c[2]};
+        float t;
+        if (tri_test(o, d, v0, v1, v2, 0.0f, INFINITY, &t)) {
+            if (t < best) { best = t; bid = k; } /* ascending k: equal t keeps the lowest id */
+        }
+    }
+    *t_best = (bid == LSO_INVALID) ? -1.0f : best;
+    *gid_best = bid;
+}
+
+typedef struct {
+    const float *dirs; const float *verts; const uint32_t *tris; uint32_t ntris;
+    float *t; uint32_t *gid; uint32_t r0, r1;
+} brute_job;
+
+static void *brute_worker(void *p)
+{
+    brute_job *j = (brute_job *)p;
+    for (uint32_t r = j->r0; r < j->r1; ++r)
+        closest_brute(j->dirs + 3 * (size_t)r, j->verts, j->tris, j->ntris, j->t + r, j->gid + r);
+    return NULL;
+}
+
+/* t[r] = hit distance or -1; gid[r] = global triangle id or 0xFFFFFFFF */
+void lso_trace_bruteforce(const float *dirs, uint32_t nrays, const float *verts, const uint32_t *tris,
+                          uint32_t ntris, float *t, uint32_t *gid, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    brute_job jobs[256];
+    for (int i = 0; i < nthreads; ++i) {
+        jobs[i] = (brute_job){dirs, verts, tris, ntris, t, gid,
+                              (uint32_t)((uint64_t)nrays * i / nthreads),
+                              (uint32_t)((uint64_t)nrays * (i + 1) / nthreads)};
+        pthread_create(&th[i], NULL, brute_worker, &jobs[i]);
+    }
+    for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * CPU BVH tracer used (a) as the cpu_baseline of bench.py and (b) to check full-size GPU
+ * results.  Binned-SAH BVH2, leaves <= 4 triangles, single-ray stack traversal, near child
+ * first.  The box test is conservative (tmax padded by 2 ulp-ish, Ize 2013) and culls with
+ * `tnear_box <= t_best`, so the result equals lso_trace_bruteforce bit for bit (same tri_test,
+ * same tie-break); tests/test_oracle.py checks that.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float lo[3], hi[3];
+    uint32_t left;  /* internal: index of left child (right = left+1); leaf: first prim slot */
+    uint32_t count; /* 0 = internal, else number of prims */
+} cpu_node;
+
+typedef struct {
+    cpu_node *nodes; uint32_t nnodes;
+    uint32_t *prim;     /* permutation: slot -> global triangle id */
+    float *tv;          /* 9 floats per slot: v0,v1,v2 */
+    uint32_t ntris;
+} lso_bvh;
+
+typedef struct { float lo[3], hi[3], c[3]; } prim_info;
+
+static void box_init(float *lo, float *hi) { for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
+static void box_grow(float *lo, float *hi, const float *l2, const float *h2)
+{
+    for (int a = 0; a < 3; ++a) { if (l2[a] < lo[a]) lo[a] = l2[a]; if (h2[a] > hi[a]) hi[a] = h2[a]; }
+}
+static float box_area(const float *lo, const float *hi)
+{
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0.f) return 0.f;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+#define NBINS 16
+static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t node, uint32_t first, uint32_t n)
+{
+    cpu_node *nd = &b->nodes[node];
+    float clo[3], chi[3];
+    box_init(nd->lo, nd->hi);
+    box_init(clo, chi);
+    for (uint32_t i = first; i < first + n; ++i) {
+        const prim_info *p = &pi[idx[i]];
+        box_grow(nd->lo, nd->hi, p->lo, p->hi);
+        box_grow(clo, chi, p->c, p->c);
+    }
+    if (n <= 4) { nd->left = first; nd->count = n; return; }
+    int bestAxis = -1, bestSplit = -1;
+    float bestCost = INFINITY;
+    for (int a = 0; a < 3; ++a) {
+        const float ext = chi[a] - clo[a];
+        if (!(ext > 0.f)) continue;
+        float blo[NBINS][3], bhi[NBINS][3];
+        uint32_t bc[NBINS];
+        for (int k = 0; k < NBINS; ++k) { box_init(blo[k], bhi[k]); bc[k] = 0; }
+        const float scale = (float)NBINS / ext;
+        for (uint32_t i = first; i < first + n; ++i) {
+            const prim_info *p = &pi[idx[i]];
+            int k = (int)((p->c[a] - clo[a]) * scale);
+            if (k >= NBINS) k = NBINS - 1;
+            if (k < 0) k = 0;
+            box_grow(blo[k], bhi[k], p->lo, p->hi);
+            bc[k]++;
+        }
+        float rarea[NBINS];
+        uint32_t rcount[NBINS];
+        float l2[3], h2[3];
+        box_init(l2, h2);
+        uint32_t c = 0;
+        for (int k = NBINS - 1; k >= 1; --k) {
+            box_grow(l2, h2, blo[k], bhi[k]);
+            c += bc[k];
+            rarea[k] = box_area(l2, h2);
+            rcount[k] = c;
+        }
+        box_init(l2, h2);
+        c = 0;
+        for (int k = 0; k < NBINS - 1; ++k) {
+            box_grow(l2, h2, blo[k], bhi[k]);
+            c += bc[k];
+            if (c == 0 || rcount[k + 1] == 0) continue;
+            const float cost = box_area(l2, h2) * (float)c + rarea[k + 1] * (float)rcount[k + 1];
+            if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = k; }
+        }
+    }
+    uint32_t mid;
+    if (bestAxis < 0) {
+        mid = first + n / 2; /* all centroids equal: median split by position */
+    } else {
+        const float ext = chi[bestAxis] - clo[bestAxis];
+        const float scale = (float)NBINS / ext;
+        uint32_t i = first, j = first + n;
+        while (i < j) {
+            const prim_info *p = &pi[idx[i]];
+            int k = (int)((p->c[bestAxis] - clo[bestAxis]) * scale);
+            if (k >= NBINS) k = NBINS - 1;
+            if (k < 0) k = 0;
+            if (k <= bestSplit) ++i;
+            else { --j; uint32_t tmp = idx[i]; idx[i] = idx[j]; idx[j] = tmp; }
+        }
+        mid = i;
+        if (mid == first || mid == first + n) mid = first + n / 2;
+    }
+    const uint32_t left = b->nnodes;
+    b->nnodes += 2;
+    nd->left = left;
+    nd->count = 0;
+    build_rec(b, pi, idx, left, first, mid - first);
+    build_rec(b, pi, idx, left + 1, mid, first + n - mid);
+}
+
+lso_bvh *lso_bvh_build(const float *verts, const uint32_t *tris, uint32_t ntris)
+{
+    lso_bvh *b = (lso_bvh *)calloc(1, sizeof(lso_bvh));
+    b->ntris = ntris;
+    if (ntris == 0) return b;
+    prim_info *pi = (prim_info *)malloc(sizeof(prim_info) * ntris);
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * ntris);
+    for (uint32_t k = 0; k < ntris; ++k) {
+        box_init(pi[k].lo, pi[k].hi);
+        float m = 0.0f;
+        for (int c = 0; c < 3; ++c) {
+            const float *p = verts + 3 * (size_t)tris[3 * k + c];
+            box_grow(pi[k].lo, pi[k].hi, p, p);
+            for (int a = 0; a < 3; ++a) if (fabsf(p[a]) > m) m = fabsf(p[a]);
+        }
+        for (int a = 0; a < 3; ++a) pi[k].c[a] = 0.5f * (pi[k].lo[a] + pi[k].hi[a]);
+        /* pad: tri_test accepts rays that miss the exact triangle by rounding error, so the
+         * boxes must be a little fatter than the exact bounds for BVH == brute force */
+        const float pad = m * 0x1p-16f;
+        for (int a = 0; a < 3; ++a) { pi[k].lo[a] -= pad; pi[k].hi[a] += pad; }
+        idx[k] = k;
+    }
+    b->nodes = (cpu_node *)malloc(sizeof(cpu_node) * (2 * (size_t)ntris + 1));
+    b->nnodes = 1;
+    build_rec(b, pi, idx, 0, 0, ntris);
+    b->prim = idx;
+    b->tv = (float *)malloc(sizeof(float) * 9 * (size_t)ntris);
+    for (uint32_t s = 0; s < ntris; ++s)
+        for (int c = 0; c < 3; ++c)
+            memcpy(b->tv + 9 * (size_t)s + 3 * c, verts + 3 * (size_t)tris[3 * idx[s] + c], 12);
+    free(pi);
+    return b;
+}
+
+void lso_bvh_free(lso_bvh *b)
+{
+    if (!b) return;
+    free(b->nodes); free(b->prim); free(b->tv); free(b);
+}
+
+uint32_t lso_bvh_node_count(const lso_bvh *b) { return b->nnodes; }
+
+/* conservative slab test for a ray from the origin; returns entry distance via *t0 */
+static inline int box_hit(const float *lo, const float *hi, const float *inv, float tbest, float *t0)
+{
+    float tn = 0.0f, tf = tbest;
+    for (int a = 0; a < 3; ++a) {
+        const float t1 = lo[a] * inv[a], t2 = hi[a] * inv[a]; /* inv is finite: no NaN */
+        const float mn = fminf(t1, t2);
+        const float mx = fmaxf(t1, t2) * 1.0000004f; /* 1 + 3 ulp: robust traversal (Ize 2013) */
+        tn = fmaxf(tn, mn);
+        tf = fminf(tf, mx);
+    }
+    *t0 = tn;
+    return tn <= tf;
+}
+
+static void closest_bvh(const lso_bvh *b, const float *dir, float *t_best, uint32_t *gid_best,
+                        uint64_t *nnode, uint64_t *ntri)
+{
+    float best = INFINITY;
+    uint32_t bid = LSO_INVALID;
+    if (b->ntris == 0) { *t_best = -1.0f; *gid_best = LSO_INVALID; return; }
+    float inv[3];
+    for (int a = 0; a < 3; ++a) /* |d| < 1e-30 -> 1e-30 keeps inv finite (azimuth 0 has dy == 0) */
+        inv[a] = 1.0f / (fabsf(dir[a]) < 1e-30f ? copysignf(1e-30f, dir[a]) : dir[a]);
+    const v3 o = {0.f, 0.f, 0.f}, d = {dir[0], dir[1], dir[2]};
+    uint32_t stack[128];
+    int sp = 0;
+    float t0;
+    ++*nnode;
+    if (box_hit(b->nodes[0].lo, b->nodes[0].hi, inv, best, &t0)) stack[sp++] = 0;
+    while (sp) {
+        const cpu_node *nd = &b->nodes[stack[--sp]];
+        if (nd->count) {
+            for (uint32_t s = nd->left; s < nd->left + nd->count; ++s) {
+                const float *tv = b->tv + 9 * (size_t)s;
+                v3 v0 = {tv[0], tv[1], tv[2]}, v1 = {tv[3], tv[4], tv[5]}, v2 = {tv[6], tv[7], tv[8]};
+                float t;
+                ++*ntri;
+                if (tri_test(o, d, v0, v1, v2, 0.0f, INFINITY, &t)) {
+                    const uint32_t id = b->prim[s];
+                    if (t < best || (t == best && id < bid)) { best = t; bid = id; }
+                }
+            }
+            continue;
+        }
+        float ta, tb;
+        const int ha = box_hit(b->nodes[nd->left].lo, b->nodes[nd->left].hi, inv, best, &ta);
+        const int hb = box_hit(b->nodes[nd->left + 1].lo, b->nodes[nd->left + 1].hi, inv, best, &tb);
+        *nnode += 2;
+        if (ha && hb) {
+            if (ta <= tb) { stack[sp++] = nd->left + 1; stack[sp++] = nd->left; }
+            else { stack[sp++] = nd->left; stack[sp++] = nd->left + 1; }
+        } else if (ha) stack[sp++] = nd->left;
+        else if (hb) stack[sp++] = nd->left + 1;
+    }
+    *t_best = (bid == LSO_INVALID) ? -1.0f : best;
+    *gid_best = bid;
+}
+
+typedef struct {
+    const lso_bvh *b; const float *dirs; float *t; uint32_t *gid; uint32_t r0, r1;
+    uint64_t nnode, ntri;
+} bvh_job;
+
+static void *bvh_worker(void *p)
+{
+    bvh_job *j = (bvh_job *)p;
+    for (uint32_t r = j->r0; r < j->r1; ++r)
+        closest_bvh(j->b, j->dirs + 3 * (size_t)r, j->t + r, j->gid + r, &j->nnode, &j->ntri);
+    return NULL;
+}
+
+/* stats (optional, may be NULL): stats[0] = box tests, stats[1] = triangle tests, summed over rays */
+void lso_bvh_trace(const lso_bvh *b, const float *dirs, uint32_t nrays, float *t, uint32_t *gid,
+                   int nthreads, uint64_t *stats)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    bvh_job jobs[256];
+    /* interleave small blocks so threads get equal shares of hit and miss channels */
+    for (int i = 0; i < nthreads; ++i) {
+        jobs[i] = (bvh_job){b, dirs, t, gid, (uint32_t)((uint64_t)nrays * i / nthreads),
+                            (uint32_t)((uint64_t)nrays * (i + 1) / nthreads), 0, 0};
+        pthread_create(&th[i], NULL, bvh_worker, &jobs[i]);
+    }
+    uint64_t a = 0, c = 0;
+    for (int i = 0; i < nthreads; ++i) { pthread_join(th[i], NULL); a += jobs[i].nnode; c += jobs[i].ntri; }
+    if (stats) { stats[0] = a; stats[1] = c; }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-9  Hit -> 32-byte point.  EmbreeTracer.cpp:340-346: xyz = tfar*dir (float), intensity 64.0;
+ * ring = channel index (LidarDeviceKernels.cu:51; the Embree path's constant 0 is a bug, SURVEY
+ * appendix).  XYZIRBytes.cpp:24-40: x@0 y@4 z@8 0@12 intensity@16 ring(int32)@20 0@24..31.
+ * Points are emitted in ray-index order (the reference's order is thread-interleaved and
+ * nondeterministic).  hits (optional): 4 x uint32 per point {ray index, geomID, primID, t bits};
+ * geom_first[g] = first global triangle id of geometry slot g (ascending), ngeom slots,
+ * geom_ids[g] = the geomID of slot g.
+ * ------------------------------------------------------------------------------------------ */
+uint32_t lso_pack_points(const float *t, const uint32_t *gid, const float *dirs, uint32_t nrays,
+                         uint32_t H, const uint32_t *geom_first, const uint32_t *geom_ids,
+                         uint32_t ngeom, uint8_t *points, uint32_t *hits)
+{
+    uint32_t n = 0;
+    for (uint32_t r = 0; r < nrays; ++r) {
+        if (gid[r] == LSO_INVALID) continue;
+        const float *d = dirs + 3 * (size_t)r;
+        const float xyz[3] = {t[r] * d[0], t[r] * d[1], t[r] * d[2]};
+        const float intensity = 64.0f;
+        const int32_t ring = (int32_t)(r / H);
+        uint8_t *p = points + 32 * (size_t)n;
+        memset(p, 0, 32);
+        memcpy(p + 0, xyz, 12);
+        memcpy(p + 16, &intensity, 4);
+        memcpy(p + 20, &ring, 4);
+        if (hits) {
+            uint32_t g = 0;
+            while (g + 1 < ngeom && geom_first[g + 1] <= gid[r]) ++g;
+            hits[4 * (size_t)n + 0] = r;
+            hits[4 * (size_t)n + 1] = geom_ids ? geom_ids[g] : g;
+            hits[4 * (size_t)n + 2] = gid[r] - (ngeom ? geom_first[g] : 0);
+            memcpy(&hits[4 * (size_t)n + 3], &t[r], 4);
+        }
+        ++n;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Walk a BVH that the HIP library built (downloaded with ls_debug_download_bvh; layout in
+ * include/lidarshooter_hip.h) in exactly the kernel's stackless order, to (a) check that the
+ * device traversal of that BVH is what the CPU gets from the same arrays and (b) count the
+ * node fetches and triangle tests per ray that bench.py's algorithmic-bytes figure uses.
+ *   node slot s (32 B): float lo[3]; uint32 left; float hi[3]; uint32 skip
+ *       even s = leaf s/2 (left = number of triangle records, first record = (s/2)*leaf_size)
+ *       odd  s = internal node (left = slot of first child); skip = next slot in DFS order
+ *       0xFFFFFFFF ends the walk; root slot = (nslots > 1) ? 1 : 0
+ *   triangle record (48 B): float v0[3]; uint32 gid; float e1[3]; float NgC; float e2[3]; uint32 pad
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { float lo[3]; uint32_t left; float hi[3]; uint32_t skip; } dev_node;
+typedef struct { float v0[3]; uint32_t gid; float e1[3]; float NgC; float e2[3]; uint32_t pad; } dev_tri;
+
+void lso_inorder_traverse_stats(const void *nodes_, const void *tris_, uint32_t nslots, uint32_t leaf_size,
+                                const float *dirs, uint32_t nrays, float *t_out, uint32_t *gid_out,
+                                uint64_t *stats)
+{
+    const dev_node *nodes = (const dev_node *)nodes_;
+    const dev_tri *tris = (const dev_tri *)tris_;
+    uint64_t nn = 0, nt = 0;
+    for (uint32_t r = 0; r < nrays; ++r) {
+        const float *dir = dirs + 3 * (size_t)r;
+        float inv[3];
+        for (int a = 0; a < 3; ++a)
+            inv[a] = 1.0f / (fabsf(dir[a]) < 1e-30f ? copysignf(1e-30f, dir[a]) : dir[a]);
+        const v3 d = {dir[0], dir[1], dir[2]};
+        float best = INFINITY;
+        uint32_t bid = LSO_INVALID;
+        uint32_t n = nslots ? (nslots > 1 ? 1u : 0u) : LSO_INVALID;
+        while (n != LSO_INVALID) {
+            const dev_node *nd = &nodes[n];
+            float t0;
+            ++nn;
+            if (!box_hit(nd->lo, nd->hi, inv, best, &t0)) { n = nd->skip; continue; }
+            if (n & 1u) { n = nd->left; continue; }
+            const uint32_t first = (n >> 1) * leaf_size;
+            for (uint32_t s = first; s < first + nd->left; ++s) {
+                const dev_tri *tr = &tris[s];
+                const v3 v0 = {tr->v0[0], tr->v0[1], tr->v0[2]};
+                const v3 e1 = {tr->e1[0], tr->e1[1], tr->e1[2]};
+                const v3 e2 = {tr->e2[0], tr->e2[1], tr->e2[2]};
+                ++nt;
+                /* tri_test() with org = 0 and e1, e2, dot(Ng,C) taken from the record */
+                const v3 Ng = v3_cross(e2, e1);
+                const v3 R = v3_cross(v0, d);
+                const float den = v3_dot(Ng, d);
+                const float absDen = fabsf(den);
+                uint32_t sgn;
+                memcpy(&sgn, &den, 4);
+                sgn &= 0x80000000u;
+                const float U = xor_sign(v3_dot(R, e2), sgn);
+                const float V = xor_sign(v3_dot(R, e1), sgn);
+                const float T = xor_sign(tr->NgC, sgn);
+                if (den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absDen && 0.0f < T) {
+                    const float t = T / absDen;
+                    if (t < best || (t == best && tr->gid < bid)) { best = t; bid = tr->gid; }
+                }
+            }
+            n = nd->skip;
+        }
+        t_out[r] = (bid == LSO_INVALID) ? -1.0f : best;
+        gid_out[r] = bid;
+    }
+    if (stats) { stats[0] = nn; stats[1] = nt; }
+}

@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path, called through the C ABI (lidarshooter_amd/capi.py), against the
+CPU oracle on identical inputs.  Bar (BASELINE.json north_star): identical hit triangle ids and
+channel indices; hit t and XYZ within 1e-4 relative.  Because the kernels and the oracle use the
+same float operation sequence, the tests first ask for bit-equality and report how far off t is
+if that ever fails; ids must always be identical.
+
+Test cases mirror the reference's gtests (EmbreeTracer_test.cpp, OptixTracer_test.cpp)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_tracer
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4  # north_star tolerance on t / XYZ
+
+
+def _add(tr, name, mesh):
+    gid = tr.addGeometry(name, mesh[0].shape[0], mesh[1].shape[0])
+    assert gid >= 0
+    return gid
+
+
+def _assert_parity(O, sensor, tr, meshes_list, pts, hits):
+    """meshes_list: [(geomID, verts, tris, affine)] as given to the tracer."""
+    ref = O.trace_frame(sensor, meshes_list)
+    t, gid = tr.denseHits()
+    assert np.array_equal(gid, ref["gid"]), "hit triangle ids / hit-miss set differ from the oracle"
+    hit = ref["gid"] != O.INVALID
+    rel = np.abs(t[hit] - ref["t"][hit]) / np.abs(ref["t"][hit])
+    assert rel.size == 0 or float(rel.max()) <= REL_TOL
+    assert np.array_equal(t, ref["t"]), f"t not bit-equal (max rel err {rel.max() if rel.size else 0})"
+    # packed outputs
+    assert pts.shape == ref["points"].shape
+    assert np.array_equal(pts, ref["points"])
+    got = np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1)
+    assert np.array_equal(got, ref["hits"])
+    return ref
+
+
+@pytest.mark.parametrize("uid,with_ben,expected", [
+    ("0000", False, 1668),   # EmbreeTracer_test.cpp:122-135 / OptixTracer_test.cpp:93-120
+    ("0000", True, 1781),    # OptixTracer_test.cpp:122-169
+    ("0001", False, 1633),
+    ("0001", True, 1769),
+])
+def test_xt32_known_answers(oracle, capi, sensors, meshes, uid, with_ben, expected):
+    s = sensors[uid]
+    tr = make_tracer(capi, s)
+    assert tr.getTotalRays() == 4800                      # LidarDevice_test.cpp:58
+    ml = []
+    g0 = _add(tr, "ground", meshes["ground"])
+    ml.append((g0, *meshes["ground"], oracle.IDENTITY_AFFINE))
+    if with_ben:
+        g1 = _add(tr, "face", meshes["ben"])
+        ml.append((g1, *meshes["ben"], oracle.IDENTITY_AFFINE))
+    for gid, v, t, A in ml:
+        assert tr.updateGeometry("ground" if gid == g0 else "face", A, v, t) == 0
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    assert rc == 0
+    assert len(pts) == expected                           # cloud->width * cloud->height
+    _assert_parity(oracle, s, tr, ml, pts, hits)
+    # golden vectors committed under tests/golden
+    g = np.load(os.path.join(GOLDEN, "xt32_golden.npz"))
+    k = f"lidar_{uid}_{'ground_ben' if with_ben else 'ground'}"
+    t, gid = tr.denseHits()
+    assert np.array_equal(gid, g[k + "_gid"]) and np.array_equal(t, g[k + "_t"])
+    assert hashlib.sha256(pts.tobytes()).digest() == g[k + "_points_sha256"].tobytes()
+    tr.close()
+
+
+def test_geometry_bookkeeping(capi, sensors, meshes):
+    # EmbreeTracer_test.cpp:86-120, OptixTracer_test.cpp:171-215
+    tr = make_tracer(capi, sensors["0000"])
+    gid = _add(tr, "mesh", meshes["ground"])
+    assert tr.getGeometryCount() == 1
+    assert tr.getVertexCount("mesh") == 98 and tr.getElementCount("mesh") == 162
+    assert tr.getGeometryId("mesh") == gid
+    g2 = _add(tr, "face", meshes["ben"])
+    assert g2 == gid + 1 and tr.getGeometryCount() == 2
+    assert tr.addGeometry("face", 3, 1) < 0                                   # duplicate key
+    assert tr.addGeometry("quad", 4, 1, geometry_type=1) < 0                  # unsupported type
+    assert tr.removeGeometry("mesh") == gid
+    assert tr.getGeometryCount() == 1
+    assert tr.removeGeometry("mesh") == -1                                    # EmbreeTracer.cpp:224-225
+    g3 = _add(tr, "again", meshes["ground"])
+    assert g3 == gid                                                          # lowest free id is reused
+    assert tr.removeGeometry("face") == g2 and tr.removeGeometry("again") == g3
+    assert tr.getGeometryCount() == 0
+    assert tr.getGeometryId("nope") < 0
+    tr.close()
+
+
+def test_remove_and_retrace_sequence(oracle, capi, sensors, meshes):
+    # OptixTracer_test.cpp:217-311: 1781 -> remove "face" -> 1668 -> remove "ground" -> -1 / 0 points
+    s = sensors["0000"]
+    tr = make_tracer(capi, s)
+    _add(tr, "ground", meshes["ground"])
+    _add(tr, "face", meshes["ben"])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    assert tr.commitScene() == 0
+    rc, pts, _ = tr.traceScene(0)
+    assert rc == 0 and len(pts) == 1781
+    assert tr.removeGeometry("face") == 1
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(1)
+    assert rc == 0 and len(pts) == 1668
+    _assert_parity(oracle, s, tr, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)], pts, hits)
+    assert tr.removeGeometry("ground") == 0
+    assert tr.commitScene() == -1                         # OptixTracer.cpp:266-267
+    rc, pts, _ = tr.traceScene(2)
+    assert rc == -1 and len(pts) == 0                     # OptixTracer.cpp:280-288
+    assert tr.getGeometryCount() == 0
+    tr.close()
+
+
+def test_dual_sensor_shared_scene(oracle, capi, sensors, meshes):
+    # BASELINE.json configs[2]: lidar_0000 + lidar_0001, one tracer per sensor (mainwindow.cpp:258)
+    trs = {u: make_tracer(capi, sensors[u]) for u in ("0000", "0001")}
+    for u, tr in trs.items():
+        _add(tr, "ground", meshes["ground"])
+        _add(tr, "face", meshes["ben"])
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+        tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+        assert tr.commitScene() == 0
+    ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)]
+    for u, n in (("0000", 1781), ("0001", 1769)):
+        rc, pts, hits = trs[u].traceScene(5)
+        assert rc == 0 and len(pts) == n
+        _assert_parity(oracle, sensors[u], trs[u], ml, pts, hits)
+    for tr in trs.values():
+        tr.close()
+
+
+def test_moved_mesh_components(oracle, capi, sensors, meshes):
+    # updateGeometry(name, translation, rotation, mesh): EmbreeTracer.cpp:276-288, MeshTransformer.cpp:467-477
+    s = sensors["0000"]
+    lin, ang = [1.5, -2.0, 0.25], [0.1, -0.2, 0.7]
+    tr = make_tracer(capi, s)
+    _add(tr, "ground", meshes["ground"])
+    _add(tr, "face", meshes["ben"])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    tr.updateGeometryComponents("face", lin, ang, *meshes["ben"])
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    A = oracle.affine_from_components(lin, ang)
+    _assert_parity(oracle, s, tr, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)], pts, hits)
+    g = np.load(os.path.join(GOLDEN, "xt32_golden.npz"))
+    assert np.array_equal(A, g["benmoved_affine"])
+    t, gid = tr.denseHits()
+    assert np.array_equal(gid, g["lidar_0000_ground_benmoved_gid"])
+    assert np.array_equal(t, g["lidar_0000_ground_benmoved_t"])
+    # transform-only update (AffineMesh pose change): back to identity without re-sending vertices
+    tr.updateGeometryTransform("face", oracle.IDENTITY_AFFINE)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(1)
+    assert len(pts) == 1781
+    tr.close()
+
+
+def test_vertex_stride_and_transformed_vertices(oracle, capi, sensors, meshes):
+    s = sensors["0001"]
+    v, t = meshes["ben"]
+    rec = np.zeros((v.shape[0], 8), np.float32)           # 32-byte XYZIRPoint-like records
+    rec[:, :3] = v
+    rec[:, 3:] = 123.0
+    tr = make_tracer(capi, s)
+    _add(tr, "face", meshes["ben"])
+    A = oracle.affine_from_components([0.5, 0.25, -0.125], [0.3, 0.2, -0.1])
+    tr.updateGeometry("face", A, rec, t, stride=32)
+    assert tr.commitScene() == 0
+    dv, dt = tr.downloadScene()
+    assert np.array_equal(dv, oracle.transform_vertices(v, A, s))     # bit-exact vertex transform
+    assert np.array_equal(dt, t)
+    rc, pts, hits = tr.traceScene(0)
+    _assert_parity(oracle, s, tr, [(0, v, t, A)], pts, hits)
+    tr.close()
+
+
+@pytest.mark.parametrize("leaf", [1, 2, 4, 8])
+def test_leaf_sizes(oracle, capi, sensors, meshes, leaf):
+    s = sensors["0000"]
+    tr = make_tracer(capi, s)
+    tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
+    _add(tr, "ground", meshes["ground"])
+    _add(tr, "face", meshes["ben"])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    assert len(pts) == 1781
+    _assert_parity(oracle, s, tr, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE),
+                                   (1, *meshes["ben"], oracle.IDENTITY_AFFINE)], pts, hits)
+    # the BVH walked on the CPU (same arrays, same order) gives the same answer and the same counts
+    tr.setOption(capi.LS_OPT_COUNT_VISITS, 1)
+    tr.traceScene(1)
+    nodes, tri, g = tr.downloadBvh()
+    assert g == leaf
+    t2, gid2, stats = oracle.inorder_traverse_stats(nodes, tri, g, oracle.ray_dirs(s))
+    t, gid = tr.denseHits()
+    assert np.array_equal(gid2, gid) and np.array_equal(t2, t)
+    assert tr.visitCounts() == (int(stats[0]), int(stats[1]))
+    tr.close()
+
+
+def test_bvh_structure(oracle, capi, sensors, meshes):
+    """Every node's box contains its children's; leaves partition the triangles; skip links walk
+    the whole tree in depth-first order."""
+    tr = make_tracer(capi, sensors["0000"])
+    tr.setOption(capi.LS_OPT_LEAF_SIZE, 2)
+    _add(tr, "face", meshes["ben"])
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    assert tr.commitScene() == 0
+    nodes, tri, g = tr.downloadBvh()
+    nt = tri.shape[0]
+    L = (nt + g - 1) // g
+    assert nodes.shape[0] == 2 * L - 1
+    assert sorted(tri["gid"].tolist()) == list(range(nt))
+    # walk: always descend
+    n, seen_leaves, steps = 1, [], 0
+    while n != 0xFFFFFFFF:
+        steps += 1
+        nd = nodes[n]
+        if n & 1:
+            c = nodes[nd["left"]]
+            assert np.all(c["lo"] >= nd["lo"]) and np.all(c["hi"] <= nd["hi"])
+            n = int(nd["left"])
+        else:
+            seen_leaves.append(n >> 1)
+            lo = tri["v0"][(n >> 1) * g:(n >> 1) * g + nd["left"]]
+            assert np.all(lo >= nd["lo"] - 1e-3) and np.all(lo <= nd["hi"] + 1e-3)
+            n = int(nd["skip"])
+    assert steps == 2 * L - 1
+    assert seen_leaves == list(range(L))                  # left-to-right = Morton order
+    tr.close()
+
+
+def test_raygen_kernel(oracle, capi, sensors):
+    # LidarDevice::allRaysGPU (LidarDeviceKernels.cu:25-126) vs the libm tables of the CPU path
+    import torch
+    s = sensors["0000"]
+    tr = make_tracer(capi, s)
+    n = tr.getTotalRays()
+    d = torch.zeros(3, n, dtype=torch.float32, device="cuda:0")
+    tr.generateRays(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
+    tr.synchronize()
+    assert np.array_equal(d.cpu().numpy().T, oracle.ray_dirs(s))
+    tr.close()
+
+
+def test_shards_union_equals_full(oracle, capi, sensors, meshes):
+    from lidarshooter_amd import synth
+    s = sensors["0000"]
+    ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)]
+    ref = oracle.trace_frame(s, ml)
+    allhits = []
+    for world in (3, 8):
+        allhits.clear()
+        for rank in range(world):
+            tr = make_tracer(capi, s)
+            first, n = synth.shard_columns(s.H, world, rank)
+            tr.setShard(first, n)
+            assert tr.getTotalRays() == s.V * n
+            _add(tr, "ground", meshes["ground"])
+            _add(tr, "face", meshes["ben"])
+            tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+            tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+            assert tr.commitScene() == 0
+            rc, pts, hits = tr.traceScene(0)
+            allhits.append((pts, hits))
+            tr.close()
+        hits = np.concatenate([h for _, h in allhits])
+        pts = np.concatenate([p for p, _ in allhits])
+        order = np.argsort(hits["ray"], kind="stable")
+        got = np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1)[order]
+        assert np.array_equal(got, ref["hits"])
+        assert np.array_equal(pts[order], ref["points"])
+
+
+def test_synthetic_medium_vs_oracle_and_bruteforce(oracle, capi, sensors):
+    """20k-triangle relief mesh, XT-32 and a 64x512 sensor: GPU BVH == oracle brute force == GPU
+    exhaustive kernel, for several leaf sizes."""
+    from lidarshooter_amd import synth
+    v, t = synth.grid_mesh(100, 100, half=40.0, seed=11)
+    base = sensors["0000"]
+    s = oracle.Sensor(uid="syn", vertical=synth.syn_vertical(64), h_begin=np.float32(0), h_end=np.float32(360),
+                      h_count=512, R=base.R, Rinv=base.Rinv, t=base.t)
+    ml = [(0, v, t, oracle.IDENTITY_AFFINE)]
+    ref = oracle.trace_frame(s, ml, use_bvh=True)
+    assert int((ref["gid"] != oracle.INVALID).sum()) > 5000
+    for leaf in (1, 4):
+        tr = make_tracer(capi, s)
+        tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
+        tr.addGeometry("g", v.shape[0], t.shape[0])
+        tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(0)
+        _assert_parity(oracle, s, tr, ml, pts, hits)
+        bt, bg = tr.bruteForce()
+        assert np.array_equal(bg, ref["gid"]) and np.array_equal(bt, ref["t"])
+        tr.close()

@@ -1,0 +1,184 @@
+"""CPU tests of the oracle against every known answer the reference's own gtests hold for the hot
+path, against the committed golden vectors, and of its internal
+consistency (BVH tracer == brute force).  No GPU."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN
+
+
+def _meshes(meshes, with_ben, O):
+    m = [(0, meshes["ground"][0], meshes["ground"][1], O.IDENTITY_AFFINE)]
+    if with_ben:
+        m.append((1, meshes["ben"][0], meshes["ben"][1], O.IDENTITY_AFFINE))
+    return m
+
+
+def test_stl_counts(meshes):
+    # EmbreeTracer_test.cpp:86-91: ground.stl -> 98 vertices, 162 triangles
+    assert meshes["ground"][0].shape == (98, 3)
+    assert meshes["ground"][1].shape == (162, 3)
+    assert meshes["ben"][1].shape == (5489, 3)
+    assert int(meshes["ben"][1].max()) == meshes["ben"][0].shape[0] - 1
+
+
+def test_sensor_config(sensors):
+    # LidarDevice_test.cpp:51-59
+    s = sensors["0000"]
+    assert s.uid == "lidar_0000"
+    assert s.total_rays == 150 * 32 == 4800
+    assert s.V == 32 and s.H == 150
+    assert float(s.h_begin) == 0.0 and float(s.h_end) == 360.0
+    assert sensors["0001"].uid == "lidar_0001"
+    # pose: R * Rinv ~ I (quaternion in the file is unit to float precision)
+    R, Ri = s.R.reshape(3, 3), s.Rinv.reshape(3, 3)
+    assert np.allclose(R @ Ri, np.eye(3), atol=1e-6)
+
+
+def test_init_message(oracle, sensors):
+    # LidarDevice_test.cpp:61-76
+    m = oracle.init_message(sensors["0000"], 7)
+    assert len(m["fields"]) == 5
+    assert m["height"] == 1 and m["width"] == 0
+    assert m["point_step"] == 32 and m["row_step"] == 0
+    assert m["is_bigendian"] is False and m["is_dense"] is True
+    assert m["seq"] == 7 and m["frame_id"] == "PandarXT-32"
+    assert [f[0] for f in m["fields"]] == ["x", "y", "z", "intensity", "ring"]
+    assert [f[1] for f in m["fields"]] == [0, 4, 8, 16, 20]
+
+
+def test_json_comments_and_url(oracle):
+    txt = '{ "a": "http://x//y", // trailing\n "b": 1 /* c */ }'
+    import json
+    j = json.loads(oracle.strip_json_comments(txt))
+    assert j == {"a": "http://x//y", "b": 1}
+
+
+@pytest.mark.parametrize("uid,with_ben,expected", [
+    ("0000", False, 1668),   # EmbreeTracer_test.cpp:122-135, OptixTracer_test.cpp:93-120
+    ("0000", True, 1781),    # OptixTracer_test.cpp:122-169
+    ("0001", False, 1633),   # SURVEY.md 8c (survey-session evidence, not reference-owned)
+    ("0001", True, 1769),
+])
+def test_reference_hit_counts(oracle, sensors, meshes, uid, with_ben, expected):
+    r = oracle.trace_frame(sensors[uid], _meshes(meshes, with_ben, oracle))
+    assert len(r["points"]) == expected
+    assert len(r["hits"]) == expected
+    assert int((r["gid"] != oracle.INVALID).sum()) == expected
+
+
+def test_empty_scene(oracle, sensors):
+    # OptixTracer_test.cpp:292-310: empty scene -> 0 points
+    r = oracle.trace_frame(sensors["0000"], [])
+    assert len(r["points"]) == 0
+
+
+def test_ring_histogram_and_range(oracle, sensors, meshes):
+    # SURVEY.md 8c evidence
+    s = sensors["0000"]
+    r = oracle.trace_frame(s, _meshes(meshes, False, oracle))
+    ring = r["hits"][:, 0] // s.H
+    h = np.bincount(ring, minlength=32)
+    assert list(h[:18]) == [0] * 18
+    assert list(h[18:23]) == [9, 48, 74, 83, 104]
+    assert list(h[23:]) == [150] * 9
+    t = r["t"][r["t"] > 0]
+    assert abs(float(t.min()) - 16.7702) < 1e-3 and abs(float(t.max()) - 75.9094) < 1e-3
+    r2 = oracle.trace_frame(s, _meshes(meshes, True, oracle))
+    assert abs(float(r2["t"][r2["t"] > 0].min()) - 13.0177) < 1e-3
+
+
+def test_point_layout(oracle, sensors, meshes):
+    # XYZIRBytes.cpp:24-40
+    s = sensors["0000"]
+    r = oracle.trace_frame(s, _meshes(meshes, True, oracle))
+    p = r["points"]
+    f = p.view(np.float32).reshape(-1, 8)
+    i = p.view(np.int32).reshape(-1, 8)
+    assert np.all(i[:, 3] == 0) and np.all(i[:, 6:] == 0)
+    assert np.all(f[:, 4] == 64.0)
+    ray = r["hits"][:, 0]
+    assert np.array_equal(i[:, 5], (ray // s.H).astype(np.int32))
+    t = r["hits"][:, 3].view(np.float32)
+    assert np.array_equal(f[:, 0], t * r["dirs"][ray, 0])
+    assert np.array_equal(f[:, 2], t * r["dirs"][ray, 2])
+    assert np.all(np.diff(ray.astype(np.int64)) > 0)          # ray-index order
+    # geom/prim ids decode the global id
+    gid = r["gid"][ray]
+    geom, prim = r["hits"][:, 1], r["hits"][:, 2]
+    assert np.array_equal(np.where(gid >= 162, 1, 0), geom)
+    assert np.array_equal(np.where(gid >= 162, gid - 162, gid), prim)
+
+
+def test_golden_vectors(oracle, sensors, meshes):
+    g = np.load(os.path.join(GOLDEN, "xt32_golden.npz"))
+    for uid in ("0000", "0001"):
+        assert np.array_equal(oracle.ray_dirs(sensors[uid]), g[f"lidar_{uid}_dirs"])
+        assert np.array_equal(sensors[uid].Rinv, g[f"lidar_{uid}_Rinv"])
+        for scene, wb in (("ground", False), ("ground_ben", True)):
+            r = oracle.trace_frame(sensors[uid], _meshes(meshes, wb, oracle))
+            k = f"lidar_{uid}_{scene}"
+            assert np.array_equal(r["t"], g[k + "_t"])
+            assert np.array_equal(r["gid"], g[k + "_gid"])
+            assert hashlib.sha256(r["points"].tobytes()).digest() == g[k + "_points_sha256"].tobytes()
+            assert hashlib.sha256(r["hits"].tobytes()).digest() == g[k + "_hits_sha256"].tobytes()
+
+
+def test_bvh_equals_bruteforce_shipped(oracle, sensors, meshes):
+    for uid in ("0000", "0001"):
+        a = oracle.trace_frame(sensors[uid], _meshes(meshes, True, oracle))
+        b = oracle.trace_frame(sensors[uid], _meshes(meshes, True, oracle), use_bvh=True)
+        assert np.array_equal(a["t"], b["t"]) and np.array_equal(a["gid"], b["gid"])
+
+
+def test_bvh_equals_bruteforce_synthetic(oracle, sensors):
+    from lidarshooter_amd import synth
+    v, t = synth.grid_mesh(60, 40, half=30.0, seed=3)
+    s = sensors["0001"]
+    m = [(0, v, t, oracle.IDENTITY_AFFINE)]
+    a = oracle.trace_frame(s, m)
+    b = oracle.trace_frame(s, m, use_bvh=True)
+    assert int((a["gid"] != oracle.INVALID).sum()) > 500
+    assert np.array_equal(a["t"], b["t"]) and np.array_equal(a["gid"], b["gid"])
+
+
+def test_tie_break_lowest_id(oracle, sensors):
+    # two coincident triangles: equal t, the lower (geomID, primID) must win
+    s = sensors["0000"]
+    d = oracle.ray_dirs(s)[31 * s.H + 10].astype(np.float64)       # a downward ray
+    c = d * 20.0
+    # build a triangle around point c, perpendicular-ish to the ray, directly in the sensor frame
+    u = np.cross(d, [0, 0, 1.0]); u /= np.linalg.norm(u)
+    w = np.cross(d, u)
+    tri = np.array([c + 2 * u, c - u + 2 * w, c - u - 2 * w], np.float32)
+    scene = oracle.Scene(np.concatenate([tri, tri]), np.array([[0, 1, 2], [3, 4, 5]], np.uint32),
+                         np.array([0, 1], np.uint32), np.array([0, 1], np.uint32))
+    t, gid = oracle.trace_bruteforce(oracle.ray_dirs(s), scene)
+    hit = gid != oracle.INVALID
+    assert hit.sum() > 0 and np.all(gid[hit] == 0)
+    bv = oracle.CpuBvh(scene)
+    t2, gid2, _ = bv.trace(oracle.ray_dirs(s))
+    assert np.array_equal(gid, gid2) and np.array_equal(t, t2)
+
+
+def test_transform_components_identity(oracle):
+    A = oracle.affine_from_components([0, 0, 0], [0, 0, 0])
+    assert np.array_equal(A, oracle.IDENTITY_AFFINE)
+    A = oracle.affine_from_components([1, 2, 3], [0, 0, np.pi / 2])
+    R = A.reshape(3, 4)[:, :3]
+    assert np.allclose(R, [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-6)
+    assert np.array_equal(A.reshape(3, 4)[:, 3], np.array([1, 2, 3], np.float32))
+
+
+def test_vertex_stride(oracle, sensors, meshes):
+    s = sensors["0000"]
+    v = meshes["ground"][0]
+    rec = np.zeros((v.shape[0], 8), np.float32)       # 32-byte records like XYZIRPoint (XYZIRPoint.hpp:11-35)
+    rec[:, :3] = v
+    rec[:, 3:] = 7.0
+    a = oracle.transform_vertices(v, oracle.IDENTITY_AFFINE, s)
+    b = oracle.transform_vertices(rec, oracle.IDENTITY_AFFINE, s, stride=32)
+    assert np.array_equal(a, b)
