@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the LiDAR tracer hot path on MI355X.
+
+Metric (BASELINE.json): Mrays/s (and LiDAR frames/s) for a 128-channel x 4096-azimuth sensor over
+a 1M-triangle mesh (BASELINE.json configs[3] = BASELINE.md section 4 config 4, "SYN-128 x SYN-1M").
+One "step" = one LiDAR frame = the reference's per-frame sequence (MeshProjector.cpp:446-464):
+updateGeometry(every mesh) + commitScene (vertex transform + full BVH rebuild) + traceScene
+(ray generation + closest hit + point packing), with the mesh already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): rays are
+  sharded by azimuth sector, every rank keeps a full BVH replica, and one all-gather of the
+  fixed-capacity hit-record slots per frame (count word in the slot header) collects the cloud.
+
+Rank 0 prints ONE JSON line (see README/DESIGN.md for the extra keys).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from lidarshooter_amd import capi, hostapi, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NODE_BYTES, TRI_BYTES, RAY_OUT_BYTES = 32, 48, 8  # DESIGN.md "algorithmic bytes"
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "xt32"])
+    ap.add_argument("--leaf", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--breakdown", action="store_true", help="extra pass with per-stage hipEvent timings")
+    return ap.parse_args()
+
+
+def build_workload(name):
+    """-> (sensor dict for capi.Tracer, list of (mesh name, verts f32[n,3], tris u32[m,3]))."""
+    dev = hostapi.LidarDevice(os.path.join(DATA, "config", "hesai-pandar-XT-32-lidar_0000.json"))
+    d = dev.desc()
+    if name == "xt32":
+        g = hostapi.PolygonMesh(os.path.join(DATA, "mesh", "ground.stl"))
+        b = hostapi.PolygonMesh(os.path.join(DATA, "mesh", "ben.stl"))
+        return d, [("ground", g.points(), g.polygons()), ("face", b.points(), b.polygons())]
+    d = dict(d)
+    d["vertical"] = synth.syn_vertical(128)      # +15 .. -25 deg
+    d["h_begin"], d["h_end"], d["h_count"] = np.float32(0.0), np.float32(360.0), 4096
+    v, t = synth.syn_1m()
+    return d, [("ground1m", v, t)]
+
+
+def cpu_baseline(sensor, meshes, frames, total_rays):
+    """The oracle's CPU path (oracle/: binned-SAH BVH2, threaded single-ray traversal) timed on
+    the host cores for the SAME frame definition: transform + full BVH build + trace + pack."""
+    from oracle import oracle as O
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    s = O.Sensor(uid="bench", vertical=sensor["vertical"], h_begin=sensor["h_begin"], h_end=sensor["h_end"],
+                 h_count=sensor["h_count"], R=np.eye(3, dtype=np.float32).reshape(9), Rinv=sensor["Rinv"], t=sensor["t"])
+    ml = [(i, v, t, O.IDENTITY_AFFINE) for i, (_, v, t) in enumerate(meshes)]
+    dirs = O.ray_dirs(s)
+    times, parts = [], []
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        scene = O.assemble_scene(s, ml)
+        t1 = time.perf_counter()
+        bvh = O.CpuBvh(scene, ncpu)
+        t2 = time.perf_counter()
+        tt, gid, _ = bvh.trace(dirs, ncpu)
+        O.pack_points(tt, gid, dirs, s.H, scene)
+        t3 = time.perf_counter()
+        bvh.close()
+        times.append(t3 - t0)
+        parts.append((t1 - t0, t2 - t1, t3 - t2))
+        if sum(times) > 30.0:
+            break
+    med = float(np.median(times))
+    p = np.median(np.array(parts), axis=0)
+    return {
+        "value": total_rays / med / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "port",
+        "frames_per_s": 1.0 / med,
+        "sample": f"{len(times)} full frames of the same workload (median): transform {p[0]*1e3:.0f} ms + "
+                  f"binned-SAH BVH2 build {p[1]*1e3:.0f} ms + trace/pack {p[2]*1e3:.0f} ms, {ncpu} threads; "
+                  "CPU restatement (Embree 3.13.4 is not installed)",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    sensor, meshes = build_workload(args.workload)
+    V, H = int(sensor["vertical"].shape[0]), int(sensor["h_count"])
+    first_az, n_az = synth.shard_columns(H, world, rank)
+    cap = V * max(synth.shard_columns(H, world, r)[1] for r in range(world))  # records per slot
+
+    tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"],
+                     device=local_rank)
+    if args.leaf:
+        tr.setOption(capi.LS_OPT_LEAF_SIZE, args.leaf)
+    tr.setShard(first_az, n_az)
+    # a dedicated (non-default) stream shared by the tracer's kernels and, through torch, by RCCL's
+    # stream dependencies: the all-gather of frame i is ordered after frame i's pack kernel
+    stream = torch.cuda.Stream(device)
+    tr.setStream(stream.cuda_stream)
+    torch.cuda.set_stream(stream)
+
+    # inputs resident in HBM before the timed region
+    d_meshes = []
+    for name, v, t in meshes:
+        dv = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(device)
+        dt = torch.from_numpy(np.ascontiguousarray(t, np.uint32).view(np.int32)).to(device)
+        assert tr.addGeometry(name, v.shape[0], t.shape[0]) >= 0
+        d_meshes.append((name, dv, dt))
+    # one slot = [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap]; gathered slots for N > 1
+    slot_bytes = 64 + 48 * cap
+    slot = torch.zeros(slot_bytes, dtype=torch.uint8, device=device)
+    gathered = torch.zeros(world * slot_bytes, dtype=torch.uint8, device=device) if world > 1 else None
+    base = slot.data_ptr()
+    tr.setOutputBuffers(base + 64, base + 64 + 32 * cap, base, cap)
+    ident = capi.IDENTITY_AFFINE
+
+    def frame(i):
+        for name, dv, dt in d_meshes:                      # MeshProjector.cpp:448-461
+            tr.updateGeometryDevice(name, ident, dv.data_ptr(), 12, dt.data_ptr())
+        tr.commitScene()
+        tr.traceSceneAsync(i)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, slot)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    # ---- node / triangle visits per ray on this BVH (algorithmic bytes), outside the timed region
+    tr.setOption(capi.LS_OPT_COUNT_VISITS, 1)
+    frame(0)
+    sync()
+    n_node, n_tri = tr.visitCounts()
+    tr.setOption(capi.LS_OPT_COUNT_VISITS, 0)
+    shard_rays = tr.getTotalRays()
+    n_hits = int(slot[:4].view(torch.int32).item())
+    info = tr.sceneSize()
+
+    for i in range(args.warmup):
+        frame(i)
+    sync()
+    tr.setOption(capi.LS_OPT_TIMING, 2)      # hipEvents around the trace kernel only, never syncs
+    tr.timings()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    tm = tr.timings()
+    tr.setOption(capi.LS_OPT_TIMING, 0)
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e.item())
+
+    breakdown = None
+    if args.breakdown or world == 1:
+        tr.setOption(capi.LS_OPT_TIMING, 1)
+        tr.timings()
+        for i in range(min(args.steps, 50)):
+            frame(i)
+        sync()
+        breakdown = tr.timings()
+        tr.setOption(capi.LS_OPT_TIMING, 0)
+        # trace-only frames (static scene, BVH kept): the traversal kernel + pack, nothing else
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            tr.traceSceneAsync(i)
+        sync()
+        trace_only_s = (time.perf_counter() - t1) / args.steps
+
+    total_rays = V * H
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays * args.steps / elapsed / 1e6
+    trace_ms = tm["trace"]
+    b_ray = RAY_OUT_BYTES + (NODE_BYTES * n_node + TRI_BYTES * n_tri) / shard_rays
+    achieved = (b_ray * shard_rays) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+
+    out = {
+        "metric": "Mrays/s (full LiDAR frame: update + BVH rebuild + trace + pack; 128ch x 4096az over 1M tris)"
+                  if args.workload == "syn128x1m" else "Mrays/s (XT-32 over ground+ben)",
+        "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)"
+                   if args.workload == "syn128x1m" else "XT-32 lidar_0000 x ground.stl+ben.stl",
+                   "rays_per_frame": total_rays, "triangles": info["n_tris"], "leaf_size": info["leaf_size"],
+                   "bvh_node_slots": info["n_slots"], "frame": "updateGeometry(device) + commitScene(full rebuild) + traceScene",
+                   "parallelism": f"azimuth-sector shards x{world}, BVH replica per GPU, all-gather of hit slots"
+                   if world > 1 else "single GPU"},
+        "frames_per_s": args.steps / elapsed,
+        "hits_per_frame_rank0": n_hits,
+        "roofline": {
+            "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel_ms": trace_ms, "frames_timed": tm["frames"], "rays_per_launch": shard_rays,
+            "bytes_per_ray": b_ray, "nodes_per_ray": n_node / shard_rays, "tris_per_ray": n_tri / shard_rays,
+        },
+    }
+    if breakdown is not None:
+        out["stage_ms"] = {k: round(v, 5) for k, v in breakdown.items() if k != "frames"}
+        out["trace_only_ms"] = trace_only_s * 1e3
+        out["trace_only_mrays_per_s"] = shard_rays / trace_only_s / 1e6
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sensor, meshes, args.cpu_frames, total_rays)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    tr.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

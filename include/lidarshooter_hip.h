@@ -164,13 +164,15 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 
 /* ---- options */
 #define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1..8), default 2; takes effect at next commit  */
-#define LS_OPT_TIMING 2         /* 1: bracket every stage with hipEvents (ls_get_timings)                 */
+#define LS_OPT_TIMING 2         /* 1: bracket every stage with hipEvents, 2: only the trace kernel        */
 #define LS_OPT_COUNT_VISITS 3   /* 1: trace kernel also counts node fetches / triangle tests              */
 #define LS_OPT_REFIT 4          /* 1: commit refits the BVH when the geometry set is unchanged
                                  *    (OptixTracer.cpp:532-535 OPERATION_UPDATE); 0 (default): full rebuild */
 int ls_tracer_set_option(ls_tracer *tr, int option, int value);
 
-/* Stage timings of the last commit + trace, milliseconds from hipEvents on the handle's stream. */
+/* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded
+ * since the previous call; recording never synchronises, this call does.  Returns the number of
+ * frames averaged (>= 0) or a negative ls_status. */
 #define LS_T_TRANSFORM 0
 #define LS_T_MORTON 1
 #define LS_T_SORT 2

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -59,6 +60,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname
+    # libamdhip64.so.7, the one this library needs).  Importing torch first makes the loader bind
+    # this library to that copy; loading /opt/rocm's copy first and torch's afterwards would put
+    # two HIP runtimes in the process and the second one finds no GPU.
+    if "torch" not in sys.modules and os.environ.get("LS_HIP_STANDALONE") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise LidarShooterHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -254,9 +264,12 @@ class Tracer:
         return self._check(self.L.ls_tracer_set_option(self.h, option, value), "ls_tracer_set_option")
 
     def timings(self) -> dict:
+        """Mean stage durations in ms over the frames recorded since the last call (+ 'frames')."""
         ms = np.zeros(len(STAGES), np.float32)
-        self._check(self.L.ls_get_timings(self.h, _f32p(ms)), "ls_get_timings")
-        return dict(zip(STAGES, [float(x) for x in ms]))
+        n = self._check(self.L.ls_get_timings(self.h, _f32p(ms)), "ls_get_timings")
+        d = dict(zip(STAGES, [float(x) for x in ms]))
+        d["frames"] = int(n)
+        return d
 
     def visitCounts(self):
         c = (C.c_uint64 * 2)()

@@ -92,11 +92,17 @@ struct ls_tracer {
     bool traced = false;
 
     // options / measurement
-    bool opt_timing = false, opt_count = false, opt_refit = false;
-    hipEvent_t ev[LS_T_COUNT + 2] = {};
-    bool ev_valid[LS_T_COUNT + 2] = {};
-    float last_ms[LS_T_COUNT] = {};
-    uint64_t last_visits[2] = {0, 0};
+    int opt_timing = 0;  // 0 off, 1 every stage, 2 only the trace kernel
+    bool opt_count = false, opt_refit = false;
+    // hipEvent records: one TimingRecord per frame (commit marks 0..6, trace marks 7..9), kept until
+    // ls_get_timings averages and recycles them, so that timing a run never synchronises inside it.
+    struct TimingRecord {
+        hipEvent_t ev[LS_T_COUNT + 2];
+        bool set[LS_T_COUNT + 2];
+    };
+    std::vector<TimingRecord> trec;
+    size_t trec_used = 0;
+    bool trec_open = false;
 };
 
 namespace {
@@ -169,13 +175,31 @@ int ensure_outputs(ls_tracer *tr)
     return LS_OK;
 }
 
+constexpr size_t kMaxTimingRecords = 4096;
+
+// Marks 0..6 bracket the six commit stages, 7..9 bracket trace and pack.  A commit opens a new
+// record; a trace without a preceding commit opens its own.
 void mark(ls_tracer *tr, int i)
 {
     if (!tr->opt_timing) return;
-    if (!tr->ev[i]) {
-        if (hipEventCreate(&tr->ev[i]) != hipSuccess) return;
+    if (tr->opt_timing == 2 && i != 7 && i != 8) return;
+    const bool opens = (i == 0) || (i == 7 && !tr->trec_open);
+    if (opens) {
+        if (tr->trec_used >= kMaxTimingRecords) { tr->trec_open = false; return; }
+        if (tr->trec_used == tr->trec.size()) {
+            ls_tracer::TimingRecord r;
+            for (auto &e : r.ev) e = nullptr;
+            tr->trec.push_back(r);
+        }
+        for (auto &b : tr->trec[tr->trec_used].set) b = false;
+        ++tr->trec_used;
+        tr->trec_open = true;
     }
-    tr->ev_valid[i] = hipEventRecord(tr->ev[i], tr->stream) == hipSuccess;
+    if (!tr->trec_open || tr->trec_used == 0) return;
+    ls_tracer::TimingRecord &r = tr->trec[tr->trec_used - 1];
+    if (!r.ev[i] && hipEventCreate(&r.ev[i]) != hipSuccess) return;
+    r.set[i] = hipEventRecord(r.ev[i], tr->stream) == hipSuccess;
+    if (i == 9 || (tr->opt_timing == 2 && i == 8)) tr->trec_open = false;
 }
 
 // LidarDevice.cpp:306-316 on the host: the V+H distinct angles of a revolution go through libm
@@ -509,8 +533,9 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->h_points) (void)hipHostFree(tr->h_points);
     if (tr->h_hits) (void)hipHostFree(tr->h_hits);
     if (tr->h_n_points) (void)hipHostFree(tr->h_n_points);
-    for (auto &e : tr->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto &r : tr->trec)
+        for (auto &e : r.ev)
+            if (e) (void)hipEventDestroy(e);
     if (tr->own_stream) (void)hipStreamDestroy(tr->own_stream);
     delete tr;
 }
@@ -701,7 +726,11 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(tr, LS_ERR_INVALID_ARGUMENT, "leaf size must be 1, 2, 4 or 8");
         tr->leaf_size = (uint32_t)value;
         return LS_OK;
-    case LS_OPT_TIMING: tr->opt_timing = value != 0; return LS_OK;
+    case LS_OPT_TIMING:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "timing level must be 0, 1 or 2");
+        tr->opt_timing = value;
+        tr->trec_open = false;
+        return LS_OK;
     case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
     case LS_OPT_REFIT: tr->opt_refit = value != 0; return LS_OK;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown option");
@@ -713,17 +742,23 @@ int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT])
     LS_ENTER(tr);
     if (!ms) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
     LS_HIP(hipStreamSynchronize(tr->stream));
-    // events: 0..6 bracket the six commit stages, 7..9 bracket trace and pack
     static const int first[LS_T_COUNT] = {0, 1, 2, 3, 4, 5, 7, 8};
-    for (int i = 0; i < LS_T_COUNT; ++i) {
-        ms[i] = 0.0f;
-        const int a = first[i], b = a + 1;
-        if (tr->ev[a] && tr->ev[b] && tr->ev_valid[a] && tr->ev_valid[b]) {
+    double sum[LS_T_COUNT] = {};
+    uint32_t cnt[LS_T_COUNT] = {};
+    for (size_t k = 0; k < tr->trec_used; ++k) {
+        const ls_tracer::TimingRecord &r = tr->trec[k];
+        for (int i = 0; i < LS_T_COUNT; ++i) {
+            const int a = first[i], b = a + 1;
+            if (!r.set[a] || !r.set[b]) continue;
             float v = 0.0f;
-            if (hipEventElapsedTime(&v, tr->ev[a], tr->ev[b]) == hipSuccess) ms[i] = v;
+            if (hipEventElapsedTime(&v, r.ev[a], r.ev[b]) == hipSuccess) { sum[i] += v; ++cnt[i]; }
         }
     }
-    return LS_OK;
+    for (int i = 0; i < LS_T_COUNT; ++i) ms[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.0f;
+    const int n = (int)tr->trec_used;
+    tr->trec_used = 0;
+    tr->trec_open = false;
+    return n;
 }
 
 int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[2])

@@ -341,7 +341,17 @@ static float box_area(const float *lo, const float *hi)
 }
 
 #define NBINS 16
-static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t node, uint32_t first, uint32_t n)
+typedef struct { lso_bvh *b; const prim_info *pi; uint32_t *idx; uint32_t node, first, n; int par; } build_job;
+static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t node, uint32_t first, uint32_t n, int par);
+static void *build_thread(void *p)
+{
+    build_job *j = (build_job *)p;
+    build_rec(j->b, j->pi, j->idx, j->node, j->first, j->n, j->par);
+    return NULL;
+}
+
+/* par = remaining levels at which the two children are built by two threads */
+static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t node, uint32_t first, uint32_t n, int par)
 {
     cpu_node *nd = &b->nodes[node];
     float clo[3], chi[3];
@@ -409,16 +419,26 @@ static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t n
         mid = i;
         if (mid == first || mid == first + n) mid = first + n / 2;
     }
-    const uint32_t left = b->nnodes;
-    b->nnodes += 2;
+    const uint32_t left = __atomic_fetch_add(&b->nnodes, 2u, __ATOMIC_RELAXED);
     nd->left = left;
     nd->count = 0;
-    build_rec(b, pi, idx, left, first, mid - first);
-    build_rec(b, pi, idx, left + 1, mid, first + n - mid);
+    if (par > 0 && n > 8192) {
+        pthread_t th;
+        build_job job = {b, pi, idx, left, first, mid - first, par - 1};
+        if (pthread_create(&th, NULL, build_thread, &job) == 0) {
+            build_rec(b, pi, idx, left + 1, mid, first + n - mid, par - 1);
+            pthread_join(th, NULL);
+            return;
+        }
+    }
+    build_rec(b, pi, idx, left, first, mid - first, 0);
+    build_rec(b, pi, idx, left + 1, mid, first + n - mid, 0);
 }
 
-lso_bvh *lso_bvh_build(const float *verts, const uint32_t *tris, uint32_t ntris)
+lso_bvh *lso_bvh_build(const float *verts, const uint32_t *tris, uint32_t ntris, int nthreads)
 {
+    int par = 0;
+    while ((1 << par) < nthreads && par < 8) ++par;
     lso_bvh *b = (lso_bvh *)calloc(1, sizeof(lso_bvh));
     b->ntris = ntris;
     if (ntris == 0) return b;
@@ -441,7 +461,7 @@ lso_bvh *lso_bvh_build(const float *verts, const uint32_t *tris, uint32_t ntris)
     }
     b->nodes = (cpu_node *)malloc(sizeof(cpu_node) * (2 * (size_t)ntris + 1));
     b->nnodes = 1;
-    build_rec(b, pi, idx, 0, 0, ntris);
+    build_rec(b, pi, idx, 0, 0, ntris, par);
     b->prim = idx;
     b->tv = (float *)malloc(sizeof(float) * 9 * (size_t)ntris);
     for (uint32_t s = 0; s < ntris; ++s)

@@ -56,7 +56,7 @@ def lib() -> C.CDLL:
         L.lso_tri_intersect.argtypes = [f32p] * 5 + [f32p]
         L.lso_tri_intersect.restype = C.c_int
         L.lso_trace_bruteforce.argtypes = [f32p, C.c_uint32, f32p, u32p, C.c_uint32, f32p, u32p, C.c_int]
-        L.lso_bvh_build.argtypes = [f32p, u32p, C.c_uint32]
+        L.lso_bvh_build.argtypes = [f32p, u32p, C.c_uint32, C.c_int]
         L.lso_bvh_build.restype = C.c_void_p
         L.lso_bvh_free.argtypes = [C.c_void_p]
         L.lso_bvh_node_count.argtypes = [C.c_void_p]
@@ -300,10 +300,10 @@ def trace_bruteforce(dirs: np.ndarray, scene: Scene, nthreads: int = 8):
 class CpuBvh:
     """Binned-SAH BVH2 + threaded single-ray tracer (cpu_baseline and full-size checker)."""
 
-    def __init__(self, scene: Scene):
+    def __init__(self, scene: Scene, nthreads: int = 8):
         self._v = np.ascontiguousarray(scene.verts, np.float32)
         self._t = np.ascontiguousarray(scene.tris, np.uint32)
-        self.h = lib().lso_bvh_build(_p(self._v, C.c_float), _p(self._t, C.c_uint32), self._t.shape[0])
+        self.h = lib().lso_bvh_build(_p(self._v, C.c_float), _p(self._t, C.c_uint32), self._t.shape[0], nthreads)
 
     def node_count(self) -> int:
         return int(lib().lso_bvh_node_count(self.h))
@@ -370,7 +370,7 @@ def trace_frame(sensor: Sensor, meshes, use_bvh: bool = False, nthreads: int = 8
         t = np.full(dirs.shape[0], -1.0, np.float32)
         gid = np.full(dirs.shape[0], INVALID, np.uint32)
     elif use_bvh:
-        b = CpuBvh(scene)
+        b = CpuBvh(scene, nthreads)
         t, gid, _ = b.trace(dirs, nthreads)
         b.close()
     else:

@@ -305,3 +305,43 @@ def test_synthetic_medium_vs_oracle_and_bruteforce(oracle, capi, sensors):
         bt, bg = tr.bruteForce()
         assert np.array_equal(bg, ref["gid"]) and np.array_equal(bt, ref["t"])
         tr.close()
+
+
+def test_host_mirror_hiptracer(oracle, sensors, meshes):
+    """The C++ host class (HipTracer : ITracer surface) end to end, reading the shipped JSON and STL
+    files itself: the reference's TraceSceneCloud test (EmbreeTracer_test.cpp:122-135) and the
+    two-mesh / remove sequence (OptixTracer_test.cpp:122-169, 217-311)."""
+    from conftest import DATA
+    from lidarshooter_amd import hostapi
+    dev = hostapi.LidarDevice(os.path.join(DATA, "config", "hesai-pandar-XT-32-lidar_0000.json"))
+    ground = hostapi.PolygonMesh(os.path.join(DATA, "mesh", "ground.stl"))
+    ben = hostapi.PolygonMesh(os.path.join(DATA, "mesh", "ben.stl"))
+    tr = hostapi.HipTracer(dev)
+    gid = tr.addGeometry("mesh", ground.numPoints(), ground.numPolygons())
+    assert gid == 0 and tr.getGeometryCount() == 1
+    assert tr.getVertexCount("mesh") == 98 and tr.getElementCount("mesh") == 162
+    assert tr.getGeometryId("mesh") == gid
+    assert tr.getVertexCount("unknown") == -100            # TraceException (EmbreeTracer.cpp:369-439)
+    assert tr.addGeometry("q", 4, 1, geometry_type=1) == 0  # EmbreeTracer.cpp:200-201 returns false
+    assert tr.updateGeometry("mesh", oracle.IDENTITY_AFFINE, ground) == 0
+    assert tr.commitScene() == 0
+    assert tr.traceScene(0) == 0
+    c = tr.getTraceCloud()
+    assert c["width"] * c["height"] == 1668 and c["point_step"] == 32 and c["seq"] == 0
+    ref = oracle.trace_frame(sensors["0000"], [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    assert np.array_equal(c["data"], ref["points"])
+    assert tr.addGeometry("face", ben.numPoints(), ben.numPolygons()) == 1
+    tr.updateGeometry("mesh", oracle.IDENTITY_AFFINE, ground)
+    tr.updateGeometryComponents("face", [0, 0, 0], [0, 0, 0], ben)
+    assert tr.commitScene() == 0 and tr.traceScene(1) == 0
+    c = tr.getTraceCloud()
+    assert c["width"] == 1781 and c["seq"] == 1
+    ref = oracle.trace_frame(sensors["0000"], [(0, *meshes["ground"], oracle.IDENTITY_AFFINE),
+                                                (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
+    assert np.array_equal(c["data"], ref["points"])
+    h = tr.getHits()
+    assert np.array_equal(np.stack([h["ray"], h["geom"], h["prim"], h["t"].view(np.uint32)], axis=1), ref["hits"])
+    assert tr.removeGeometry("face") == 1 and tr.removeGeometry("mesh") == 0
+    assert tr.commitScene() == -1 and tr.traceScene(2) == -1
+    assert tr.getTraceCloud()["width"] == 0 and tr.getGeometryCount() == 0
+    tr.close()
