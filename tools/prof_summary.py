@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense a tools_profile.sh output directory into the small summaries committed under profiles/.
+
+  python tools/prof_summary.py gpurun_out/prof_<tag> profiles/<tag>
+
+Writes <out>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, kernel names shortened) and
+<out>_hbm.json: per kernel, mean FETCH_SIZE / WRITE_SIZE per launch and the HBM bytes derived as
+MI355X_MICROARCH.md section HBM prescribes: counters are in KiB, collected in separate --pmc passes, and on
+gfx950 FETCH_SIZE reports half of the bytes fetched -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_]+)(<\w+>)?", name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    m = re.search(r"wrapped_(\w+?)_config", name)
+    if m:
+        return "rocprim::" + m.group(1)
+    return name.split("(")[0][-60:]
+
+
+def pmc(dirname, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(dirname, "*_counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            a = acc[short(row["Kernel_Name"])]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    rows = []
+    for f in glob.glob(os.path.join(src, "stats", "*_kernel_stats.csv")):
+        for row in csv.DictReader(open(f)):
+            rows.append([short(row["Name"]), row["Calls"], row["TotalDurationNs"], row["AverageNs"], row["Percentage"],
+                         row["MinNs"], row["MaxNs"], row["StdDev"]])
+    with open(out + "_kernel_stats.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        w.writerows(rows)
+    fetch = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+    write = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    hbm = {}
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, (0.0, 0))
+        wv = write.get(k, (0.0, 0))
+        hbm[k] = {"FETCH_SIZE_KiB_per_launch": f[0], "WRITE_SIZE_KiB_per_launch": wv[0], "launches": max(f[1], wv[1]),
+                  "hbm_bytes_per_launch": (2.0 * f[0] + wv[0]) * 1024.0}
+    json.dump({"note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE reads 1/2)",
+               "kernels": hbm}, open(out + "_hbm.json", "w"), indent=1)
+    for r in rows[:12]:
+        print(r[0], r[1], r[3], r[4])
+    for k, v in hbm.items():
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
