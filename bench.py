@@ -163,7 +163,7 @@ def main():
     tr.setOption(capi.LS_OPT_COUNT_VISITS, 1)
     frame(0)
     sync()
-    n_node, n_tri = tr.visitCounts()
+    n_node, n_tri, wave_trips, max_trips = tr.visitStats()
     tr.setOption(capi.LS_OPT_COUNT_VISITS, 0)
     shard_rays = tr.getTotalRays()
     n_hits = int(slot[:4].view(torch.int32).item())
@@ -228,6 +228,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "kernel_ms": trace_ms, "frames_timed": tm["frames"], "rays_per_launch": shard_rays,
             "bytes_per_ray": b_ray, "nodes_per_ray": n_node / shard_rays, "tris_per_ray": n_tri / shard_rays,
+            "wave_trips_mean": wave_trips / max(1, (shard_rays + 63) // 64), "wave_trips_max": max_trips,
         },
     }
     if breakdown is not None:

@@ -163,7 +163,7 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
                                  uint32_t capacity);
 
 /* ---- options */
-#define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1..8), default 2; takes effect at next commit  */
+#define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1,2,4,8), default 1; takes effect at next commit  */
 #define LS_OPT_TIMING 2         /* 1: bracket every stage with hipEvents, 2: only the trace kernel        */
 #define LS_OPT_COUNT_VISITS 3   /* 1: trace kernel also counts node fetches / triangle tests              */
 #define LS_OPT_REFIT 4          /* 1: commit refits the BVH when the geometry set is unchanged
@@ -184,8 +184,9 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value);
 #define LS_T_COUNT 8
 int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT]);
 
-/* Totals of the last trace when LS_OPT_COUNT_VISITS is on: {node fetches, triangle tests}. */
-int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[2]);
+/* Totals of the last trace when LS_OPT_COUNT_VISITS is on: {node fetches, triangle tests,
+ * sum over waves of traversal-loop trips (a wave runs as long as its slowest lane), max trips}. */
+int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[4]);
 
 /* ---- ray generation on its own: LidarDevice::allRaysGPU (LidarDeviceKernels.cu:25-126).
  * Writes the shard's rays as SoA float arrays of n = ls_total_rays() entries each, in device

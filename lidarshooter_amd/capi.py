@@ -272,9 +272,14 @@ class Tracer:
         return d
 
     def visitCounts(self):
-        c = (C.c_uint64 * 2)()
+        """-> (node fetches, triangle tests) of the last counted trace."""
+        return self.visitStats()[:2]
+
+    def visitStats(self):
+        """-> (node fetches, triangle tests, sum of per-wave loop trips, max loop trips)."""
+        c = (C.c_uint64 * 4)()
         self._check(self.L.ls_get_visit_counts(self.h, c), "ls_get_visit_counts")
-        return int(c[0]), int(c[1])
+        return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
     def generateRays(self, d_dx: int, d_dy: int, d_dz: int):
         return self._check(self.L.ls_generate_rays(self.h, d_dx, d_dy, d_dz), "ls_generate_rays")

@@ -74,9 +74,9 @@ __global__ __launch_bounds__(kBlock) void k_transform(const uint8_t *__restrict_
                                                       Affine m, float *__restrict__ out,
                                                       uint32_t *__restrict__ maxabs)
 {
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float s_max[kBlock / 64];
     float mx = 0.0f;
-    if (j < n) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const float *p = reinterpret_cast<const float *>(raw + (size_t)j * stride);
         const float x = p[0], y = p[1], z = p[2];
         float q[3];
@@ -91,9 +91,15 @@ __global__ __launch_bounds__(kBlock) void k_transform(const uint8_t *__restrict_
             mx = fmaxf(mx, fabsf(o));
         }
     }
+    // one atomic per block (a single hot address sustains only ~90 atomics/us chip-wide)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(maxabs, __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        if (mx > 0.0f) atomicMax(maxabs, __float_as_uint(mx));
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_rebase(const uint32_t *__restrict__ idx, uint32_t n, uint32_t vbase,
@@ -384,13 +390,13 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, const Node *_
     float best = INFINITY;
     uint32_t bid = kInvalid;
     uint32_t n = active && nslots ? (nslots > 1u ? 1u : 0u) : kInvalid;
-    uint32_t cn = 0, ctri = 0;
+    uint32_t cn = 0, ctri = 0, trips = 0;
     const float4 *nodes4 = reinterpret_cast<const float4 *>(nodes);
     const float4 *rec4 = reinterpret_cast<const float4 *>(records);
 
     while (n != kInvalid) {
         const float4 A = nodes4[2 * (size_t)n], B = nodes4[2 * (size_t)n + 1];
-        if (COUNT) ++cn;
+        if (COUNT) { ++cn; ++trips; }
         const float x1 = A.x * ix, x2 = B.x * ix, y1 = A.y * iy, y2 = B.y * iy, z1 = A.z * iz, z2 = B.z * iz;
         const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
         const float tf = fminf(fminf(fmaxf(x1, x2) * kSlabPad, fmaxf(y1, y2) * kSlabPad),
@@ -420,8 +426,17 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, const Node *_
     if (lane == 0) row_counts[row] = (uint32_t)__popcll(hits);
     if (COUNT) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { cn += __shfl_xor(cn, off); ctri += __shfl_xor(ctri, off); }
-        if (lane == 0) { atomicAdd(&visit_counts[0], (unsigned long long)cn); atomicAdd(&visit_counts[1], (unsigned long long)ctri); }
+        for (int off = 32; off >= 1; off >>= 1) {
+            cn += __shfl_xor(cn, off);
+            ctri += __shfl_xor(ctri, off);
+            trips = max(trips, (uint32_t)__shfl_xor(trips, off));
+        }
+        if (lane == 0) {
+            atomicAdd(&visit_counts[0], (unsigned long long)cn);
+            atomicAdd(&visit_counts[1], (unsigned long long)ctri);
+            atomicAdd(&visit_counts[2], (unsigned long long)trips);  // loop trips of the wave = its slowest lane
+            atomicMax(&visit_counts[3], (unsigned long long)trips);
+        }
     }
 }
 
@@ -560,7 +575,7 @@ void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t 
     for (int i = 0; i < 12; ++i) m.a[i] = affine12[i];
     for (int i = 0; i < 9; ++i) m.rinv[i] = rinv9[i];
     for (int i = 0; i < 3; ++i) m.t[i] = t3[i];
-    hipLaunchKernelGGL(k_transform, dim3(blocks_for(n)), dim3(kBlock), 0, s, static_cast<const uint8_t *>(raw),
+    hipLaunchKernelGGL(k_transform, dim3(min(blocks_for(n), 512u)), dim3(kBlock), 0, s, static_cast<const uint8_t *>(raw),
                        stride, n, m, out_xyz, d_maxabs_bits);
 }
 
@@ -578,11 +593,16 @@ void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint
                        keys, vals);
 }
 
+// rocprim's default configuration falls back to a merge sort up to 2^20 items (10 merge passes
+// at 1M triangles); 30-bit keys sort in 4 onesweep radix passes instead.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, 32768>;
+
 size_t sort_temp_bytes(uint32_t n)
 {
     size_t bytes = 0;
     uint32_t *p = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)n, 0u, 30u);
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, p, p, p, p, (size_t)n, 0u, 30u);
     return bytes;
 }
 
@@ -590,7 +610,7 @@ void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in
                  uint32_t *vals_in, uint32_t *vals_out, uint32_t n)
 {
     if (!n) return;
-    (void)rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 30u, s);
+    (void)rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 30u, s);
 }
 
 void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,

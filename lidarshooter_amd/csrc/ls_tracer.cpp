@@ -64,7 +64,7 @@ struct ls_tracer {
     // committed scene
     std::vector<int> slot_geom_ids;       // geometry ids in layout order
     std::vector<uint32_t> slot_tri_first; // [n+1]
-    uint32_t n_verts = 0, n_tris = 0, n_leaves = 0, n_slots = 0, leaf_size = 2, committed_leaf_size = 2;
+    uint32_t n_verts = 0, n_tris = 0, n_leaves = 0, n_slots = 0, leaf_size = 1, committed_leaf_size = 1;
     bool committed = false;
     DevBuf<float> verts;
     DevBuf<uint32_t> tris, keys_a, keys_b, vals_a, vals_b, geom_table;
@@ -427,7 +427,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     uint8_t *d_points = tr->ext_points ? static_cast<uint8_t *>(tr->ext_points) : tr->points.p;
     void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
     uint32_t *d_n = tr->ext_points ? tr->ext_n_points : tr->d_n_points;
-    if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 16, s));
+    if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 32, s));
     mark(tr, 7);
     ls::launch_trace(s, tb, tr->nodes.p, tr->records.p, tr->n_slots, tr->committed_leaf_size, tr->hit_t.p,
                      tr->hit_gid.p, tr->row_counts.p, tr->opt_count ? tr->d_visits : nullptr);
@@ -508,7 +508,7 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_tables), tab.size() * 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMemcpy(tr->d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_maxabs), 4) != hipSuccess) return bail(LS_ERR_HIP);
-    if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16) != hipSuccess) return bail(LS_ERR_HIP);
     tr->slot_tri_first.assign(1, 0u);
@@ -761,12 +761,12 @@ int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT])
     return n;
 }
 
-int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[2])
+int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[4])
 {
     LS_ENTER(tr);
     if (!counts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
     LS_HIP(hipStreamSynchronize(tr->stream));
-    LS_HIP(hipMemcpy(counts, tr->d_visits, 16, hipMemcpyDeviceToHost));
+    LS_HIP(hipMemcpy(counts, tr->d_visits, 32, hipMemcpyDeviceToHost));
     return LS_OK;
 }
 
