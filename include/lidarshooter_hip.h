@@ -208,9 +208,10 @@ int ls_debug_scene_size(ls_tracer *tr, uint32_t *n_verts, uint32_t *n_tris, uint
                         uint32_t *leaf_size);
 int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx);
 
-/* BVH arrays: node slots (32 B each) and triangle records (48 B each), layouts in DESIGN.md:
- *   node slot s: float lo[3]; uint32 left; float hi[3]; uint32 skip
- *     even s = leaf s/2 (left = number of records, first record = (s/2)*leaf_size); odd s = internal
+/* BVH arrays: n_node_slots BVH2 nodes (64 B each) and n_tris triangle records (48 B each):
+ *   node i: float4 q[4] = (L.lo.xyz, bits(left ref)), (L.hi.xyz, bits(right ref)), (R.lo.xyz, 0), (R.hi.xyz, 0)
+ *     child ref: bit 31 set = leaf k (records [k*leaf_size, k*leaf_size+leaf_size) clipped to n_tris),
+ *     else index of another node; node 0 is the root (a one-leaf scene has no node at all)
  *   triangle record: float v0[3]; uint32 gid; float e1[3]; float NgC; float e2[3]; uint32 pad */
 int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records);
 

@@ -44,7 +44,9 @@ class Frame(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("ray", "<u4"), ("geom", "<u4"), ("prim", "<u4"), ("t", "<f4")])
-NODE_DTYPE = np.dtype([("lo", "<f4", 3), ("left", "<u4"), ("hi", "<f4", 3), ("skip", "<u4")])
+NODE_DTYPE = np.dtype([("llo", "<f4", 3), ("left", "<u4"), ("lhi", "<f4", 3), ("right", "<u4"),
+                       ("rlo", "<f4", 3), ("pad0", "<u4"), ("rhi", "<f4", 3), ("pad1", "<u4")])
+LEAF_BIT = 0x80000000
 TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("gid", "<u4"), ("e1", "<f4", 3), ("NgC", "<f4"), ("e2", "<f4", 3),
                       ("pad", "<u4")])
 

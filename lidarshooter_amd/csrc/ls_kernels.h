@@ -8,17 +8,21 @@
 namespace ls {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr uint32_t kLeafBit = 0x80000000u;  // child reference: bit 31 set = leaf index, else node index
 constexpr int kMaxRangeLevels = 32;
 constexpr int kMaxGeoms = 1024;
+constexpr int kQueues = 8;           // one ray queue per XCD
+constexpr int kStackLds = 32;        // per-lane traversal stack entries kept in LDS
+constexpr int kStackSpill = 32;      // further entries in global memory (tree depth <= 62 by construction)
 
-// 32-byte BVH node slot; see DESIGN.md "BVH layout".
-struct alignas(16) Node {
-    float lo[3];
-    uint32_t left;  // internal (odd slot): slot of the first child; leaf (even slot): record count
-    float hi[3];
-    uint32_t skip;  // next slot in depth-first order once this subtree is done / culled
+// 64-byte BVH2 node: both child boxes + both child references (DESIGN.md "BVH layout").
+//   q[0] = (L.lo.x, L.lo.y, L.lo.z, bits(left ref))    q[1] = (L.hi.x, L.hi.y, L.hi.z, bits(right ref))
+//   q[2] = (R.lo.x, R.lo.y, R.lo.z, 0)                 q[3] = (R.hi.x, R.hi.y, R.hi.z, 0)
+// Node i is Karras' internal node i; the left child comes first in Morton order = front to back.
+struct alignas(64) FatNode {
+    float4 q[4];
 };
-static_assert(sizeof(Node) == 32, "node slot must be 32 bytes");
+static_assert(sizeof(FatNode) == 64, "node must be 64 bytes");
 
 // 48-byte triangle record, in Morton-sorted order (leaf k owns records [k*g, k*g+count)).
 struct alignas(16) TriRecord {
@@ -31,12 +35,12 @@ struct alignas(16) TriRecord {
 };
 static_assert(sizeof(TriRecord) == 48, "triangle record must be 48 bytes");
 
-// Aligned-range tree over the leaf boxes: level 0 = the leaf node slots themselves, level l >= 1
-// at boxes[offset[l] .. offset[l]+count[l]) where entry j bounds leaves [j<<l, (j+1)<<l).
+// Aligned-range tree over the leaf boxes: entry j of level l (at boxes[offset[l]+j], 2 x float4 =
+// lo,hi) bounds leaves [j<<l, (j+1)<<l).  Level 0 = the leaf boxes themselves.
 struct RangeTree {
-    uint32_t levels;                      // number of levels including level 0
+    uint32_t levels;
     uint32_t count[kMaxRangeLevels];
-    uint32_t offset[kMaxRangeLevels];     // in box entries (2 x float4 each); offset[0] unused
+    uint32_t offset[kMaxRangeLevels];  // in box entries
 };
 
 struct SensorTables {
@@ -46,13 +50,21 @@ struct SensorTables {
     const float *cos_phi;    // [H]
     uint32_t V, H;
     uint32_t az0, naz;       // shard: azimuth columns [az0, az0+naz)
-    uint32_t n_az_blocks;    // ceil(naz / 64)
 };
 
 struct GeomTable {
     uint32_t n;
     const uint32_t *tri_first;  // device, [n+1] ascending global triangle id offsets
     const uint32_t *geom_ids;   // device, [n]
+};
+
+// Ray queues of the persistent trace kernel: the shard's azimuth columns are cut into kQueues
+// sectors (one per XCD); queue x enumerates its sector channel by channel.  heads live in device
+// memory, one per 64-byte line.
+struct RayQueues {
+    uint32_t *heads;               // device, kQueues * 16 words, zeroed before every launch
+    uint32_t chan_mul;             // channels are visited in the order (j * chan_mul) % V (coprime with V)
+    uint32_t refill_min;           // idle lanes of a wave that trigger a refill
 };
 
 // ---- build ---------------------------------------------------------------------------------
@@ -65,15 +77,19 @@ size_t sort_temp_bytes(uint32_t n);
 void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out,
                  uint32_t *vals_in, uint32_t *vals_out, uint32_t n);
 void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,
-                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, Node *nodes);
-void launch_range_tree(hipStream_t s, const Node *nodes, const RangeTree &rt, float4 *boxes);
+                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes);
+void launch_range_tree(hipStream_t s, const RangeTree &rt, float4 *boxes);
 void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleaves, uint32_t leaf_size,
-                      const RangeTree &rt, const float4 *boxes, Node *nodes);
+                      const RangeTree &rt, const float4 *boxes, FatNode *nodes);
 
 // ---- trace ---------------------------------------------------------------------------------
-void launch_trace(hipStream_t s, const SensorTables &tb, const Node *nodes, const TriRecord *records,
-                  uint32_t nslots, uint32_t leaf_size, float *t_out, uint32_t *gid_out, uint32_t *row_counts,
+uint32_t trace_grid_blocks(int device);  // persistent grid: resident blocks of the device
+size_t trace_spill_bytes(uint32_t grid_blocks);
+void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq,
+                  const FatNode *nodes, const TriRecord *records, uint32_t nleaves, uint32_t leaf_size,
+                  uint32_t ntris, float *t_out, uint32_t *gid_out, uint32_t *spill,
                   unsigned long long *visit_counts /* nullptr = do not count */);
+void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts);
 void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
                  const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits,
                  uint32_t *n_points);

@@ -16,6 +16,7 @@
 //                        (OptixTracer.cpp:895-942)
 #include "ls_kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -25,7 +26,6 @@ namespace ls {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr float kSlabPad = 1.0000004f;  // 1 + 3 ulp on the far slab distance (robust traversal)
 
 struct V3 { float x, y, z; };
 
@@ -150,13 +150,13 @@ __global__ __launch_bounds__(kBlock) void k_morton(const float *__restrict__ ver
 
 // ------------------------------------------------------------------------------------------
 // Triangle records + leaf boxes, one thread per Morton-sorted position.
-// Leaf k = records [k*g, k*g+g); its box (padded, see below) goes to node slot 2k.
+// Leaf k = records [k*g, k*g+g); its box (padded, see below) is entry k of range-tree level 0.
 // Bytes per triangle: 4 (sorted id) + 12 (indices) + 36 (vertices) read, 48 written, + 32/g.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_leaves(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
                                                    const uint32_t *__restrict__ sorted_vals, uint32_t ntris,
                                                    uint32_t g, TriRecord *__restrict__ records,
-                                                   Node *__restrict__ nodes)
+                                                   float4 *__restrict__ boxes)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -192,17 +192,15 @@ __global__ __launch_bounds__(kBlock) void k_leaves(const float *__restrict__ ver
     }
     if (p < ntris && (p % g) == 0) {
         const uint32_t k = p / g;
-        const uint32_t cnt = min(g, ntris - p);
-        float4 *nd = reinterpret_cast<float4 *>(nodes + 2 * (size_t)k);
-        nd[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(cnt));
-        nd[1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(kInvalid));
+        boxes[2 * (size_t)k] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        boxes[2 * (size_t)k + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Aligned-range tree: entry j of level l bounds leaves [j<<l, (j+1)<<l).  Level 0 is the leaf
-// node slots.  k_range_bottom builds levels 1..9 for 512 leaves per block in LDS; k_range_top
-// finishes the (few) remaining levels in one block.  No atomics, no cross-workgroup hand-off.
+// Aligned-range tree: entry j of level l bounds leaves [j<<l, (j+1)<<l).  k_range_bottom builds
+// levels 1..9 for 512 leaves per block in LDS; k_range_top finishes the (few) remaining levels
+// in one block.  No atomics, no cross-workgroup hand-off.
 // ------------------------------------------------------------------------------------------
 struct Box { float lo[3], hi[3]; };
 
@@ -212,18 +210,12 @@ __device__ __forceinline__ void box_merge(Box &a, const Box &b)
 #pragma unroll
     for (int i = 0; i < 3; ++i) { a.lo[i] = fminf(a.lo[i], b.lo[i]); a.hi[i] = fmaxf(a.hi[i], b.hi[i]); }
 }
-__device__ __forceinline__ Box load_leaf_box(const Node *nodes, uint32_t k)
-{
-    const float4 *nd = reinterpret_cast<const float4 *>(nodes + 2 * (size_t)k);
-    const float4 a = nd[0], b = nd[1];
-    return {{a.x, a.y, a.z}, {b.x, b.y, b.z}};
-}
-__device__ __forceinline__ Box load_level_box(const float4 *boxes, uint32_t e)
+__device__ __forceinline__ Box load_box(const float4 *boxes, uint32_t e)
 {
     const float4 a = boxes[2 * (size_t)e], b = boxes[2 * (size_t)e + 1];
     return {{a.x, a.y, a.z}, {b.x, b.y, b.z}};
 }
-__device__ __forceinline__ void store_level_box(float4 *boxes, uint32_t e, const Box &b)
+__device__ __forceinline__ void store_box(float4 *boxes, uint32_t e, const Box &b)
 {
     boxes[2 * (size_t)e] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.0f);
     boxes[2 * (size_t)e + 1] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.0f);
@@ -231,8 +223,7 @@ __device__ __forceinline__ void store_level_box(float4 *boxes, uint32_t e, const
 
 constexpr int kBottomLevels = 9;  // 512 leaves per block
 
-__global__ __launch_bounds__(kBlock) void k_range_bottom(const Node *__restrict__ nodes, RangeTree rt,
-                                                         float4 *__restrict__ boxes)
+__global__ __launch_bounds__(kBlock) void k_range_bottom(RangeTree rt, float4 *__restrict__ boxes)
 {
     __shared__ float s[6][kBlock];
     const uint32_t t = threadIdx.x;
@@ -240,14 +231,14 @@ __global__ __launch_bounds__(kBlock) void k_range_bottom(const Node *__restrict_
     Box b = box_empty();
     {
         const uint32_t k0 = base0 + 2 * t;
-        if (k0 < rt.count[0]) b = load_leaf_box(nodes, k0);
-        if (k0 + 1 < rt.count[0]) { const Box c = load_leaf_box(nodes, k0 + 1); box_merge(b, c); }
+        if (k0 < rt.count[0]) b = load_box(boxes, k0);
+        if (k0 + 1 < rt.count[0]) { const Box c = load_box(boxes, k0 + 1); box_merge(b, c); }
     }
     for (uint32_t l = 1; l <= (uint32_t)kBottomLevels && l < rt.levels; ++l) {
         const uint32_t n = 512u >> l;  // entries of this level owned by the block
         if (t < n) {
             const uint32_t j = (base0 >> l) + t;
-            if (j < rt.count[l]) store_level_box(boxes, rt.offset[l] + j, b);
+            if (j < rt.count[l]) store_box(boxes, rt.offset[l] + j, b);
 #pragma unroll
             for (int i = 0; i < 3; ++i) { s[i][t] = b.lo[i]; s[3 + i][t] = b.hi[i]; }
         }
@@ -267,9 +258,9 @@ __global__ __launch_bounds__(kBlock) void k_range_top(RangeTree rt, float4 *__re
 {
     for (uint32_t l = kBottomLevels + 1; l < rt.levels; ++l) {
         for (uint32_t j = threadIdx.x; j < rt.count[l]; j += kBlock) {
-            Box b = load_level_box(boxes, rt.offset[l - 1] + 2 * j);
-            if (2 * j + 1 < rt.count[l - 1]) { const Box c = load_level_box(boxes, rt.offset[l - 1] + 2 * j + 1); box_merge(b, c); }
-            store_level_box(boxes, rt.offset[l] + j, b);
+            Box b = load_box(boxes, rt.offset[l - 1] + 2 * j);
+            if (2 * j + 1 < rt.count[l - 1]) { const Box c = load_box(boxes, rt.offset[l - 1] + 2 * j + 1); box_merge(b, c); }
+            store_box(boxes, rt.offset[l] + j, b);
         }
         __threadfence_block();
         __syncthreads();
@@ -277,13 +268,10 @@ __global__ __launch_bounds__(kBlock) void k_range_top(RangeTree rt, float4 *__re
 }
 
 // ------------------------------------------------------------------------------------------
-// Radix-tree hierarchy (Karras 2012) over the leaf keys, one thread per leaf index i:
-//   internal node i (i < L-1) lives in slot 2i+1, leaf i in slot 2i, so a subtree over leaves
-//   [l,r] occupies the contiguous slots [2l, 2r].  Each thread finds its node's range and split
-//   from the keys alone, takes the node's box from the aligned-range tree (no bottom-up pass, no
-//   atomics) and derives the skip link locally: the subtree that follows range [.,r] in
-//   depth-first order starts at leaf r+1 and is internal node r+1 iff that node's range starts
-//   there (direction +1), else leaf r+1.
+// Radix-tree hierarchy (Karras 2012) over the leaf keys, one thread per internal node i:
+// the thread finds its node's leaf range [l,r] and split from the keys alone and takes the boxes of
+// its two children [l,split] and [split+1,r] from the aligned-range tree -- no bottom-up pass, no
+// atomics, no cross-workgroup hand-off.  The left child precedes the right one in Morton order.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int delta(const uint32_t *__restrict__ keys, uint32_t g, int L, int i, uint32_t ki, int j)
 {
@@ -292,26 +280,24 @@ __device__ __forceinline__ int delta(const uint32_t *__restrict__ keys, uint32_t
     return x ? __clz(x) : 32 + __clz((uint32_t)i ^ (uint32_t)j);
 }
 
-__device__ __forceinline__ uint32_t skip_after(const uint32_t *__restrict__ keys, uint32_t g, int L, int r)
+__device__ __forceinline__ Box range_box(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t r)
 {
-    if (r >= L - 1) return kInvalid;
-    const int q = r + 1;
-    if (q <= L - 2) {
-        const uint32_t kq = keys[(size_t)q * g];
-        if (delta(keys, g, L, q, kq, q + 1) > delta(keys, g, L, q, kq, q - 1)) return 2u * (uint32_t)q + 1u;
+    Box b = box_empty();
+    uint32_t a = l, e = r + 1u, lev = 0;
+    while (a < e) {
+        if (a & 1u) { const Box c = load_box(boxes, rt.offset[lev] + a); box_merge(b, c); ++a; }
+        if (e & 1u) { --e; const Box c = load_box(boxes, rt.offset[lev] + e); box_merge(b, c); }
+        a >>= 1; e >>= 1; ++lev;
     }
-    return 2u * (uint32_t)q;
+    return b;
 }
 
 __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict__ keys, uint32_t L_, uint32_t g,
                                                       RangeTree rt, const float4 *__restrict__ boxes,
-                                                      Node *__restrict__ nodes)
+                                                      FatNode *__restrict__ nodes)
 {
     const int L = (int)L_;
     const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (i >= L) return;
-    // leaf i: skip link only (box and count were written by k_leaves)
-    nodes[2 * (size_t)i].skip = skip_after(keys, g, L, i);
     if (i >= L - 1) return;
 
     const uint32_t ki = keys[(size_t)i * g];
@@ -331,120 +317,185 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict
     } while (t > 1);
     const int gamma = i + s * d + min(d, 0);
     const int l = min(i, j), r = max(i, j);
-    const uint32_t left = (l == gamma) ? 2u * (uint32_t)gamma : 2u * (uint32_t)gamma + 1u;
-
-    // box of leaves [l, r] from the aligned-range tree
-    Box b = box_empty();
-    uint32_t a = (uint32_t)l, e = (uint32_t)r + 1u, lev = 0;
-    while (a < e) {
-        if (a & 1u) {
-            const Box c = lev ? load_level_box(boxes, rt.offset[lev] + a) : load_leaf_box(nodes, a);
-            box_merge(b, c);
-            ++a;
-        }
-        if (e & 1u) {
-            --e;
-            const Box c = lev ? load_level_box(boxes, rt.offset[lev] + e) : load_leaf_box(nodes, e);
-            box_merge(b, c);
-        }
-        a >>= 1; e >>= 1; ++lev;
-    }
-    float4 *nd = reinterpret_cast<float4 *>(nodes + 2 * (size_t)i + 1);
-    nd[0] = make_float4(b.lo[0], b.lo[1], b.lo[2], __uint_as_float(left));
-    nd[1] = make_float4(b.hi[0], b.hi[1], b.hi[2], __uint_as_float(skip_after(keys, g, L, r)));
+    const uint32_t left = (l == gamma) ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
+    const uint32_t right = (r == gamma + 1) ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+    const Box bl = range_box(rt, boxes, (uint32_t)l, (uint32_t)gamma);
+    const Box br = range_box(rt, boxes, (uint32_t)gamma + 1u, (uint32_t)r);
+    float4 *nd = nodes[i].q;
+    nd[0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
+    nd[1] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __uint_as_float(right));
+    nd[2] = make_float4(br.lo[0], br.lo[1], br.lo[2], 0.0f);
+    nd[3] = make_float4(br.hi[0], br.hi[1], br.hi[2], 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused ray generation + closest-hit traversal.  One lane per ray; a wave is 64 consecutive
-// azimuth columns of one channel (coherent rays -> its node fetches share cache lines); a block
-// is 4 adjacent channels.  Blocks are dealt to XCDs round-robin by the hardware, so the tile
-// index is remapped to give each XCD a contiguous azimuth sector (its L2 then holds that sector's
-// part of the BVH).  Traversal is stackless: follow `left` on a box hit, `skip` otherwise.
-// Outputs (padded row layout, row = channel*n_az_blocks + az_block, 64 entries per row):
-//   t_out / gid_out per ray, row_counts[row] = hits in the row (feeds the ordered pack).
+// Fused ray generation + closest-hit traversal, persistent waves with ray refill.
+//
+// The grid is exactly the resident capacity of the chip (5 blocks of 256 per CU: the 32 KB of LDS
+// stack per block is the limiter).  The shard's rays sit in kQueues queues, one per XCD: queue x =
+// azimuth sector x, enumerated channel by channel, so that the 64 rays a wave takes together are 64
+// consecutive azimuth columns of one channel (coherent: their node fetches share cache lines) and
+// an XCD's L2 keeps seeing its own sector of the BVH.  A wave reads its XCD id from HW_REG_XCC_ID
+// (speed only: an exhausted queue is followed by the others).  Whenever at least kRefillMin lanes
+// of a wave are idle -- wave-ballot -- the idle lanes take the next rays of the queue with ONE
+// atomicAdd: no lane waits for the slowest ray of its wave, and the kernel has no tail.
+//
+// Per lane: BVH2 traversal with both child boxes in the parent (one 64-byte fetch resolves two
+// boxes), left child first = front to back for every ray (sensor-centred Morton order), pending
+// right children on a per-lane stack in LDS (spill to global past 32 entries).
 // ------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, const Node *__restrict__ nodes,
-                                                  const TriRecord *__restrict__ records, uint32_t nslots,
-                                                  uint32_t g, float *__restrict__ t_out,
-                                                  uint32_t *__restrict__ gid_out, uint32_t *__restrict__ row_counts,
+template <int MODE>
+__device__ __forceinline__ float4 ld16(const float4 *p)
+{
+    if (MODE == 1) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    if (MODE == 2) {
+        float4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+    return *p;
+}
+
+template <bool COUNT, int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq, const FatNode *__restrict__ nodes,
+                                                  const TriRecord *__restrict__ records, uint32_t L, uint32_t g,
+                                                  uint32_t ntris, float *__restrict__ t_out,
+                                                  uint32_t *__restrict__ gid_out, uint32_t *__restrict__ spill,
                                                   unsigned long long *__restrict__ visit_counts)
 {
-    const uint32_t n_cg = (tb.V + 3u) >> 2;  // channel groups of 4
-    const uint32_t n_tiles = tb.n_az_blocks * n_cg;
-    uint32_t tile = blockIdx.x;
-    if ((n_tiles & 7u) == 0) tile = (blockIdx.x & 7u) * (n_tiles >> 3) + (blockIdx.x >> 3);
-    const uint32_t ab = tile / n_cg, cg = tile - ab * n_cg;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t v = __builtin_amdgcn_readfirstlane(cg * 4u + (threadIdx.x >> 6));
-    if (v >= tb.V) return;
-    const uint32_t hl = ab * 64u + lane;  // shard-local azimuth column
-    const bool active = hl < tb.naz;
-    const uint32_t h = tb.az0 + (active ? hl : 0u);
+    __shared__ uint32_t s_stack[kStackLds][kBlock];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t *my_spill = spill + ((size_t)blockIdx.x * kBlock + tid) * kStackSpill;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t qsel = xcc & (kQueues - 1);
+    uint32_t tried = 0;
+    bool drained = false;
+    const uint32_t root = (L > 1u) ? 0u : kLeafBit;
 
-    // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
-    const float st = tb.sin_theta[v], ct = tb.cos_theta[v];
-    const V3 d = {st * tb.cos_phi[h], st * tb.sin_phi[h], ct};
-    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
-
-    float best = INFINITY;
-    uint32_t bid = kInvalid;
-    uint32_t n = active && nslots ? (nslots > 1u ? 1u : 0u) : kInvalid;
+    bool has = false;
+    V3 d = {0.f, 0.f, 1.f};
+    float ix = 1.f, iy = 1.f, iz = 1.f, best = INFINITY;
+    uint32_t bid = kInvalid, q = 0, cur = kInvalid, sp = 0;
     uint32_t cn = 0, ctri = 0, trips = 0;
-    const float4 *nodes4 = reinterpret_cast<const float4 *>(nodes);
     const float4 *rec4 = reinterpret_cast<const float4 *>(records);
 
-    while (n != kInvalid) {
-        const float4 A = nodes4[2 * (size_t)n], B = nodes4[2 * (size_t)n + 1];
-        if (COUNT) { ++cn; ++trips; }
-        const float x1 = A.x * ix, x2 = B.x * ix, y1 = A.y * iy, y2 = B.y * iy, z1 = A.z * iz, z2 = B.z * iz;
-        const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
-        const float tf = fminf(fminf(fmaxf(x1, x2) * kSlabPad, fmaxf(y1, y2) * kSlabPad),
-                               fminf(fmaxf(z1, z2) * kSlabPad, best));
-        const uint32_t skip = __float_as_uint(B.w);
-        if (!(tn <= tf)) { n = skip; continue; }
-        const uint32_t left = __float_as_uint(A.w);
-        if (n & 1u) { n = left; continue; }
-        const uint32_t first = (n >> 1) * g;
-        for (uint32_t s = first; s < first + left; ++s) {
-            const float4 r0 = rec4[3 * (size_t)s], r1 = rec4[3 * (size_t)s + 1], r2 = rec4[3 * (size_t)s + 2];
-            if (COUNT) ++ctri;
-            float t;
-            if (tri_test(d, {r0.x, r0.y, r0.z}, {r1.x, r1.y, r1.z}, {r2.x, r2.y, r2.z}, r1.w, t)) {
-                const uint32_t id = __float_as_uint(r0.w);
-                if (t < best || (t == best && id < bid)) { best = t; bid = id; }
+    while (true) {
+        unsigned long long act = __ballot(has);
+        if (!drained && (uint32_t)__popcll(act) <= 64u - rq.refill_min) {
+            const unsigned long long idle = ~act;
+            const uint32_t nidle = (uint32_t)__popcll(idle);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            while (tried < (uint32_t)kQueues) {
+                const uint32_t first = (uint32_t)(((unsigned long long)qsel * tb.naz) / kQueues);
+                const uint32_t width = (uint32_t)(((unsigned long long)(qsel + 1u) * tb.naz) / kQueues) - first;
+                const uint32_t len = width * tb.V;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&rq.heads[qsel * 16u], nidle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base < len) {
+                    const uint32_t sidx = base + rank;
+                    if (!has && sidx < len) {
+                        const uint32_t j = sidx / width, c = sidx - j * width;
+                        const uint32_t v = (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        const uint32_t hl = first + c, h = tb.az0 + hl;
+                        // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
+                        const float st = tb.sin_theta[v];
+                        d = {st * tb.cos_phi[h], st * tb.sin_phi[h], tb.cos_theta[v]};
+                        ix = safe_inv(d.x); iy = safe_inv(d.y); iz = safe_inv(d.z);
+                        q = v * tb.naz + hl;
+                        best = INFINITY; bid = kInvalid; sp = 0; cur = root; has = true;
+                    }
+                    break;
+                }
+                ++tried;
+                qsel = (qsel + 1u) & (kQueues - 1);
+            }
+            if (tried >= (uint32_t)kQueues) drained = true;
+            act = __ballot(has);
+        }
+        if (act == 0ull) break;
+        if (COUNT) ++trips;
+        if (has) {
+            if (!(cur & kLeafBit)) {
+                const float4 *nd = nodes[cur].q;
+                const float4 A = ld16<MODE>(nd), B = ld16<MODE>(nd + 1), C = ld16<MODE>(nd + 2), D = ld16<MODE>(nd + 3);
+                if (COUNT) ++cn;
+                float x1 = A.x * ix, x2 = B.x * ix, y1 = A.y * iy, y2 = B.y * iy, z1 = A.z * iz, z2 = B.z * iz;
+                const float tnL = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
+                const float tfL = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), best));
+                x1 = C.x * ix; x2 = D.x * ix; y1 = C.y * iy; y2 = D.y * iy; z1 = C.z * iz; z2 = D.z * iz;
+                const float tnR = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
+                const float tfR = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), best));
+                const bool hl_ = tnL <= tfL, hr_ = tnR <= tfR;
+                const uint32_t left = __float_as_uint(A.w), right = __float_as_uint(B.w);
+                if (hl_) {
+                    cur = left;
+                    if (hr_) {  // push the far (right) child
+                        if (sp < (uint32_t)kStackLds) s_stack[sp][tid] = right;
+                        else if (sp < (uint32_t)(kStackLds + kStackSpill)) my_spill[sp - kStackLds] = right;
+                        ++sp;
+                    }
+                } else if (hr_) {
+                    cur = right;
+                } else {
+                    cur = kInvalid;
+                    if (sp) { --sp; cur = sp < (uint32_t)kStackLds ? s_stack[sp][tid] : my_spill[sp - kStackLds]; }
+                }
+            }
+            while (cur != kInvalid && (cur & kLeafBit)) {
+                const uint32_t first = (cur & ~kLeafBit) * g;
+                const uint32_t last = min(first + g, ntris);
+                for (uint32_t s = first; s < last; ++s) {
+                    const float4 r0 = ld16<MODE>(rec4 + 3 * (size_t)s), r1 = ld16<MODE>(rec4 + 3 * (size_t)s + 1), r2 = ld16<MODE>(rec4 + 3 * (size_t)s + 2);
+                    if (COUNT) ++ctri;
+                    float t;
+                    if (tri_test(d, {r0.x, r0.y, r0.z}, {r1.x, r1.y, r1.z}, {r2.x, r2.y, r2.z}, r1.w, t)) {
+                        const uint32_t id = __float_as_uint(r0.w);
+                        if (t < best || (t == best && id < bid)) { best = t; bid = id; }
+                    }
+                }
+                cur = kInvalid;
+                if (sp) { --sp; cur = sp < (uint32_t)kStackLds ? s_stack[sp][tid] : my_spill[sp - kStackLds]; }
+            }
+            if (cur == kInvalid) {
+                t_out[q] = (bid == kInvalid) ? -1.0f : best;
+                gid_out[q] = bid;
+                has = false;
             }
         }
-        n = skip;
     }
-
-    const uint32_t row = v * tb.n_az_blocks + ab;
-    const size_t o = (size_t)row * 64u + lane;
-    t_out[o] = (bid == kInvalid) ? -1.0f : best;
-    gid_out[o] = bid;
-    const unsigned long long hits = __ballot(bid != kInvalid);
-    if (lane == 0) row_counts[row] = (uint32_t)__popcll(hits);
     if (COUNT) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            cn += __shfl_xor(cn, off);
-            ctri += __shfl_xor(ctri, off);
-            trips = max(trips, (uint32_t)__shfl_xor(trips, off));
-        }
+        for (int off = 32; off >= 1; off >>= 1) { cn += __shfl_xor(cn, off); ctri += __shfl_xor(ctri, off); }
         if (lane == 0) {
             atomicAdd(&visit_counts[0], (unsigned long long)cn);
             atomicAdd(&visit_counts[1], (unsigned long long)ctri);
-            atomicAdd(&visit_counts[2], (unsigned long long)trips);  // loop trips of the wave = its slowest lane
+            atomicAdd(&visit_counts[2], (unsigned long long)trips);  // traversal-loop trips of this wave
             atomicMax(&visit_counts[3], (unsigned long long)trips);
         }
     }
 }
 
+// hits per row of 64 consecutive rays (feeds the ordered pack)
+__global__ __launch_bounds__(kBlock) void k_rowcount(const uint32_t *__restrict__ gid, uint32_t n,
+                                                     uint32_t *__restrict__ row_counts)
+{
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const bool hit = q < n && gid[q] != kInvalid;
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63u) == 0 && (q >> 6) < ((n + 63u) >> 6)) row_counts[q >> 6] = (uint32_t)__popcll(m);
+}
+
 // ------------------------------------------------------------------------------------------
-// Ordered pack: one thread per padded ray slot; block b owns rows [4b, 4b+4).  Its output offset
-// is the sum of the row counts before it (each block reduces its own prefix: no scan kernel, no
-// cross-block hand-off).  Emits the 32-byte PointCloud2 record and the 16-byte ls_hit, both in
-// ray-index order.  Bytes per hit: 8 (t,gid) + 48 written.
+// Ordered pack: one thread per ray q (shard-local index v*naz + column); block b owns rows
+// [4b, 4b+4) of 64 rays.  Its output offset is the sum of the row counts before it (each block
+// reduces its own prefix: no scan kernel, no cross-block hand-off).  Emits the 32-byte PointCloud2
+// record and the 16-byte ls_hit, both in ray-index order.  Bytes per hit: 8 (t,gid) + 48 written.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *__restrict__ t_in,
                                                  const uint32_t *__restrict__ gid_in,
@@ -454,7 +505,8 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *_
 {
     __shared__ uint32_t s_part[kBlock / 64];
     __shared__ uint32_t s_rows[4];
-    const uint32_t n_rows = tb.V * tb.n_az_blocks;
+    const uint32_t nq = tb.V * tb.naz;
+    const uint32_t n_rows = (nq + 63u) >> 6;
     const uint32_t row0 = blockIdx.x * 4u;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
 
@@ -474,19 +526,16 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *_
         *n_points = total;
     }
 
-    const uint32_t row = row0 + w;
-    if (row >= n_rows) return;
-    const size_t o = (size_t)row * 64u + lane;
-    const uint32_t gid = gid_in[o];
+    const uint32_t q = (row0 + w) * 64u + lane;
+    const uint32_t gid = q < nq ? gid_in[q] : kInvalid;
     const bool hit = gid != kInvalid;
     const unsigned long long m = __ballot(hit);
     if (!hit) return;
     const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     const uint32_t dst = base + rank;
 
-    const uint32_t v = row / tb.n_az_blocks, ab = row - v * tb.n_az_blocks;
-    const uint32_t h = tb.az0 + ab * 64u + lane;
-    const float t = t_in[o];
+    const uint32_t v = q / tb.naz, h = tb.az0 + (q - v * tb.naz);
+    const float t = t_in[q];
     const float st = tb.sin_theta[v];
     const float dx = st * tb.cos_phi[h], dy = st * tb.sin_phi[h], dz = tb.cos_theta[v];
     // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
@@ -614,47 +663,74 @@ void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in
 }
 
 void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,
-                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, Node *nodes)
+                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes)
 {
     if (!ntris) return;
     hipLaunchKernelGGL(k_leaves, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris,
-                       leaf_size, records, nodes);
+                       leaf_size, records, boxes);
 }
 
-void launch_range_tree(hipStream_t s, const Node *nodes, const RangeTree &rt, float4 *boxes)
+void launch_range_tree(hipStream_t s, const RangeTree &rt, float4 *boxes)
 {
     if (rt.levels <= 1) return;
-    hipLaunchKernelGGL(k_range_bottom, dim3((rt.count[0] + 511u) / 512u), dim3(kBlock), 0, s, nodes, rt, boxes);
+    hipLaunchKernelGGL(k_range_bottom, dim3((rt.count[0] + 511u) / 512u), dim3(kBlock), 0, s, rt, boxes);
     if (rt.levels > (uint32_t)kBottomLevels + 1u)
         hipLaunchKernelGGL(k_range_top, dim3(1), dim3(kBlock), 0, s, rt, boxes);
 }
 
 void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleaves, uint32_t leaf_size,
-                      const RangeTree &rt, const float4 *boxes, Node *nodes)
+                      const RangeTree &rt, const float4 *boxes, FatNode *nodes)
 {
-    if (!nleaves) return;
-    hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(nleaves)), dim3(kBlock), 0, s, sorted_keys, nleaves, leaf_size,
-                       rt, boxes, nodes);
+    if (nleaves < 2) return;
+    hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(nleaves - 1)), dim3(kBlock), 0, s, sorted_keys, nleaves,
+                       leaf_size, rt, boxes, nodes);
 }
 
-void launch_trace(hipStream_t s, const SensorTables &tb, const Node *nodes, const TriRecord *records,
-                  uint32_t nslots, uint32_t leaf_size, float *t_out, uint32_t *gid_out, uint32_t *row_counts,
-                  unsigned long long *visit_counts)
+uint32_t trace_grid_blocks(int device)
 {
-    const uint32_t n_tiles = tb.n_az_blocks * ((tb.V + 3u) >> 2);
-    if (!n_tiles) return;
+    // Persistent grid = resident capacity: 160 KB of LDS per CU / 32 KB of stack per block = 5 blocks
+    // (20 waves) per CU.  Over-subscription would be harmless (late blocks find the queues empty), so
+    // the figure is not taken from the occupancy API, which answers for a 64 KB LDS on this stack.
+    hipDeviceProp_t prop;
+    uint32_t cus = 256u;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = (uint32_t)prop.multiProcessorCount;
+    uint32_t per_cu = 5u;
+    if (const char *e = getenv("LS_TRACE_BLOCKS_PER_CU")) per_cu = (uint32_t)max(1, atoi(e));
+    return cus * per_cu;
+}
+
+size_t trace_spill_bytes(uint32_t grid_blocks) { return (size_t)grid_blocks * kBlock * kStackSpill * sizeof(uint32_t); }
+
+void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq,
+                  const FatNode *nodes, const TriRecord *records, uint32_t nleaves, uint32_t leaf_size,
+                  uint32_t ntris, float *t_out, uint32_t *gid_out, uint32_t *spill, unsigned long long *visit_counts)
+{
+    const uint32_t nq = tb.V * tb.naz;
+    if (!nq || !nleaves) return;
+    const uint32_t grid = min(grid_blocks, (nq + kBlock - 1) / kBlock);
+    static const int mode = getenv("LS_TRACE_LOAD_MODE") ? atoi(getenv("LS_TRACE_LOAD_MODE")) : 0;
     if (visit_counts)
-        hipLaunchKernelGGL(k_trace<true>, dim3(n_tiles), dim3(kBlock), 0, s, tb, nodes, records, nslots, leaf_size,
-                           t_out, gid_out, row_counts, visit_counts);
+        hipLaunchKernelGGL((k_trace<true, 0>), dim3(grid), dim3(kBlock), 0, s, tb, rq, nodes, records, nleaves, leaf_size,
+                           ntris, t_out, gid_out, spill, visit_counts);
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_trace<false, 1>), dim3(grid), dim3(kBlock), 0, s, tb, rq, nodes, records, nleaves,
+                           leaf_size, ntris, t_out, gid_out, spill, visit_counts);
     else
-        hipLaunchKernelGGL(k_trace<false>, dim3(n_tiles), dim3(kBlock), 0, s, tb, nodes, records, nslots,
-                           leaf_size, t_out, gid_out, row_counts, visit_counts);
+        hipLaunchKernelGGL((k_trace<false, 0>), dim3(grid), dim3(kBlock), 0, s, tb, rq, nodes, records, nleaves,
+                           leaf_size, ntris, t_out, gid_out, spill, visit_counts);
+}
+
+void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts)
+{
+    if (!nrays) return;
+    hipLaunchKernelGGL(k_rowcount, dim3(blocks_for(nrays)), dim3(kBlock), 0, s, gid, nrays, row_counts);
 }
 
 void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
                  const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
 {
-    const uint32_t n_rows = tb.V * tb.n_az_blocks;
+    const uint32_t n_rows = (tb.V * tb.naz + 63u) >> 6;
     if (!n_rows) return;
     hipLaunchKernelGGL(k_pack, dim3((n_rows + 3u) / 4u), dim3(kBlock), 0, s, tb, t, gid, row_counts, gt,
                        reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);

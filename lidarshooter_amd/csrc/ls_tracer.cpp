@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -70,8 +71,11 @@ struct ls_tracer {
     DevBuf<uint32_t> tris, keys_a, keys_b, vals_a, vals_b, geom_table;
     DevBuf<uint8_t> sort_temp;
     DevBuf<ls::TriRecord> records;
-    DevBuf<ls::Node> nodes;
+    DevBuf<ls::FatNode> nodes;
     DevBuf<float4> range_boxes;
+    DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
+    uint32_t *d_queue_heads = nullptr;
+    uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 24;
     ls::RangeTree rt{};
     uint32_t *d_maxabs = nullptr;
     unsigned long long *d_visits = nullptr;
@@ -154,20 +158,19 @@ ls::SensorTables tables(const ls_tracer *tr)
     tb.H = tr->H;
     tb.az0 = tr->az0;
     tb.naz = tr->naz;
-    tb.n_az_blocks = (tr->naz + 63u) / 64u;
     return tb;
 }
 
 uint32_t shard_rays(const ls_tracer *tr) { return tr->V * tr->naz; }
-uint32_t padded_rays(const ls_tracer *tr) { return tr->V * ((tr->naz + 63u) / 64u) * 64u; }
 
 int ensure_outputs(ls_tracer *tr)
 {
-    const size_t pr = padded_rays(tr), nr = shard_rays(tr);
+    const size_t nr = shard_rays(tr);
     int rc;
-    if ((rc = ensure(tr, tr->hit_t, pr))) return rc;
-    if ((rc = ensure(tr, tr->hit_gid, pr))) return rc;
-    if ((rc = ensure(tr, tr->row_counts, pr / 64 + 4))) return rc;
+    if ((rc = ensure(tr, tr->hit_t, nr))) return rc;
+    if ((rc = ensure(tr, tr->hit_gid, nr))) return rc;
+    if ((rc = ensure(tr, tr->row_counts, nr / 64 + 4))) return rc;
+    if ((rc = ensure(tr, tr->spill, ls::trace_spill_bytes(tr->trace_blocks) / 4))) return rc;
     if (!tr->ext_points) {
         if ((rc = ensure(tr, tr->points, nr * 32))) return rc;
         if ((rc = ensure(tr, tr->hits, nr * 16))) return rc;
@@ -347,7 +350,7 @@ int commit_locked(ls_tracer *tr)
     if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
     if ((rc = ensure(tr, tr->vals_b, nt))) return rc;
     if ((rc = ensure(tr, tr->records, (size_t)L * g))) return rc;
-    if ((rc = ensure(tr, tr->nodes, 2 * (size_t)L))) return rc;
+    if ((rc = ensure(tr, tr->nodes, (size_t)L))) return rc;
     if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
 
     if (relayout) {
@@ -362,8 +365,8 @@ int commit_locked(ls_tracer *tr)
         uint32_t cnt = L, off = 0, lev = 0;
         while (true) {
             rt.count[lev] = cnt;
-            rt.offset[lev] = lev ? off : 0;
-            if (lev) off += cnt;
+            rt.offset[lev] = off;
+            off += cnt;
             ++lev;
             if (cnt <= 1) break;
             cnt = (cnt + 1) / 2;
@@ -389,9 +392,9 @@ int commit_locked(ls_tracer *tr)
     mark(tr, 2);
     ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
     mark(tr, 3);
-    ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->nodes.p);
+    ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->range_boxes.p);
     mark(tr, 4);
-    ls::launch_range_tree(s, tr->nodes.p, tr->rt, tr->range_boxes.p);
+    ls::launch_range_tree(s, tr->rt, tr->range_boxes.p);
     mark(tr, 5);
     ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
     mark(tr, 6);
@@ -400,7 +403,7 @@ int commit_locked(ls_tracer *tr)
     tr->n_verts = nv;
     tr->n_tris = nt;
     tr->n_leaves = L;
-    tr->n_slots = 2 * L - 1;
+    tr->n_slots = L - 1;  // BVH2 nodes (64 B each)
     tr->committed_leaf_size = g;
     tr->slot_geom_ids = ids;
     tr->slot_tri_first = tfirst;
@@ -428,10 +431,16 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
     uint32_t *d_n = tr->ext_points ? tr->ext_n_points : tr->d_n_points;
     if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 32, s));
+    LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
+    ls::RayQueues rq;
+    rq.heads = tr->d_queue_heads;
+    rq.chan_mul = tr->chan_mul;
+    rq.refill_min = tr->refill_min;
     mark(tr, 7);
-    ls::launch_trace(s, tb, tr->nodes.p, tr->records.p, tr->n_slots, tr->committed_leaf_size, tr->hit_t.p,
-                     tr->hit_gid.p, tr->row_counts.p, tr->opt_count ? tr->d_visits : nullptr);
+    ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,
+                     tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
     mark(tr, 8);
+    ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p);
     ls::GeomTable gt;
     gt.n = (uint32_t)tr->slot_geom_ids.size();
     gt.tri_first = tr->geom_table.p;
@@ -510,6 +519,19 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_maxabs), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_queue_heads), ls::kQueues * 16 * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
+    tr->trace_blocks = ls::trace_grid_blocks(hip_device);
+    {
+        // channel visiting order (j * chan_mul) % V: a stride near 0.38 V that is coprime with V, so
+        // that cheap (sky) and expensive (grazing) channels alternate in every ray queue
+        auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+        uint32_t m = std::max<uint32_t>(1u, (uint32_t)(tr->V * 0.382f)) | 1u;
+        while (m > 1u && gcd(m, tr->V) != 1u) m += 2u;
+        tr->chan_mul = (tr->V > 1u) ? m % tr->V : 1u;
+        if (tr->chan_mul == 0u || gcd(tr->chan_mul, tr->V) != 1u) tr->chan_mul = 1u;
+        if (const char *e = getenv("LS_TRACE_CHAN_MUL")) { const uint32_t v = (uint32_t)atoi(e); if (v && gcd(v, tr->V) == 1u) tr->chan_mul = v; }
+        if (const char *e = getenv("LS_TRACE_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) tr->refill_min = (uint32_t)v; }
+    }
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16) != hipSuccess) return bail(LS_ERR_HIP);
     tr->slot_tri_first.assign(1, 0u);
     *out = tr;
@@ -530,6 +552,8 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->d_maxabs) (void)hipFree(tr->d_maxabs);
     if (tr->d_visits) (void)hipFree(tr->d_visits);
     if (tr->d_n_points) (void)hipFree(tr->d_n_points);
+    if (tr->d_queue_heads) (void)hipFree(tr->d_queue_heads);
+    release(tr->spill);
     if (tr->h_points) (void)hipHostFree(tr->h_points);
     if (tr->h_hits) (void)hipHostFree(tr->h_hits);
     if (tr->h_n_points) (void)hipHostFree(tr->h_n_points);
@@ -783,23 +807,14 @@ int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid)
 {
     LS_ENTER(tr);
     if (!t || !gid) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
-    const uint32_t nab = (tr->naz + 63u) / 64u;
+    const uint32_t n = shard_rays(tr);
     if (!tr->traced) {
-        for (uint32_t q = 0; q < shard_rays(tr); ++q) { t[q] = -1.0f; gid[q] = ls::kInvalid; }
+        for (uint32_t q = 0; q < n; ++q) { t[q] = -1.0f; gid[q] = ls::kInvalid; }
         return LS_OK;
     }
-    const size_t pr = padded_rays(tr);
-    std::vector<float> pt(pr);
-    std::vector<uint32_t> pg(pr);
     LS_HIP(hipStreamSynchronize(tr->stream));
-    LS_HIP(hipMemcpy(pt.data(), tr->hit_t.p, pr * 4, hipMemcpyDeviceToHost));
-    LS_HIP(hipMemcpy(pg.data(), tr->hit_gid.p, pr * 4, hipMemcpyDeviceToHost));
-    for (uint32_t v = 0; v < tr->V; ++v)
-        for (uint32_t hl = 0; hl < tr->naz; ++hl) {
-            const size_t o = ((size_t)v * nab + hl / 64u) * 64u + (hl & 63u);
-            t[(size_t)v * tr->naz + hl] = pt[o];
-            gid[(size_t)v * tr->naz + hl] = pg[o];
-        }
+    LS_HIP(hipMemcpy(t, tr->hit_t.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    LS_HIP(hipMemcpy(gid, tr->hit_gid.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return LS_OK;
 }
 
@@ -849,7 +864,7 @@ int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records)
     LS_ENTER(tr);
     if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
     LS_HIP(hipStreamSynchronize(tr->stream));
-    if (nodes) LS_HIP(hipMemcpy(nodes, tr->nodes.p, (size_t)tr->n_slots * sizeof(ls::Node), hipMemcpyDeviceToHost));
+    if (nodes) LS_HIP(hipMemcpy(nodes, tr->nodes.p, (size_t)tr->n_slots * sizeof(ls::FatNode), hipMemcpyDeviceToHost));
     if (tri_records) LS_HIP(hipMemcpy(tri_records, tr->records.p, (size_t)tr->n_tris * sizeof(ls::TriRecord), hipMemcpyDeviceToHost));
     return LS_OK;
 }

@@ -309,8 +309,8 @@ void lso_trace_bruteforce(const float *dirs, uint32_t nrays, const float *verts,
 /* ------------------------------------------------------------------------------------------
  * CPU BVH tracer used (a) as the cpu_baseline of bench.py and (b) to check full-size GPU
  * results.  Binned-SAH BVH2, leaves <= 4 triangles, single-ray stack traversal, near child
- * first.  The box test is conservative (tmax padded by 2 ulp-ish, Ize 2013) and culls with
- * `tnear_box <= t_best`, so the result equals lso_trace_bruteforce bit for bit (same tri_test,
+ * first.  Triangle boxes are padded by 2^-16 of the largest |coordinate| and the box test culls
+ * with `tnear_box <= t_best`, so the result equals lso_trace_bruteforce bit for bit (same tri_test,
  * same tie-break); tests/test_oracle.py checks that.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -486,7 +486,7 @@ static inline int box_hit(const float *lo, const float *hi, const float *inv, fl
     for (int a = 0; a < 3; ++a) {
         const float t1 = lo[a] * inv[a], t2 = hi[a] * inv[a]; /* inv is finite: no NaN */
         const float mn = fminf(t1, t2);
-        const float mx = fmaxf(t1, t2) * 1.0000004f; /* 1 + 3 ulp: robust traversal (Ize 2013) */
+        const float mx = fmaxf(t1, t2);
         tn = fmaxf(tn, mn);
         tf = fminf(tf, mx);
     }
@@ -610,25 +610,41 @@ uint32_t lso_pack_points(const float *t, const uint32_t *gid, const float *dirs,
 
 /* ------------------------------------------------------------------------------------------
  * Walk a BVH that the HIP library built (downloaded with ls_debug_download_bvh; layout in
- * include/lidarshooter_hip.h) in exactly the kernel's stackless order, to (a) check that the
- * device traversal of that BVH is what the CPU gets from the same arrays and (b) count the
- * node fetches and triangle tests per ray that bench.py's algorithmic-bytes figure uses.
- *   node slot s (32 B): float lo[3]; uint32 left; float hi[3]; uint32 skip
- *       even s = leaf s/2 (left = number of triangle records, first record = (s/2)*leaf_size)
- *       odd  s = internal node (left = slot of first child); skip = next slot in DFS order
- *       0xFFFFFFFF ends the walk; root slot = (nslots > 1) ? 1 : 0
+ * include/lidarshooter_hip.h) with exactly the kernel's per-ray order -- left child first, pending
+ * right children on a stack -- to (a) check that the device traversal of that BVH is what the CPU
+ * gets from the same arrays and (b) count the node fetches and triangle tests per ray that
+ * bench.py's algorithmic-bytes figure uses.
+ *   node i (64 B): float L.lo[3]; uint32 left; float L.hi[3]; uint32 right; float R.lo[3]; uint32 0;
+ *                  float R.hi[3]; uint32 0.   child ref: bit 31 = leaf k, else node index.
  *   triangle record (48 B): float v0[3]; uint32 gid; float e1[3]; float NgC; float e2[3]; uint32 pad
  * ------------------------------------------------------------------------------------------ */
-typedef struct { float lo[3]; uint32_t left; float hi[3]; uint32_t skip; } dev_node;
+typedef struct {
+    float llo[3]; uint32_t left; float lhi[3]; uint32_t right;
+    float rlo[3]; uint32_t pad0; float rhi[3]; uint32_t pad1;
+} dev_node;
 typedef struct { float v0[3]; uint32_t gid; float e1[3]; float NgC; float e2[3]; uint32_t pad; } dev_tri;
 
-void lso_inorder_traverse_stats(const void *nodes_, const void *tris_, uint32_t nslots, uint32_t leaf_size,
-                                const float *dirs, uint32_t nrays, float *t_out, uint32_t *gid_out,
-                                uint64_t *stats)
+#define DEV_LEAF 0x80000000u
+
+static inline int dev_box_hit(const float *lo, const float *hi, const float *inv, float tbest)
+{
+    float tn = 0.0f, tf = tbest;
+    for (int a = 0; a < 3; ++a) {
+        const float t1 = lo[a] * inv[a], t2 = hi[a] * inv[a];
+        tn = fmaxf(tn, fminf(t1, t2));
+        tf = fminf(tf, fmaxf(t1, t2));
+    }
+    return tn <= tf;
+}
+
+void lso_fat_traverse_stats(const void *nodes_, const void *tris_, uint32_t nleaves, uint32_t leaf_size,
+                            uint32_t ntris, const float *dirs, uint32_t nrays, float *t_out, uint32_t *gid_out,
+                            uint64_t *stats, uint32_t *per_ray_nodes /* optional */)
 {
     const dev_node *nodes = (const dev_node *)nodes_;
     const dev_tri *tris = (const dev_tri *)tris_;
     uint64_t nn = 0, nt = 0;
+    uint32_t maxsp = 0;
     for (uint32_t r = 0; r < nrays; ++r) {
         const float *dir = dirs + 3 * (size_t)r;
         float inv[3];
@@ -637,40 +653,56 @@ void lso_inorder_traverse_stats(const void *nodes_, const void *tris_, uint32_t 
         const v3 d = {dir[0], dir[1], dir[2]};
         float best = INFINITY;
         uint32_t bid = LSO_INVALID;
-        uint32_t n = nslots ? (nslots > 1 ? 1u : 0u) : LSO_INVALID;
-        while (n != LSO_INVALID) {
-            const dev_node *nd = &nodes[n];
-            float t0;
-            ++nn;
-            if (!box_hit(nd->lo, nd->hi, inv, best, &t0)) { n = nd->skip; continue; }
-            if (n & 1u) { n = nd->left; continue; }
-            const uint32_t first = (n >> 1) * leaf_size;
-            for (uint32_t s = first; s < first + nd->left; ++s) {
-                const dev_tri *tr = &tris[s];
-                const v3 v0 = {tr->v0[0], tr->v0[1], tr->v0[2]};
-                const v3 e1 = {tr->e1[0], tr->e1[1], tr->e1[2]};
-                const v3 e2 = {tr->e2[0], tr->e2[1], tr->e2[2]};
-                ++nt;
-                /* tri_test() with org = 0 and e1, e2, dot(Ng,C) taken from the record */
-                const v3 Ng = v3_cross(e2, e1);
-                const v3 R = v3_cross(v0, d);
-                const float den = v3_dot(Ng, d);
-                const float absDen = fabsf(den);
-                uint32_t sgn;
-                memcpy(&sgn, &den, 4);
-                sgn &= 0x80000000u;
-                const float U = xor_sign(v3_dot(R, e2), sgn);
-                const float V = xor_sign(v3_dot(R, e1), sgn);
-                const float T = xor_sign(tr->NgC, sgn);
-                if (den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absDen && 0.0f < T) {
-                    const float t = T / absDen;
-                    if (t < best || (t == best && tr->gid < bid)) { best = t; bid = tr->gid; }
+        uint32_t stack[128];
+        uint32_t sp = 0;
+        uint32_t cur = nleaves ? (nleaves > 1 ? 0u : DEV_LEAF) : LSO_INVALID;
+        const uint64_t nn0 = nn;
+        while (cur != LSO_INVALID) {
+            if (!(cur & DEV_LEAF)) {
+                const dev_node *nd = &nodes[cur];
+                ++nn;
+                const int hl = dev_box_hit(nd->llo, nd->lhi, inv, best);
+                const int hr = dev_box_hit(nd->rlo, nd->rhi, inv, best);
+                if (hl) {
+                    cur = nd->left;
+                    if (hr) { stack[sp++] = nd->right; if (sp > maxsp) maxsp = sp; }
+                } else if (hr) {
+                    cur = nd->right;
+                } else {
+                    cur = sp ? stack[--sp] : LSO_INVALID;
                 }
             }
-            n = nd->skip;
+            while (cur != LSO_INVALID && (cur & DEV_LEAF)) {
+                const uint32_t first = (cur & ~DEV_LEAF) * leaf_size;
+                const uint32_t last = first + leaf_size < ntris ? first + leaf_size : ntris;
+                for (uint32_t s = first; s < last; ++s) {
+                    const dev_tri *tr = &tris[s];
+                    const v3 v0 = {tr->v0[0], tr->v0[1], tr->v0[2]};
+                    const v3 e1 = {tr->e1[0], tr->e1[1], tr->e1[2]};
+                    const v3 e2 = {tr->e2[0], tr->e2[1], tr->e2[2]};
+                    ++nt;
+                    /* tri_test() with org = 0 and e1, e2, dot(Ng,C) taken from the record */
+                    const v3 Ng = v3_cross(e2, e1);
+                    const v3 R = v3_cross(v0, d);
+                    const float den = v3_dot(Ng, d);
+                    const float absDen = fabsf(den);
+                    uint32_t sgn;
+                    memcpy(&sgn, &den, 4);
+                    sgn &= 0x80000000u;
+                    const float U = xor_sign(v3_dot(R, e2), sgn);
+                    const float V = xor_sign(v3_dot(R, e1), sgn);
+                    const float T = xor_sign(tr->NgC, sgn);
+                    if (den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absDen && 0.0f < T) {
+                        const float t = T / absDen;
+                        if (t < best || (t == best && tr->gid < bid)) { best = t; bid = tr->gid; }
+                    }
+                }
+                cur = sp ? stack[--sp] : LSO_INVALID;
+            }
         }
         t_out[r] = (bid == LSO_INVALID) ? -1.0f : best;
         gid_out[r] = bid;
+        if (per_ray_nodes) per_ray_nodes[r] = (uint32_t)(nn - nn0);
     }
-    if (stats) { stats[0] = nn; stats[1] = nt; }
+    if (stats) { stats[0] = nn; stats[1] = nt; stats[2] = maxsp; }
 }

@@ -64,8 +64,8 @@ def lib() -> C.CDLL:
         L.lso_bvh_trace.argtypes = [C.c_void_p, f32p, C.c_uint32, f32p, u32p, C.c_int, u64p]
         L.lso_pack_points.argtypes = [f32p, u32p, f32p, C.c_uint32, C.c_uint32, u32p, u32p, C.c_uint32, u8p, u32p]
         L.lso_pack_points.restype = C.c_uint32
-        L.lso_inorder_traverse_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, f32p, C.c_uint32,
-                                                 f32p, u32p, u64p]
+        L.lso_fat_traverse_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, f32p,
+                                             C.c_uint32, f32p, u32p, u64p, u32p]
         _lib = L
     return _lib
 
@@ -344,20 +344,22 @@ def pack_points(t, gid, dirs, H, scene: Scene):
     return pts[:k].copy(), hits[:k].copy()
 
 
-def inorder_traverse_stats(nodes: np.ndarray, tris: np.ndarray, leaf_size: int, dirs: np.ndarray):
+def fat_traverse_stats(nodes: np.ndarray, tris: np.ndarray, leaf_size: int, dirs: np.ndarray, per_ray=None):
     """Walk a BVH downloaded from the HIP library (ls_debug_download_bvh layout, see
-    include/lidarshooter_hip.h) with the same stackless order as the kernel and count
-    node fetches / triangle tests per ray.  -> (t, gid, stats[2])."""
+    include/lidarshooter_hip.h) with the kernel's per-ray order and count node fetches / triangle
+    tests.  -> (t, gid, stats[3] = node fetches, triangle tests, deepest stack)."""
     n = dirs.shape[0]
     t = np.full(n, -1.0, np.float32)
     gid = np.full(n, INVALID, np.uint32)
-    stats = np.zeros(2, np.uint64)
+    stats = np.zeros(3, np.uint64)
     dirs = np.ascontiguousarray(dirs, np.float32)
     nodes = np.ascontiguousarray(nodes)
     tris = np.ascontiguousarray(tris)
-    lib().lso_inorder_traverse_stats(nodes.ctypes.data, tris.ctypes.data, nodes.nbytes // 32, leaf_size,
-                                     _p(dirs, C.c_float), n, _p(t, C.c_float), _p(gid, C.c_uint32),
-                                     _p(stats, C.c_uint64))
+    ntris = tris.nbytes // 48
+    nleaves = (ntris + leaf_size - 1) // leaf_size
+    lib().lso_fat_traverse_stats(nodes.ctypes.data, tris.ctypes.data, nleaves, leaf_size, ntris,
+                                 _p(dirs, C.c_float), n, _p(t, C.c_float), _p(gid, C.c_uint32),
+                                 _p(stats, C.c_uint64), _p(per_ray, C.c_uint32) if per_ray is not None else None)
     return t, gid, stats
 
 

@@ -28,7 +28,7 @@ def test_abi_version(capi):
 
 def test_struct_sizes(capi):
     assert capi.HIT_DTYPE.itemsize == 16
-    assert capi.NODE_DTYPE.itemsize == 32
+    assert capi.NODE_DTYPE.itemsize == 64
     assert capi.TRI_DTYPE.itemsize == 48
 
 

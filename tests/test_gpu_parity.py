@@ -202,7 +202,7 @@ def test_leaf_sizes(oracle, capi, sensors, meshes, leaf):
     tr.traceScene(1)
     nodes, tri, g = tr.downloadBvh()
     assert g == leaf
-    t2, gid2, stats = oracle.inorder_traverse_stats(nodes, tri, g, oracle.ray_dirs(s))
+    t2, gid2, stats = oracle.fat_traverse_stats(nodes, tri, g, oracle.ray_dirs(s))
     t, gid = tr.denseHits()
     assert np.array_equal(gid2, gid) and np.array_equal(t2, t)
     assert tr.visitCounts() == (int(stats[0]), int(stats[1]))
@@ -210,8 +210,8 @@ def test_leaf_sizes(oracle, capi, sensors, meshes, leaf):
 
 
 def test_bvh_structure(oracle, capi, sensors, meshes):
-    """Every node's box contains its children's; leaves partition the triangles; skip links walk
-    the whole tree in depth-first order."""
+    """Every node's child boxes contain the grandchildren's; the leaves partition the triangles;
+    a left-first depth-first walk meets the leaves in Morton order."""
     tr = make_tracer(capi, sensors["0000"])
     tr.setOption(capi.LS_OPT_LEAF_SIZE, 2)
     _add(tr, "face", meshes["ben"])
@@ -220,23 +220,30 @@ def test_bvh_structure(oracle, capi, sensors, meshes):
     nodes, tri, g = tr.downloadBvh()
     nt = tri.shape[0]
     L = (nt + g - 1) // g
-    assert nodes.shape[0] == 2 * L - 1
+    assert nodes.shape[0] == L - 1
     assert sorted(tri["gid"].tolist()) == list(range(nt))
-    # walk: always descend
-    n, seen_leaves, steps = 1, [], 0
-    while n != 0xFFFFFFFF:
-        steps += 1
-        nd = nodes[n]
-        if n & 1:
-            c = nodes[nd["left"]]
-            assert np.all(c["lo"] >= nd["lo"]) and np.all(c["hi"] <= nd["hi"])
-            n = int(nd["left"])
-        else:
-            seen_leaves.append(n >> 1)
-            lo = tri["v0"][(n >> 1) * g:(n >> 1) * g + nd["left"]]
-            assert np.all(lo >= nd["lo"] - 1e-3) and np.all(lo <= nd["hi"] + 1e-3)
-            n = int(nd["skip"])
-    assert steps == 2 * L - 1
+    LEAF = capi.LEAF_BIT
+    seen_leaves, visited, stack = [], 0, [0]
+    while stack:
+        ref = stack.pop()
+        if ref & LEAF:
+            k = ref & ~LEAF
+            seen_leaves.append(k)
+            continue
+        visited += 1
+        nd = nodes[ref]
+        for side, child in (("l", int(nd["left"])), ("r", int(nd["right"]))):
+            lo, hi = nd[side + "lo"], nd[side + "hi"]
+            if child & LEAF:
+                k = child & ~LEAF
+                v = tri["v0"][k * g:min(k * g + g, nt)]
+                assert np.all(v >= lo) and np.all(v <= hi)
+            else:
+                c = nodes[child]
+                assert np.all(np.minimum(c["llo"], c["rlo"]) >= lo) and np.all(np.maximum(c["lhi"], c["rhi"]) <= hi)
+        stack.append(int(nd["right"]))
+        stack.append(int(nd["left"]))
+    assert visited == L - 1
     assert seen_leaves == list(range(L))                  # left-to-right = Morton order
     tr.close()
 
