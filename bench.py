@@ -33,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 from lidarshooter_amd import capi, hostapi, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NODE_BYTES, TRI_BYTES, RAY_OUT_BYTES = 32, 48, 8  # DESIGN.md "algorithmic bytes"
+NODE_BYTES, TRI_BYTES, RAY_OUT_BYTES = 64, 48, 8  # DESIGN.md "algorithmic bytes" (BVH engine)
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 
 
@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "xt32"])
     ap.add_argument("--leaf", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
+    ap.add_argument("--engine", default="auto", choices=["auto", "bvh", "projection"],
+                    help="closest-hit engine (auto = the library default: sensor-space projection)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--breakdown", action="store_true", help="extra pass with per-stage hipEvent timings")
@@ -123,6 +125,8 @@ def main():
                      device=local_rank)
     if args.leaf:
         tr.setOption(capi.LS_OPT_LEAF_SIZE, args.leaf)
+    tr.setOption(capi.LS_OPT_ENGINE, {"auto": 0, "bvh": 1, "projection": 2}[args.engine])
+    engine = "bvh" if args.engine == "bvh" else "projection"
     tr.setShard(first_az, n_az)
     # a dedicated (non-default) stream shared by the tracer's kernels and, through torch, by RCCL's
     # stream dependencies: the all-gather of frame i is ordered after frame i's pack kernel
@@ -168,6 +172,7 @@ def main():
     shard_rays = tr.getTotalRays()
     n_hits = int(slot[:4].view(torch.int32).item())
     info = tr.sceneSize()
+    n_tris_total = info["n_tris"]
 
     for i in range(args.warmup):
         frame(i)
@@ -206,30 +211,42 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays * args.steps / elapsed / 1e6
     trace_ms = tm["trace"]
-    b_ray = RAY_OUT_BYTES + (NODE_BYTES * n_node + TRI_BYTES * n_tri) / shard_rays
-    achieved = (b_ray * shard_rays) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+    if engine == "bvh":
+        # k_trace: 64 B per node fetch + 48 B per triangle test + 8 B per ray written
+        kernel = "k_trace"
+        b_launch = RAY_OUT_BYTES * shard_rays + NODE_BYTES * n_node + TRI_BYTES * n_tri
+        units = {"rays_per_launch": shard_rays, "bytes_per_ray": b_launch / shard_rays,
+                 "nodes_per_ray": n_node / shard_rays, "tris_per_ray": n_tri / shard_rays,
+                 "wave_trips_mean": wave_trips / max(1, (shard_rays + 63) // 64), "wave_trips_max": max_trips}
+    else:
+        # k_project_tris: every triangle is streamed once (12 B indices + 36 B vertex gather) and every
+        # hit folds 8 B into the per-ray key; the angle tables (V+H entries) stay in L1
+        kernel = "k_project_tris"
+        b_launch = 48 * n_tris_total + 8 * n_hits
+        units = {"triangles_per_launch": n_tris_total, "bytes_per_triangle": b_launch / max(1, n_tris_total),
+                 "candidate_tests_per_launch": n_tri, "tests_per_triangle": n_tri / max(1, n_tris_total),
+                 "rays_per_launch": shard_rays}
+    achieved = b_launch / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
 
     out = {
-        "metric": "Mrays/s (full LiDAR frame: update + BVH rebuild + trace + pack; 128ch x 4096az over 1M tris)"
+        "metric": "Mrays/s (full LiDAR frame: update + commit + trace + pack; 128ch x 4096az over 1M tris)"
                   if args.workload == "syn128x1m" else "Mrays/s (XT-32 over ground+ben)",
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)"
                    if args.workload == "syn128x1m" else "XT-32 lidar_0000 x ground.stl+ben.stl",
-                   "rays_per_frame": total_rays, "triangles": info["n_tris"], "leaf_size": info["leaf_size"],
-                   "bvh_node_slots": info["n_slots"], "frame": "updateGeometry(device) + commitScene(full rebuild) + traceScene",
-                   "parallelism": f"azimuth-sector shards x{world}, BVH replica per GPU, all-gather of hit slots"
+                   "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,
+                   "frame": "updateGeometry(device) + commitScene + traceScene"
+                            + (" (full BVH rebuild every frame)" if engine == "bvh" else ""),
+                   "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, all-gather of hit slots"
                    if world > 1 else "single GPU"},
         "frames_per_s": args.steps / elapsed,
         "hits_per_frame_rank0": n_hits,
-        "roofline": {
-            "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": dict({
+            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel_ms": trace_ms, "frames_timed": tm["frames"], "rays_per_launch": shard_rays,
-            "bytes_per_ray": b_ray, "nodes_per_ray": n_node / shard_rays, "tris_per_ray": n_tri / shard_rays,
-            "wave_trips_mean": wave_trips / max(1, (shard_rays + 63) // 64), "wave_trips_max": max_trips,
-        },
+            "kernel_ms": trace_ms, "frames_timed": tm["frames"], "algorithmic_bytes_per_launch": b_launch}, **units),
     }
     if breakdown is not None:
         out["stage_ms"] = {k: round(v, 5) for k, v in breakdown.items() if k != "frames"}

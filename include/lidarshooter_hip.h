@@ -168,6 +168,9 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_COUNT_VISITS 3   /* 1: trace kernel also counts node fetches / triangle tests              */
 #define LS_OPT_REFIT 4          /* 1: commit refits the BVH when the geometry set is unchanged
                                  *    (OptixTracer.cpp:532-535 OPERATION_UPDATE); 0 (default): full rebuild */
+#define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
+                                 *    projection (streams triangles over the ray raster); identical results.
+                                 *    Takes effect at the next commit.                                      */
 int ls_tracer_set_option(ls_tracer *tr, int option, int value);
 
 /* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded
@@ -179,9 +182,10 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value);
 #define LS_T_LEAVES 3
 #define LS_T_RANGE_TREE 4
 #define LS_T_HIERARCHY 5
-#define LS_T_TRACE 6
-#define LS_T_PACK 7
-#define LS_T_COUNT 8
+#define LS_T_TRACE 6      /* BVH: traversal kernel; projection: per-triangle footprint kernel */
+#define LS_T_TRACE_AUX 7  /* BVH: row counts; projection: long-row kernel + resolve          */
+#define LS_T_PACK 8
+#define LS_T_COUNT 9
 int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT]);
 
 /* Totals of the last trace when LS_OPT_COUNT_VISITS is on: {node fetches, triangle tests,

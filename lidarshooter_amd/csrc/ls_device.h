@@ -1,0 +1,52 @@
+// ls_device.h -- device-side helpers shared by the kernel files: the float operation sequences
+// that must stay identical to oracle/ls_oracle.c (cross / dot with explicit fused multiply-adds,
+// the Embree 3.13.4 Moeller-Trumbore test).  Compiled with -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ls {
+namespace {
+
+constexpr int kBlock = 256;
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+// Embree common/math/vec3.h: cross = (msub(a.y,b.z,a.z*b.y), msub(a.z,b.x,a.x*b.z), msub(a.x,b.y,a.y*b.x))
+__device__ __forceinline__ V3 cross_fma(V3 a, V3 b)
+{
+    return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+}
+// dot = madd(a.x,b.x,madd(a.y,b.y,a.z*b.z))
+__device__ __forceinline__ float dot_fma(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ float xor_sign(float f, uint32_t s) { return __uint_as_float(__float_as_uint(f) ^ s); }
+
+__device__ __forceinline__ float safe_inv(float d)
+{
+    // |d| < 1e-30 -> +-1e-30 keeps 1/d finite (azimuth 0 has dir.y == 0 exactly)
+    return 1.0f / (fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d);
+}
+
+// Embree 3.13.4 Moeller-Trumbore test (triangle_intersector_moeller.h) for a ray from the origin,
+// against a record holding v0, e1 = v0-v1, e2 = v2-v0 and NgC = dot(cross(e2,e1), v0).
+// tnear = 0 (strict), no upper bound here: the caller keeps the closest.
+__device__ __forceinline__ bool tri_test(V3 d, V3 v0, V3 e1, V3 e2, float NgC, float &t)
+{
+    const V3 Ng = cross_fma(e2, e1);
+    const V3 R = cross_fma(v0, d);
+    const float den = dot_fma(Ng, d);
+    const float absDen = fabsf(den);
+    const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+    const float U = xor_sign(dot_fma(R, e2), sgn);
+    const float V = xor_sign(dot_fma(R, e1), sgn);
+    const float T = xor_sign(NgC, sgn);
+    const bool ok = (den != 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= absDen) & (0.0f < T);
+    if (ok) t = T / absDen;
+    return ok;
+}
+
+
+}  // namespace
+}  // namespace ls

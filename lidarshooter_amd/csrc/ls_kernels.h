@@ -67,6 +67,14 @@ struct RayQueues {
     uint32_t refill_min;           // idle lanes of a wave that trigger a refill
 };
 
+// Sensor-space projection engine (ls_project.hip)
+struct ProjectParams {
+    SensorTables tb;
+    const float *chan_sorted;      // [V] channel elevations (degrees above the horizon), ascending
+    const uint32_t *chan_perm;     // [V] position in chan_sorted -> channel index
+    float begin_deg, step_deg;     // azimuth of column h = begin + step*h (LidarDevice.cpp:306)
+};
+
 // ---- build ---------------------------------------------------------------------------------
 void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t n, const float *affine12,
                       const float *rinv9, const float *t3, float *out_xyz, uint32_t *d_maxabs_bits);
@@ -93,6 +101,16 @@ void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_
 void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
                  const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits,
                  uint32_t *n_points);
+// projection engine: init + per-triangle footprint kernel, long-row kernel, resolve (+ row counts)
+void launch_project_tris(hipStream_t s, const ProjectParams &pp, const float *verts, const uint32_t *tris,
+                         uint32_t ntris, unsigned long long *best, uint4 *rows, uint32_t row_capacity,
+                         uint32_t *row_count, unsigned long long *stats);
+void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *row_count);
+void launch_project_rows(hipStream_t s, const ProjectParams &pp, const float *verts, const uint32_t *tris,
+                         uint32_t ntris, unsigned long long *best, const uint4 *rows, uint32_t row_capacity,
+                         const uint32_t *row_count, uint32_t grid_blocks, unsigned long long *stats);
+void launch_project_resolve(hipStream_t s, const ProjectParams &pp, const unsigned long long *best, float *t_out,
+                            uint32_t *gid_out, uint32_t *row_counts);
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz);
 void launch_bruteforce(hipStream_t s, const SensorTables &tb, const float *verts, const uint32_t *tris,
                        uint32_t ntris, float *t_out, uint32_t *gid_out);

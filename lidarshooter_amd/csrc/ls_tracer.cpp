@@ -73,10 +73,17 @@ struct ls_tracer {
     DevBuf<ls::TriRecord> records;
     DevBuf<ls::FatNode> nodes;
     DevBuf<float4> range_boxes;
+    DevBuf<unsigned long long> best_keys;  // projection engine: per-ray (t bits, gid) closest-hit key
+    DevBuf<uint4> proj_rows;               // projection engine: queue of long cell rows
+    uint32_t *d_proj_row_count = nullptr;
+    bool projection_ok = true;             // all channel elevations within [-90, 90] degrees
+    int engine = 0;                        // LS_OPT_ENGINE: 0 auto, 1 BVH, 2 projection
+    bool bvh_built = false;
     DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
     uint32_t *d_queue_heads = nullptr;
     uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 24;
     ls::RangeTree rt{};
+    uint32_t range_entries = 0;
     uint32_t *d_maxabs = nullptr;
     unsigned long long *d_visits = nullptr;
 
@@ -147,6 +154,10 @@ void release(DevBuf<T> &b)
     b.cap = 0;
 }
 
+bool use_projection(const ls_tracer *tr) { return tr->engine == 2 || (tr->engine == 0 && tr->projection_ok); }
+
+ls::ProjectParams project_params(const ls_tracer *tr);
+
 ls::SensorTables tables(const ls_tracer *tr)
 {
     ls::SensorTables tb;
@@ -161,6 +172,17 @@ ls::SensorTables tables(const ls_tracer *tr)
     return tb;
 }
 
+ls::ProjectParams project_params(const ls_tracer *tr)
+{
+    ls::ProjectParams pp;
+    pp.tb = tables(tr);
+    pp.chan_sorted = tr->d_tables + 2 * (size_t)tr->V + 2 * (size_t)tr->H;
+    pp.chan_perm = reinterpret_cast<const uint32_t *>(pp.chan_sorted + tr->V);
+    pp.begin_deg = tr->h_begin;
+    pp.step_deg = (tr->h_end - tr->h_begin) / static_cast<float>(tr->H - 1u);  // LidarDevice.cpp:611
+    return pp;
+}
+
 uint32_t shard_rays(const ls_tracer *tr) { return tr->V * tr->naz; }
 
 int ensure_outputs(ls_tracer *tr)
@@ -170,7 +192,12 @@ int ensure_outputs(ls_tracer *tr)
     if ((rc = ensure(tr, tr->hit_t, nr))) return rc;
     if ((rc = ensure(tr, tr->hit_gid, nr))) return rc;
     if ((rc = ensure(tr, tr->row_counts, nr / 64 + 4))) return rc;
-    if ((rc = ensure(tr, tr->spill, ls::trace_spill_bytes(tr->trace_blocks) / 4))) return rc;
+    if (use_projection(tr)) {
+        if ((rc = ensure(tr, tr->best_keys, nr))) return rc;
+        if ((rc = ensure(tr, tr->proj_rows, (size_t)1 << 20))) return rc;
+    } else {
+        if ((rc = ensure(tr, tr->spill, ls::trace_spill_bytes(tr->trace_blocks) / 4))) return rc;
+    }
     if (!tr->ext_points) {
         if ((rc = ensure(tr, tr->points, nr * 32))) return rc;
         if ((rc = ensure(tr, tr->hits, nr * 16))) return rc;
@@ -182,6 +209,7 @@ constexpr size_t kMaxTimingRecords = 4096;
 
 // Marks 0..6 bracket the six commit stages, 7..9 bracket trace and pack.  A commit opens a new
 // record; a trace without a preceding commit opens its own.
+// marks: 0..6 bracket the six commit stages; 7..10 bracket trace, trace_aux and pack
 void mark(ls_tracer *tr, int i)
 {
     if (!tr->opt_timing) return;
@@ -202,7 +230,7 @@ void mark(ls_tracer *tr, int i)
     ls_tracer::TimingRecord &r = tr->trec[tr->trec_used - 1];
     if (!r.ev[i] && hipEventCreate(&r.ev[i]) != hipSuccess) return;
     r.set[i] = hipEventRecord(r.ev[i], tr->stream) == hipSuccess;
-    if (i == 9 || (tr->opt_timing == 2 && i == 8)) tr->trec_open = false;
+    if (i == 10 || (tr->opt_timing == 2 && i == 8)) tr->trec_open = false;
 }
 
 // LidarDevice.cpp:306-316 on the host: the V+H distinct angles of a revolution go through libm
@@ -210,7 +238,7 @@ void mark(ls_tracer *tr, int i)
 void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
 {
     const uint32_t V = tr->V, H = tr->H;
-    tab.resize(2 * (size_t)V + 2 * (size_t)H);
+    tab.resize(2 * (size_t)V + 2 * (size_t)H + 2 * (size_t)V);
     const float step = (tr->h_end - tr->h_begin) / static_cast<float>(H - 1u);  // LidarDevice.cpp:611
     for (uint32_t v = 0; v < V; ++v) {
         const float preChi = tr->vertical[v];
@@ -223,6 +251,15 @@ void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
         const float phi = static_cast<float>(static_cast<double>(prePhi) * M_PI / 180.0);
         tab[2 * (size_t)V + h] = std::sin(phi);
         tab[2 * (size_t)V + H + h] = std::cos(phi);
+    }
+    // projection engine: channel elevations (degrees above the horizon) ascending + permutation
+    std::vector<uint32_t> perm(V);
+    for (uint32_t v = 0; v < V; ++v) perm[v] = v;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return tr->vertical[a] < tr->vertical[b]; });
+    float *sorted = tab.data() + 2 * (size_t)V + 2 * (size_t)H;
+    for (uint32_t i = 0; i < V; ++i) {
+        sorted[i] = tr->vertical[perm[i]];
+        std::memcpy(&sorted[V + i], &perm[i], 4);
     }
 }
 
@@ -345,13 +382,16 @@ int commit_locked(ls_tracer *tr)
     int rc;
     if ((rc = ensure(tr, tr->verts, (size_t)nv * 3))) return rc;
     if ((rc = ensure(tr, tr->tris, (size_t)nt * 3))) return rc;
-    if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
-    if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
-    if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
-    if ((rc = ensure(tr, tr->vals_b, nt))) return rc;
-    if ((rc = ensure(tr, tr->records, (size_t)L * g))) return rc;
-    if ((rc = ensure(tr, tr->nodes, (size_t)L))) return rc;
-    if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
+    const bool want_bvh = !use_projection(tr);
+    if (want_bvh) {
+        if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
+        if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
+        if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
+        if ((rc = ensure(tr, tr->vals_b, nt))) return rc;
+        if ((rc = ensure(tr, tr->records, (size_t)L * g))) return rc;
+        if ((rc = ensure(tr, tr->nodes, (size_t)L))) return rc;
+        if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
+    }
 
     if (relayout) {
         std::vector<uint32_t> table(tfirst);
@@ -372,8 +412,9 @@ int commit_locked(ls_tracer *tr)
             cnt = (cnt + 1) / 2;
         }
         rt.levels = lev;
-        if ((rc = ensure(tr, tr->range_boxes, 2 * (size_t)off + 2))) return rc;
+        tr->range_entries = off;
     }
+    if (want_bvh && (rc = ensure(tr, tr->range_boxes, 2 * (size_t)tr->range_entries + 2))) return rc;
 
     hipStream_t s = tr->stream;
     mark(tr, 0);
@@ -388,16 +429,17 @@ int commit_locked(ls_tracer *tr)
         }
     }
     mark(tr, 1);
-    ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
+    if (want_bvh) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
     mark(tr, 2);
-    ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
+    if (want_bvh) ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
     mark(tr, 3);
-    ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->range_boxes.p);
+    if (want_bvh) ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->range_boxes.p);
     mark(tr, 4);
-    ls::launch_range_tree(s, tr->rt, tr->range_boxes.p);
+    if (want_bvh) ls::launch_range_tree(s, tr->rt, tr->range_boxes.p);
     mark(tr, 5);
-    ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
+    if (want_bvh) ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
     mark(tr, 6);
+    tr->bvh_built = want_bvh;
     LS_HIP(hipGetLastError());
 
     tr->n_verts = nv;
@@ -431,22 +473,38 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
     uint32_t *d_n = tr->ext_points ? tr->ext_n_points : tr->d_n_points;
     if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 32, s));
-    LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
-    ls::RayQueues rq;
-    rq.heads = tr->d_queue_heads;
-    rq.chan_mul = tr->chan_mul;
-    rq.refill_min = tr->refill_min;
-    mark(tr, 7);
-    ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,
-                     tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
-    mark(tr, 8);
-    ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p);
+    if (use_projection(tr)) {
+        // sensor-space projection engine: stream the triangles once, test only the covered rays
+        const ls::ProjectParams pp = project_params(tr);
+        unsigned long long *stats = tr->opt_count ? tr->d_visits + 1 : nullptr;  // counts[1] = triangle tests
+        ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_proj_row_count);
+        mark(tr, 7);
+        ls::launch_project_tris(s, pp, tr->verts.p, tr->tris.p, tr->n_tris, tr->best_keys.p, tr->proj_rows.p,
+                                (uint32_t)tr->proj_rows.cap, tr->d_proj_row_count, stats);
+        mark(tr, 8);
+        ls::launch_project_rows(s, pp, tr->verts.p, tr->tris.p, tr->n_tris, tr->best_keys.p, tr->proj_rows.p,
+                                (uint32_t)tr->proj_rows.cap, tr->d_proj_row_count, 1024u, stats);
+        ls::launch_project_resolve(s, pp, tr->best_keys.p, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p);
+    } else {
+        if (!tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "the BVH engine was selected after the last commit");
+        LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
+        ls::RayQueues rq;
+        rq.heads = tr->d_queue_heads;
+        rq.chan_mul = tr->chan_mul;
+        rq.refill_min = tr->refill_min;
+        mark(tr, 7);
+        ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,
+                         tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
+        mark(tr, 8);
+        ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p);
+    }
+    mark(tr, 9);
     ls::GeomTable gt;
     gt.n = (uint32_t)tr->slot_geom_ids.size();
     gt.tri_first = tr->geom_table.p;
     gt.geom_ids = tr->geom_table.p + gt.n + 1;
     ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n);
-    mark(tr, 9);
+    mark(tr, 10);
     LS_HIP(hipGetLastError());
     tr->traced = true;
     out->d_points32 = d_points;
@@ -520,6 +578,10 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_queue_heads), ls::kQueues * 16 * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_proj_row_count), 64) != hipSuccess) return bail(LS_ERR_HIP);
+    for (float chi : tr->vertical)
+        if (!(chi >= -90.0f && chi <= 90.0f)) tr->projection_ok = false;  // elevation == channel angle only there
+    if (!std::isfinite(tr->h_begin) || !std::isfinite(tr->h_end)) tr->projection_ok = false;
     tr->trace_blocks = ls::trace_grid_blocks(hip_device);
     {
         // channel visiting order (j * chan_mul) % V: a stride near 0.38 V that is coprime with V, so
@@ -553,6 +615,9 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->d_visits) (void)hipFree(tr->d_visits);
     if (tr->d_n_points) (void)hipFree(tr->d_n_points);
     if (tr->d_queue_heads) (void)hipFree(tr->d_queue_heads);
+    if (tr->d_proj_row_count) (void)hipFree(tr->d_proj_row_count);
+    release(tr->best_keys);
+    release(tr->proj_rows);
     release(tr->spill);
     if (tr->h_points) (void)hipHostFree(tr->h_points);
     if (tr->h_hits) (void)hipHostFree(tr->h_hits);
@@ -757,6 +822,12 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         return LS_OK;
     case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
     case LS_OPT_REFIT: tr->opt_refit = value != 0; return LS_OK;
+    case LS_OPT_ENGINE:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "engine must be 0 (auto), 1 (BVH) or 2 (projection)");
+        if (value == 2 && !tr->projection_ok) return fail(tr, LS_ERR_INVALID_ARGUMENT, "projection engine needs channel angles within [-90, 90] degrees");
+        tr->engine = value;
+        tr->traced = false;
+        return LS_OK;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown option");
     }
 }
@@ -766,7 +837,7 @@ int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT])
     LS_ENTER(tr);
     if (!ms) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
     LS_HIP(hipStreamSynchronize(tr->stream));
-    static const int first[LS_T_COUNT] = {0, 1, 2, 3, 4, 5, 7, 8};
+    static const int first[LS_T_COUNT] = {0, 1, 2, 3, 4, 5, 7, 8, 9};
     double sum[LS_T_COUNT] = {};
     uint32_t cnt[LS_T_COUNT] = {};
     for (size_t k = 0; k < tr->trec_used; ++k) {
@@ -862,7 +933,7 @@ int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx)
 int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records)
 {
     LS_ENTER(tr);
-    if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
+    if (!tr->committed || !tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "no BVH: commit with LS_OPT_ENGINE = 1");
     LS_HIP(hipStreamSynchronize(tr->stream));
     if (nodes) LS_HIP(hipMemcpy(nodes, tr->nodes.p, (size_t)tr->n_slots * sizeof(ls::FatNode), hipMemcpyDeviceToHost));
     if (tri_records) LS_HIP(hipMemcpy(tri_records, tr->records.p, (size_t)tr->n_tris * sizeof(ls::TriRecord), hipMemcpyDeviceToHost));

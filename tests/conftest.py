@@ -39,5 +39,17 @@ def capi():
     return c
 
 
-def make_tracer(capi, sensor, **kw):
-    return capi.Tracer(sensor.vertical, sensor.h_begin, sensor.h_end, sensor.h_count, sensor.Rinv, sensor.t, **kw)
+ENGINES = {"bvh": 1, "projection": 2}
+
+
+def make_tracer(capi, sensor, engine=None, **kw):
+    tr = capi.Tracer(sensor.vertical, sensor.h_begin, sensor.h_end, sensor.h_count, sensor.Rinv, sensor.t, **kw)
+    if engine is not None:
+        tr.setOption(capi.LS_OPT_ENGINE, ENGINES[engine])
+    return tr
+
+
+@pytest.fixture(params=["bvh", "projection"])
+def engine(request):
+    """Both closest-hit engines must give the oracle's answer."""
+    return request.param

@@ -47,9 +47,9 @@ def _assert_parity(O, sensor, tr, meshes_list, pts, hits):
     ("0001", False, 1633),
     ("0001", True, 1769),
 ])
-def test_xt32_known_answers(oracle, capi, sensors, meshes, uid, with_ben, expected):
+def test_xt32_known_answers(oracle, capi, sensors, meshes, uid, with_ben, expected, engine):
     s = sensors[uid]
-    tr = make_tracer(capi, s)
+    tr = make_tracer(capi, s, engine)
     assert tr.getTotalRays() == 4800                      # LidarDevice_test.cpp:58
     ml = []
     g0 = _add(tr, "ground", meshes["ground"])
@@ -95,10 +95,10 @@ def test_geometry_bookkeeping(capi, sensors, meshes):
     tr.close()
 
 
-def test_remove_and_retrace_sequence(oracle, capi, sensors, meshes):
+def test_remove_and_retrace_sequence(oracle, capi, sensors, meshes, engine):
     # OptixTracer_test.cpp:217-311: 1781 -> remove "face" -> 1668 -> remove "ground" -> -1 / 0 points
     s = sensors["0000"]
-    tr = make_tracer(capi, s)
+    tr = make_tracer(capi, s, engine)
     _add(tr, "ground", meshes["ground"])
     _add(tr, "face", meshes["ben"])
     tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
@@ -120,9 +120,9 @@ def test_remove_and_retrace_sequence(oracle, capi, sensors, meshes):
     tr.close()
 
 
-def test_dual_sensor_shared_scene(oracle, capi, sensors, meshes):
+def test_dual_sensor_shared_scene(oracle, capi, sensors, meshes, engine):
     # BASELINE.json configs[2]: lidar_0000 + lidar_0001, one tracer per sensor (mainwindow.cpp:258)
-    trs = {u: make_tracer(capi, sensors[u]) for u in ("0000", "0001")}
+    trs = {u: make_tracer(capi, sensors[u], engine) for u in ("0000", "0001")}
     for u, tr in trs.items():
         _add(tr, "ground", meshes["ground"])
         _add(tr, "face", meshes["ben"])
@@ -138,11 +138,11 @@ def test_dual_sensor_shared_scene(oracle, capi, sensors, meshes):
         tr.close()
 
 
-def test_moved_mesh_components(oracle, capi, sensors, meshes):
+def test_moved_mesh_components(oracle, capi, sensors, meshes, engine):
     # updateGeometry(name, translation, rotation, mesh): EmbreeTracer.cpp:276-288, MeshTransformer.cpp:467-477
     s = sensors["0000"]
     lin, ang = [1.5, -2.0, 0.25], [0.1, -0.2, 0.7]
-    tr = make_tracer(capi, s)
+    tr = make_tracer(capi, s, engine)
     _add(tr, "ground", meshes["ground"])
     _add(tr, "face", meshes["ben"])
     tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
@@ -164,13 +164,13 @@ def test_moved_mesh_components(oracle, capi, sensors, meshes):
     tr.close()
 
 
-def test_vertex_stride_and_transformed_vertices(oracle, capi, sensors, meshes):
+def test_vertex_stride_and_transformed_vertices(oracle, capi, sensors, meshes, engine):
     s = sensors["0001"]
     v, t = meshes["ben"]
     rec = np.zeros((v.shape[0], 8), np.float32)           # 32-byte XYZIRPoint-like records
     rec[:, :3] = v
     rec[:, 3:] = 123.0
-    tr = make_tracer(capi, s)
+    tr = make_tracer(capi, s, engine)
     _add(tr, "face", meshes["ben"])
     A = oracle.affine_from_components([0.5, 0.25, -0.125], [0.3, 0.2, -0.1])
     tr.updateGeometry("face", A, rec, t, stride=32)
@@ -186,7 +186,7 @@ def test_vertex_stride_and_transformed_vertices(oracle, capi, sensors, meshes):
 @pytest.mark.parametrize("leaf", [1, 2, 4, 8])
 def test_leaf_sizes(oracle, capi, sensors, meshes, leaf):
     s = sensors["0000"]
-    tr = make_tracer(capi, s)
+    tr = make_tracer(capi, s, "bvh")
     tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
     _add(tr, "ground", meshes["ground"])
     _add(tr, "face", meshes["ben"])
@@ -212,7 +212,7 @@ def test_leaf_sizes(oracle, capi, sensors, meshes, leaf):
 def test_bvh_structure(oracle, capi, sensors, meshes):
     """Every node's child boxes contain the grandchildren's; the leaves partition the triangles;
     a left-first depth-first walk meets the leaves in Morton order."""
-    tr = make_tracer(capi, sensors["0000"])
+    tr = make_tracer(capi, sensors["0000"], "bvh")
     tr.setOption(capi.LS_OPT_LEAF_SIZE, 2)
     _add(tr, "face", meshes["ben"])
     tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
@@ -261,7 +261,7 @@ def test_raygen_kernel(oracle, capi, sensors):
     tr.close()
 
 
-def test_shards_union_equals_full(oracle, capi, sensors, meshes):
+def test_shards_union_equals_full(oracle, capi, sensors, meshes, engine):
     from lidarshooter_amd import synth
     s = sensors["0000"]
     ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)]
@@ -270,7 +270,7 @@ def test_shards_union_equals_full(oracle, capi, sensors, meshes):
     for world in (3, 8):
         allhits.clear()
         for rank in range(world):
-            tr = make_tracer(capi, s)
+            tr = make_tracer(capi, s, engine)
             first, n = synth.shard_columns(s.H, world, rank)
             tr.setShard(first, n)
             assert tr.getTotalRays() == s.V * n
@@ -290,19 +290,25 @@ def test_shards_union_equals_full(oracle, capi, sensors, meshes):
         assert np.array_equal(pts[order], ref["points"])
 
 
-def test_synthetic_medium_vs_oracle_and_bruteforce(oracle, capi, sensors):
-    """20k-triangle relief mesh, XT-32 and a 64x512 sensor: GPU BVH == oracle brute force == GPU
-    exhaustive kernel, for several leaf sizes."""
+def _syn_sensor(oracle, sensors, V=64, H=512, begin=0.0, end=360.0, vertical=None):
+    from lidarshooter_amd import synth
+    base = sensors["0000"]
+    vert = synth.syn_vertical(V) if vertical is None else np.asarray(vertical, np.float32)
+    return oracle.Sensor(uid="syn", vertical=vert, h_begin=np.float32(begin), h_end=np.float32(end), h_count=H,
+                         R=base.R, Rinv=base.Rinv, t=base.t)
+
+
+def test_synthetic_medium_vs_oracle_and_bruteforce(oracle, capi, sensors, engine):
+    """20k-triangle relief mesh, a 64x512 sensor: both engines == oracle (CPU BVH == CPU brute force)
+    == the GPU exhaustive kernel."""
     from lidarshooter_amd import synth
     v, t = synth.grid_mesh(100, 100, half=40.0, seed=11)
-    base = sensors["0000"]
-    s = oracle.Sensor(uid="syn", vertical=synth.syn_vertical(64), h_begin=np.float32(0), h_end=np.float32(360),
-                      h_count=512, R=base.R, Rinv=base.Rinv, t=base.t)
+    s = _syn_sensor(oracle, sensors)
     ml = [(0, v, t, oracle.IDENTITY_AFFINE)]
     ref = oracle.trace_frame(s, ml, use_bvh=True)
     assert int((ref["gid"] != oracle.INVALID).sum()) > 5000
-    for leaf in (1, 4):
-        tr = make_tracer(capi, s)
+    for leaf in ((1, 4) if engine == "bvh" else (1,)):
+        tr = make_tracer(capi, s, engine)
         tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
         tr.addGeometry("g", v.shape[0], t.shape[0])
         tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
@@ -312,6 +318,92 @@ def test_synthetic_medium_vs_oracle_and_bruteforce(oracle, capi, sensors):
         bt, bg = tr.bruteForce()
         assert np.array_equal(bg, ref["gid"]) and np.array_equal(bt, ref["t"])
         tr.close()
+
+
+def _random_soup(rng, n, scale):
+    """Triangles of mixed sizes all around the sensor: some straddle the vertical axis, some the
+    azimuth wrap, some are slivers, some huge."""
+    c = rng.normal(0.0, scale, size=(n, 1, 3))
+    size = np.exp(rng.uniform(np.log(0.02), np.log(scale), size=(n, 1, 1)))
+    tri = c + rng.normal(0.0, 1.0, size=(n, 3, 3)) * size
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return verts, idx
+
+
+@pytest.mark.parametrize("case", ["full_circle", "partial_negative_begin", "reversed_sweep", "unsorted_channels",
+                                  "steep_channels"])
+def test_random_soup_both_engines(oracle, capi, sensors, engine, case):
+    """Exhaustive answer on arbitrary geometry and odd sensor rasters: the footprint bounds of the
+    projection engine (and the BVH boxes) must never lose a hit."""
+    rng = np.random.default_rng({"full_circle": 1, "partial_negative_begin": 2, "reversed_sweep": 3,
+                                 "unsorted_channels": 4, "steep_channels": 5}[case])
+    kw = dict(V=24, H=200)
+    if case == "partial_negative_begin":
+        kw.update(begin=-170.0, end=35.0)
+    elif case == "reversed_sweep":
+        kw.update(begin=300.0, end=-60.0)
+    elif case == "unsorted_channels":
+        kw.update(vertical=rng.permutation(np.linspace(-40.0, 35.0, 24)))
+    elif case == "steep_channels":
+        kw.update(vertical=np.linspace(-90.0, 90.0, 24))
+    s = _syn_sensor(oracle, sensors, **kw)
+    # the sensor frame is what matters: identity pose puts the soup right around the origin
+    s = oracle.Sensor(uid="soup", vertical=s.vertical, h_begin=s.h_begin, h_end=s.h_end, h_count=s.h_count,
+                      R=np.eye(3, dtype=np.float32).reshape(9), Rinv=np.eye(3, dtype=np.float32).reshape(9),
+                      t=np.zeros(3, np.float32))
+    v, t = _random_soup(rng, 3000, 8.0)
+    # a few hand-made nasties: a triangle containing the vertical axis above and below, one through
+    # the azimuth wrap, a big far wall, a needle
+    extra = np.array([[[-1, -1, 3], [2, -1, 3], [-1, 2, 3]], [[-1, -1, -2], [2, -1, -2], [-1, 2, -2]],
+                      [[-5, -0.5, -1], [-5, 0.5, -1], [-5, 0, 2]], [[40, -60, -20], [40, 60, -20], [40, 0, 50]],
+                      [[3, 3, -1], [3.0001, 3, 1], [3, 3.0001, 0]]], np.float32)
+    v = np.concatenate([v, extra.reshape(-1, 3)])
+    t = np.concatenate([t, (np.arange(15, dtype=np.uint32) + 9000).reshape(5, 3)])
+    ml = [(0, v, t, oracle.IDENTITY_AFFINE)]
+    ref = oracle.trace_frame(s, ml)
+    assert int((ref["gid"] != oracle.INVALID).sum()) > 1000
+    tr = make_tracer(capi, s, engine)
+    tr.addGeometry("soup", v.shape[0], t.shape[0])
+    tr.updateGeometry("soup", oracle.IDENTITY_AFFINE, v, t)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    _assert_parity(oracle, s, tr, ml, pts, hits)
+    tr.close()
+
+
+def test_engines_agree_full_size(oracle, capi, sensors):
+    """BASELINE.json's headline workload (128 x 4096 rays over 1M triangles): the two engines and the
+    CPU BVH oracle agree bit for bit on every ray, and on a 256-column sector the GPU exhaustive
+    kernel (every ray x every triangle) agrees too."""
+    from lidarshooter_amd import synth
+    v, t = synth.syn_1m()
+    s = _syn_sensor(oracle, sensors, V=128, H=4096)
+    res = {}
+    for eng in ("bvh", "projection"):
+        tr = make_tracer(capi, s, eng)
+        tr.addGeometry("g", v.shape[0], t.shape[0])
+        tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(0)
+        res[eng] = (tr.denseHits(), pts, hits)
+        if eng == "projection":
+            tr.setShard(1000, 256)
+            tr.commitScene()
+            tr.traceScene(1)
+            st, sg = tr.denseHits()
+            bt, bg = tr.bruteForce()
+            assert np.array_equal(sg, bg) and np.array_equal(st, bt)
+        tr.close()
+    (tb, gb), pb, hb = res["bvh"]
+    (tp, gp), pp, hp = res["projection"]
+    assert np.array_equal(gb, gp) and np.array_equal(tb, tp)
+    assert np.array_equal(pb, pp) and np.array_equal(hb, hp)
+    ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True, nthreads=16)
+    assert np.array_equal(ref["gid"], gp) and np.array_equal(ref["t"], tp)
+    assert np.array_equal(ref["points"], pp)
+    n_hit = int((gp != oracle.INVALID).sum())
+    assert 200000 < n_hit < 300000
 
 
 def test_host_mirror_hiptracer(oracle, sensors, meshes):
