@@ -48,5 +48,21 @@ __device__ __forceinline__ bool tri_test(V3 d, V3 v0, V3 e1, V3 e2, float NgC, f
 }
 
 
+// Vertex into the sensor frame: p' = Rinv * ((A * v) - t), the reference's operation order
+// (MeshTransformer.cpp:176-195 Eigen Affine3f * Vector3f, then LidarDevice.cpp:383-391).
+__device__ __forceinline__ V3 xform_vertex(const Affine &m, const uint8_t *rec)
+{
+    const float *p = reinterpret_cast<const float *>(rec);
+    const float x = p[0], y = p[1], z = p[2];
+    float q[3], o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        q[i] = ((m.a[4 * i + 0] * x + m.a[4 * i + 1] * y) + m.a[4 * i + 2] * z) + m.a[4 * i + 3];
+    const float a = q[0] - m.t[0], b = q[1] - m.t[1], c = q[2] - m.t[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = (m.rinv[3 * i + 0] * a + m.rinv[3 * i + 1] * b) + m.rinv[3 * i + 2] * c;
+    return {o[0], o[1], o[2]};
+}
+
 }  // namespace
 }  // namespace ls

@@ -48,6 +48,7 @@ struct SensorTables {
     const float *cos_theta;  // [V]
     const float *sin_phi;    // [H]
     const float *cos_phi;    // [H]
+    const float2 *cs_phi;    // [H] (cos_phi, sin_phi) interleaved: one 8-byte load per ray
     uint32_t V, H;
     uint32_t az0, naz;       // shard: azimuth columns [az0, az0+naz)
 };
@@ -67,12 +68,34 @@ struct RayQueues {
     uint32_t refill_min;           // idle lanes of a wave that trigger a refill
 };
 
+// mesh transform A (row-major 3x4), sensor rotation inverse and sensor translation
+struct Affine {
+    float a[12];
+    float rinv[9];
+    float t[3];
+};
+
 // Sensor-space projection engine (ls_project.hip)
 struct ProjectParams {
     SensorTables tb;
-    const float *chan_sorted;      // [V] channel elevations (degrees above the horizon), ascending
-    const uint32_t *chan_perm;     // [V] position in chan_sorted -> channel index
+    const float *chan_tan_up;      // [V] tan(elevation + margin) of the channels, ascending elevation
+    const float *chan_tan_dn;      // [V] tan(elevation - margin), same order
+    const uint32_t *chan_perm;     // [V] position in that order -> channel index
     float begin_deg, step_deg;     // azimuth of column h = begin + step*h (LidarDevice.cpp:306)
+    float inv_step_deg, inv_period; // 1/step and |step|/360 (0 when step is 0)
+    float margin_deg;              // angular slack of the footprint bounds
+    int debug;                     // diagnostic: 1 = stop after the vertex loads, 2 = after the footprints
+};
+
+// one geometry as uploaded (xform = 1: vertices still need A / Rinv / t) or the committed scene
+struct GeomSource {
+    const uint8_t *verts;
+    uint32_t stride;
+    const uint32_t *idx;           // 3 * ntris vertex indices into verts
+    uint32_t ntris;
+    uint32_t gid_first;            // global triangle id of triangle 0
+    int xform;
+    Affine m;
 };
 
 // ---- build ---------------------------------------------------------------------------------
@@ -101,16 +124,16 @@ void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_
 void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
                  const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits,
                  uint32_t *n_points);
-// projection engine: init + per-triangle footprint kernel, long-row kernel, resolve (+ row counts)
-void launch_project_tris(hipStream_t s, const ProjectParams &pp, const float *verts, const uint32_t *tris,
-                         uint32_t ntris, unsigned long long *best, uint4 *rows, uint32_t row_capacity,
-                         uint32_t *row_count, unsigned long long *stats);
-void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *row_count);
-void launch_project_rows(hipStream_t s, const ProjectParams &pp, const float *verts, const uint32_t *tris,
-                         uint32_t ntris, unsigned long long *best, const uint4 *rows, uint32_t row_capacity,
-                         const uint32_t *row_count, uint32_t grid_blocks, unsigned long long *stats);
-void launch_project_resolve(hipStream_t s, const ProjectParams &pp, const unsigned long long *best, float *t_out,
-                            uint32_t *gid_out, uint32_t *row_counts);
+// projection engine: per-geometry streaming kernel, big-footprint kernel, resolve (+ row counts)
+size_t project_big_item_bytes();
+void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count);
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
+                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats);
+void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
+                        uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
+                        unsigned long long *stats);
+void launch_project_resolve(hipStream_t s, const ProjectParams &pp, unsigned long long *best, float *t_out,
+                            uint32_t *gid_out, uint32_t *row_counts, uint32_t *big_count);
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz);
 void launch_bruteforce(hipStream_t s, const SensorTables &tb, const float *verts, const uint32_t *tris,
                        uint32_t ntris, float *t_out, uint32_t *gid_out);

@@ -27,7 +27,6 @@ namespace ls {
 namespace {
 
 
-struct Affine { float a[12]; float rinv[9]; float t[3]; };
 
 // ------------------------------------------------------------------------------------------
 // Vertex transform into the sensor frame:  p' = Rinv * ((A * v) - t).  One thread per vertex;
@@ -41,19 +40,11 @@ __global__ __launch_bounds__(kBlock) void k_transform(const uint8_t *__restrict_
     __shared__ float s_max[kBlock / 64];
     float mx = 0.0f;
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const float *p = reinterpret_cast<const float *>(raw + (size_t)j * stride);
-        const float x = p[0], y = p[1], z = p[2];
-        float q[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            q[i] = ((m.a[4 * i + 0] * x + m.a[4 * i + 1] * y) + m.a[4 * i + 2] * z) + m.a[4 * i + 3];
-        const float a = q[0] - m.t[0], b = q[1] - m.t[1], c = q[2] - m.t[2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float o = (m.rinv[3 * i + 0] * a + m.rinv[3 * i + 1] * b) + m.rinv[3 * i + 2] * c;
-            out[3 * (size_t)j + i] = o;
-            mx = fmaxf(mx, fabsf(o));
-        }
+        const V3 o = xform_vertex(m, raw + (size_t)j * stride);
+        out[3 * (size_t)j + 0] = o.x;
+        out[3 * (size_t)j + 1] = o.y;
+        out[3 * (size_t)j + 2] = o.z;
+        mx = fmaxf(mx, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
     }
     // one atomic per block (a single hot address sustains only ~90 atomics/us chip-wide)
 #pragma unroll
@@ -445,55 +436,51 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
     }
 }
 
-// hits per row of 64 consecutive rays (feeds the ordered pack)
+// hits per block of 256 consecutive rays (feeds the ordered pack)
 __global__ __launch_bounds__(kBlock) void k_rowcount(const uint32_t *__restrict__ gid, uint32_t n,
-                                                     uint32_t *__restrict__ row_counts)
+                                                     uint32_t *__restrict__ block_counts)
 {
+    __shared__ uint32_t s_cnt[kBlock / 64];
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     const bool hit = q < n && gid[q] != kInvalid;
     const unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63u) == 0 && (q >> 6) < ((n + 63u) >> 6)) row_counts[q >> 6] = (uint32_t)__popcll(m);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // ------------------------------------------------------------------------------------------
-// Ordered pack: one thread per ray q (shard-local index v*naz + column); block b owns rows
-// [4b, 4b+4) of 64 rays.  Its output offset is the sum of the row counts before it (each block
-// reduces its own prefix: no scan kernel, no cross-block hand-off).  Emits the 32-byte PointCloud2
-// record and the 16-byte ls_hit, both in ray-index order.  Bytes per hit: 8 (t,gid) + 48 written.
+// Ordered pack: one thread per ray q (shard-local index v*naz + column); block b owns rays
+// [256b, 256b+256).  Its output offset is the sum of the hit counts of the blocks before it (each
+// block reduces its own prefix: no scan kernel, no cross-block hand-off).  Emits the 32-byte
+// PointCloud2 record and the 16-byte ls_hit, both in ray-index order.
+// Bytes per hit: 8 (t,gid) + 48 written.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *__restrict__ t_in,
                                                  const uint32_t *__restrict__ gid_in,
-                                                 const uint32_t *__restrict__ row_counts, GeomTable gt,
+                                                 const uint32_t *__restrict__ block_counts, GeomTable gt,
                                                  float4 *__restrict__ points, uint4 *__restrict__ hits,
                                                  uint32_t *__restrict__ n_points)
 {
     __shared__ uint32_t s_part[kBlock / 64];
-    __shared__ uint32_t s_rows[4];
+    __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t nq = tb.V * tb.naz;
-    const uint32_t n_rows = (nq + 63u) >> 6;
-    const uint32_t row0 = blockIdx.x * 4u;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
 
     uint32_t acc = 0;
-    for (uint32_t r = threadIdx.x; r < row0; r += kBlock) acc += row_counts[r];
+    for (uint32_t r = threadIdx.x; r < blockIdx.x; r += kBlock) acc += block_counts[r];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) s_part[w] = acc;
-    if (threadIdx.x < 4) s_rows[threadIdx.x] = (row0 + threadIdx.x < n_rows) ? row_counts[row0 + threadIdx.x] : 0u;
-    __syncthreads();
-    uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    for (uint32_t k = 0; k < w; ++k) base += s_rows[k];
 
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        uint32_t total = base;  // w == 0 here
-        for (uint32_t k = 0; k < 4; ++k) total += s_rows[k];
-        *n_points = total;
-    }
-
-    const uint32_t q = (row0 + w) * 64u + lane;
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gid = q < nq ? gid_in[q] : kInvalid;
     const bool hit = gid != kInvalid;
     const unsigned long long m = __ballot(hit);
+    if (lane == 0) { s_part[w] = acc; s_wave[w] = (uint32_t)__popcll(m); }
+    __syncthreads();
+    uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    for (uint32_t k = 0; k < w; ++k) base += s_wave[k];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_points = base + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     if (!hit) return;
     const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     const uint32_t dst = base + rank;
@@ -501,9 +488,9 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *_
     const uint32_t v = q / tb.naz, h = tb.az0 + (q - v * tb.naz);
     const float t = t_in[q];
     const float st = tb.sin_theta[v];
-    const float dx = st * tb.cos_phi[h], dy = st * tb.sin_phi[h], dz = tb.cos_theta[v];
+    const float2 cs = tb.cs_phi[h];
     // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
-    points[2 * (size_t)dst] = make_float4(t * dx, t * dy, t * dz, 0.0f);
+    points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * tb.cos_theta[v], 0.0f);
     points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
     // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
     uint32_t lo = 0, hi = gt.n;
@@ -694,9 +681,9 @@ void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_
 void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
                  const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
 {
-    const uint32_t n_rows = (tb.V * tb.naz + 63u) >> 6;
-    if (!n_rows) return;
-    hipLaunchKernelGGL(k_pack, dim3((n_rows + 3u) / 4u), dim3(kBlock), 0, s, tb, t, gid, row_counts, gt,
+    const uint32_t nq = tb.V * tb.naz;
+    if (!nq) return;
+    hipLaunchKernelGGL(k_pack, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, row_counts, gt,
                        reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);
 }
 

@@ -11,6 +11,10 @@
 // The result is the exhaustive closest hit, bit for bit, for any scene; the work is
 // O(triangles + covered cells) with no dependent memory chain, i.e. it runs at HBM streaming rate.
 //
+// The vertex transform into the sensor frame (MeshTransformer.cpp:142-205 + LidarDevice.cpp:383-391)
+// is fused in: the kernel reads the mesh as uploaded and transforms the three corners of each
+// triangle on the fly (same arithmetic as k_transform, so the same bits).
+//
 // Replaces (with the BVH engine in ls_kernels.hip as the general-ray alternative):
 // rtcIntersect16 over the committed scene (EmbreeTracer.cpp:297-367, :472-480) / optixLaunch
 // (OptixTracer.cpp:317-328, OptixTracerModules.cu:26-86).
@@ -22,250 +26,379 @@ namespace ls {
 namespace {
 
 constexpr float kRadToDeg = 57.29577951308232f;
-constexpr float kAngleMarginDeg = 0.02f;  // ~3.5e-4 rad: covers atan2f / table rounding and tri_test slop
-constexpr uint32_t kInlineCols = 16;      // longer rows of cells go to the row queue
+constexpr uint32_t kBigCells = 8192;   // footprints above this go to the big-triangle queue
+
+// The footprint bounds only have to be conservative, not exact: they use the hardware's 1-ulp
+// reciprocal / square root and a polynomial arctangent, and every use carries explicit slack
+// (factors 0.9999 / 1.0001, the angular margin, 1/16 raster column per side).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 __device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
 
-// squared distance from the 2-D origin to segment a-b
+// squared distance from the 2-D origin to segment a-b (approximate to a few ulp)
 __device__ __forceinline__ float seg_dist2(float ax, float ay, float bx, float by)
 {
     const float dx = bx - ax, dy = by - ay;
     const float len2 = dx * dx + dy * dy;
-    float s = len2 > 0.0f ? -(ax * dx + ay * dy) / len2 : 0.0f;
+    float s = len2 > 0.0f ? -(ax * dx + ay * dy) * fast_rcp(len2) : 0.0f;
     s = fminf(fmaxf(s, 0.0f), 1.0f);
     const float px = ax + s * dx, py = ay + s * dy;
     return px * px + py * py;
 }
 
-struct TriSetup {
-    V3 v0, e1, e2;
-    float NgC;
-};
-
-__device__ __forceinline__ void load_tri(const float *__restrict__ verts, const uint32_t *__restrict__ tris, uint32_t gid,
-                                         V3 &v0, V3 &v1, V3 &v2)
+// atan2 in degrees, |error| < 1e-3 deg (Abramowitz & Stegun 4.4.49 on [0,1] + octant folding)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
-    const uint32_t i0 = tris[3 * (size_t)gid + 0], i1 = tris[3 * (size_t)gid + 1], i2 = tris[3 * (size_t)gid + 2];
-    v0 = {verts[3 * (size_t)i0], verts[3 * (size_t)i0 + 1], verts[3 * (size_t)i0 + 2]};
-    v1 = {verts[3 * (size_t)i1], verts[3 * (size_t)i1 + 1], verts[3 * (size_t)i1 + 2]};
-    v2 = {verts[3 * (size_t)i2], verts[3 * (size_t)i2 + 1], verts[3 * (size_t)i2 + 2]};
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.0f ? mn * fast_rcp(mx) : 0.0f;
+    const float s = a * a;
+    float r = a * (0.9999772256f + s * (-0.3326234763f + s * (0.1935434479f + s * (-0.1164328762f +
+                  s * (0.0526533153f + s * -0.0117212052f)))));
+    r *= kRadToDeg;
+    if (ay > ax) r = 90.0f - r;
+    if (x < 0.0f) r = 180.0f - r;
+    return y < 0.0f ? -r : r;
 }
 
-__device__ __forceinline__ TriSetup setup_tri(V3 v0, V3 v1, V3 v2)
+// Footprint of a triangle on the raster: channels chan_perm[i0 .. i0+nch) x columns
+// [h0a, h0a+na) u [h0b, h0b+nb).  A superset of the rays that can hit the triangle.
+struct Foot {
+    uint32_t i0, nch, h0a, na, h0b, nb;
+};
+
+// per-channel tables, staged in LDS by k_project (global memory when V is too large for that)
+struct ChanTables {
+    const float *tan_up, *tan_dn, *sin_theta, *cos_theta;
+    const uint32_t *perm;
+};
+
+__device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 v1, V3 v2)
 {
-    TriSetup s;
-    s.v0 = v0;
-    s.e1 = sub(v0, v1);
-    s.e2 = sub(v2, v0);
-    s.NgC = dot_fma(cross_fma(s.e2, s.e1), v0);
-    return s;
+    Foot f = {0, 0, 0, 0, 0, 0};
+    // ---- elevation band in tangent space: tan(e) = z / rho over the triangle lies inside
+    //      [zmin / (zmin >= 0 ? rho_max : rho_min), zmax / (zmax > 0 ? rho_min : rho_max)]
+    const float zmin = fminf(v0.z, fminf(v1.z, v2.z)), zmax = fmaxf(v0.z, fmaxf(v1.z, v2.z));
+    const float r0 = v0.x * v0.x + v0.y * v0.y, r1 = v1.x * v1.x + v1.y * v1.y, r2 = v2.x * v2.x + v2.y * v2.y;
+    const float rho_max = fast_sqrt(fmaxf(r0, fmaxf(r1, r2))) * 1.0001f;
+    const float c0 = cross2(v0.x, v0.y, v1.x, v1.y), c1 = cross2(v1.x, v1.y, v2.x, v2.y),
+                c2 = cross2(v2.x, v2.y, v0.x, v0.y);
+    const float ctol = 1e-6f * rho_max * rho_max;
+    const bool inside = (c0 >= -ctol && c1 >= -ctol && c2 >= -ctol) || (c0 <= ctol && c1 <= ctol && c2 <= ctol);
+    float rho_min = 0.0f;
+    if (!inside)
+        rho_min = 0.9999f * fast_sqrt(fminf(seg_dist2(v0.x, v0.y, v1.x, v1.y),
+                                            fminf(seg_dist2(v1.x, v1.y, v2.x, v2.y), seg_dist2(v2.x, v2.y, v0.x, v0.y))));
+    float tan_lo = -INFINITY, tan_hi = INFINITY;
+    if (rho_max > 0.0f) {
+        // quotients rounded outwards by 1e-5 relative (the reciprocal is good to 1 ulp)
+        const float inv_max = fast_rcp(rho_max), inv_min = rho_min > 0.0f ? fast_rcp(rho_min) : 0.0f;
+        if (zmin >= 0.0f) tan_lo = zmin * inv_max * 0.99999f;
+        else if (rho_min > 0.0f) tan_lo = zmin * inv_min * 1.00001f;
+        if (zmax <= 0.0f) tan_hi = zmax * inv_max * 0.99999f;
+        else if (rho_min > 0.0f) tan_hi = zmax * inv_min * 1.00001f;
+    }
+    // channels whose elevation (widened by the angular margin) meets the band: chan_tan_up[i] =
+    // tan(chi_i + margin), chan_tan_dn[i] = tan(chi_i - margin), both ascending
+    uint32_t lo = 0, hi = pp.tb.V;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (ct.tan_up[m] < tan_lo) lo = m + 1; else hi = m; }
+    const uint32_t i0 = lo;
+    uint32_t i1 = i0;  // bands are narrow: walk forward instead of a second search
+    while (i1 < pp.tb.V && ct.tan_dn[i1] <= tan_hi) ++i1;
+    if (i0 >= i1) return f;
+
+    // ---- azimuth arc: the three vertex azimuths minus the largest gap between them; if that gap is
+    //      not larger than 180 deg the origin is inside the projection: full circle
+    const uint32_t az_first = pp.tb.az0, az_last = pp.tb.az0 + pp.tb.naz - 1u;
+    bool full = inside || !(fabsf(pp.step_deg) > 0.0f);
+    float phi_lo = 0.0f, span = 360.0f;
+    if (!full) {
+        float a = fast_atan2_deg(v0.y, v0.x), b = fast_atan2_deg(v1.y, v1.x), c = fast_atan2_deg(v2.y, v2.x);
+        float t;
+        if (a > b) { t = a; a = b; b = t; }
+        if (b > c) { t = b; b = c; c = t; }
+        if (a > b) { t = a; a = b; b = t; }
+        const float g0 = b - a, g1 = c - b, g2 = a + 360.0f - c;
+        float maxgap = g2;
+        phi_lo = a;                                    // arc [a, c]
+        if (g0 > maxgap) { maxgap = g0; phi_lo = b; }  // arc [b, a + 360]
+        if (g1 > maxgap) { maxgap = g1; phi_lo = c; }  // arc [c, b + 360]
+        span = 360.0f - maxgap;
+        if (!(maxgap > 180.0f + 2.0f * pp.margin_deg)) full = true;
+    }
+    f.i0 = i0;
+    f.nch = i1 - i0;
+    if (!full) {
+        // column index (real) of an azimuth: u = (phi - begin) / step; the raster repeats every P columns
+        const float inv_step = pp.inv_step_deg;
+        const float P = 360.0f * fabsf(inv_step), invP = pp.inv_period;
+        const float ua = (phi_lo - pp.margin_deg - pp.begin_deg) * inv_step;
+        const float ub = (phi_lo + span + pp.margin_deg - pp.begin_deg) * inv_step;
+        // slack per side: the angular margin (in ua/ub) + 1/16 column for the float rounding of u itself
+        const float u_lo = fminf(ua, ub) - 0.0625f, u_hi = fmaxf(ua, ub) + 0.0625f;
+        // n with [u_lo, u_hi] + n*P meeting [az_first, az_last]; half a column of slack absorbs invP's rounding
+        const int n_min = (int)ceilf(((float)az_first - u_hi - 0.5f) * invP);
+        const int n_max = (int)floorf(((float)az_last - u_lo + 0.5f) * invP);
+        if (u_hi - u_lo >= P || n_max - n_min > 1) {
+            full = true;  // more than two pieces: take the whole revolution (a superset)
+        } else {
+            for (int n = n_min; n <= n_max; ++n) {
+                const float l = ceilf(u_lo + (float)n * P), h = floorf(u_hi + (float)n * P);
+                if (h < (float)az_first || l > (float)az_last) continue;
+                const uint32_t h0 = (uint32_t)fmaxf(l, (float)az_first), h1 = (uint32_t)fminf(h, (float)az_last);
+                if (h0 > h1) continue;
+                if (n == n_min) { f.h0a = h0; f.na = h1 - h0 + 1u; }
+                else { f.h0b = h0; f.nb = h1 - h0 + 1u; }
+            }
+        }
+    }
+    if (full) { f.h0a = az_first; f.na = az_last - az_first + 1u; f.h0b = 0; f.nb = 0; }
+    return f;
+}
+
+// cell m of a footprint -> (channel, column)
+__device__ __forceinline__ void foot_cell(const ChanTables &ct, uint32_t i0, uint32_t h0a, uint32_t na, uint32_t h0b,
+                                          uint32_t nb, uint32_t m, uint32_t &v, uint32_t &h)
+{
+    // m / ncol by reciprocal with a one-step correction (m < 2^24 cells per footprint in practice;
+    // larger values fall back to the exact division)
+    const uint32_t ncol = na + nb;
+    uint32_t r;
+    if (m < (1u << 24)) {
+        r = (uint32_t)((float)m * fast_rcp((float)ncol));
+        if (r * ncol > m) --r;
+        if ((r + 1u) * ncol <= m) ++r;
+    } else {
+        r = m / ncol;
+    }
+    const uint32_t c = m - r * ncol;
+    v = ct.perm[i0 + r];
+    h = c < na ? h0a + c : h0b + (c - na);
 }
 
 // exact test of ray (v, h) against the triangle; fold a hit into the ray's closest-hit key
-__device__ __forceinline__ void test_cell(const ProjectParams &pp, const TriSetup &ts, uint32_t gid, uint32_t v, uint32_t h,
-                                          unsigned long long *__restrict__ best)
+__device__ __forceinline__ void test_cell(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 e1, V3 e2, float NgC,
+                                          uint32_t gid, uint32_t v, uint32_t h, unsigned long long *__restrict__ best)
 {
-    const float st = pp.tb.sin_theta[v];
-    const V3 d = {st * pp.tb.cos_phi[h], st * pp.tb.sin_phi[h], pp.tb.cos_theta[v]};
+    // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
+    const float st = ct.sin_theta[v];
+    const float2 cs = pp.tb.cs_phi[h];
+    const V3 d = {st * cs.x, st * cs.y, ct.cos_theta[v]};
     float t;
-    if (tri_test(d, ts.v0, ts.e1, ts.e2, ts.NgC, t)) {
+    if (tri_test(d, v0, e1, e2, NgC, t)) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | gid;  // t > 0: bits order like t
         atomicMin(&best[(size_t)v * pp.tb.naz + (h - pp.tb.az0)], key);
     }
 }
 
+// 80-byte queue entry for a triangle whose footprint is too large for one wave
+struct BigItem {
+    float v0[3], e1[3], e2[3], NgC;
+    uint32_t gid, i0, nch, h0a, na, h0b, nb, pad[3];
+};
+static_assert(sizeof(BigItem) == 80, "BigItem must be 80 bytes");
+
 // ------------------------------------------------------------------------------------------
-// One thread per triangle: conservative footprint on the (channel, column) raster, short rows
-// tested in place, long rows pushed to the row queue for k_project_rows.
-// Algorithmic bytes per triangle: 12 (indices) + 36 (vertex gather).
+// One lane per triangle; each wave then spreads the cells of its 64 footprints evenly over its
+// lanes (prefix sum + search), so a wave's cost is its total cell count / 64, not its largest
+// footprint.  Algorithmic bytes per triangle: 12 (indices) + 36 (vertex gather); per hit 8.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_project_tris(ProjectParams pp, const float *__restrict__ verts,
-                                                         const uint32_t *__restrict__ tris, uint32_t ntris,
-                                                         unsigned long long *__restrict__ best,
-                                                         uint4 *__restrict__ rows, uint32_t row_capacity,
-                                                         uint32_t *__restrict__ row_count,
-                                                         unsigned long long *__restrict__ stats)
+template <bool COUNT, bool LDS_TABLES>
+__global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource src,
+                                                    unsigned long long *__restrict__ best, BigItem *__restrict__ big,
+                                                    uint32_t big_capacity, uint32_t *__restrict__ big_count,
+                                                    unsigned long long *__restrict__ stats)
 {
-    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t ntest = 0;
-    if (gid < ntris) {
-        V3 v0, v1, v2;
-        load_tri(verts, tris, gid, v0, v1, v2);
-
-        // ---- elevation band: e = atan2(z, rho) over the triangle is inside
-        //      [atan2(zmin, zmin >= 0 ? rho_max : rho_min), atan2(zmax, zmax > 0 ? rho_min : rho_max)]
-        const float zmin = fminf(v0.z, fminf(v1.z, v2.z)), zmax = fmaxf(v0.z, fmaxf(v1.z, v2.z));
-        const float r0 = v0.x * v0.x + v0.y * v0.y, r1 = v1.x * v1.x + v1.y * v1.y, r2 = v2.x * v2.x + v2.y * v2.y;
-        const float rho_max = sqrtf(fmaxf(r0, fmaxf(r1, r2)));
-        const float c0 = cross2(v0.x, v0.y, v1.x, v1.y), c1 = cross2(v1.x, v1.y, v2.x, v2.y),
-                    c2 = cross2(v2.x, v2.y, v0.x, v0.y);
-        const float ctol = 1e-6f * rho_max * rho_max;
-        const bool inside = (c0 >= -ctol && c1 >= -ctol && c2 >= -ctol) || (c0 <= ctol && c1 <= ctol && c2 <= ctol);
-        float rho_min = 0.0f;
-        if (!inside)
-            rho_min = sqrtf(fminf(seg_dist2(v0.x, v0.y, v1.x, v1.y),
-                                  fminf(seg_dist2(v1.x, v1.y, v2.x, v2.y), seg_dist2(v2.x, v2.y, v0.x, v0.y))));
-        rho_min *= 0.9999f;  // rounding slack, keeps the band conservative
-        const float e_lo = atan2f(zmin, zmin >= 0.0f ? rho_max * 1.0001f : rho_min) * kRadToDeg - kAngleMarginDeg;
-        const float e_hi = atan2f(zmax, zmax > 0.0f ? rho_min : rho_max * 1.0001f) * kRadToDeg + kAngleMarginDeg;
-
-        // channels with elevation in [e_lo, e_hi]: a contiguous range of the sorted channel table
-        uint32_t i0 = 0, i1 = pp.tb.V;
-        {
-            uint32_t lo = 0, hi = pp.tb.V;  // first index with chan_sorted >= e_lo
-            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (pp.chan_sorted[m] < e_lo) lo = m + 1; else hi = m; }
-            i0 = lo;
-            hi = pp.tb.V;                   // first index with chan_sorted > e_hi
-            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (pp.chan_sorted[m] <= e_hi) lo = m + 1; else hi = m; }
-            i1 = lo;
+    __shared__ float s_tri[kBlock / 64][10][64];      // v0, e1, e2, NgC of the wave's triangles
+    __shared__ uint32_t s_meta[kBlock / 64][6][64];   // gid, i0, h0a, na, h0b, nb
+    __shared__ uint32_t s_pref[kBlock / 64][64];      // exclusive prefix of the cell counts
+    extern __shared__ float s_chan[];                 // LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
+    if (LDS_TABLES) {
+        const uint32_t V = pp.tb.V;
+        for (uint32_t i = threadIdx.x; i < V; i += kBlock) {
+            s_chan[i] = pp.chan_tan_up[i];
+            s_chan[V + i] = pp.chan_tan_dn[i];
+            s_chan[2 * V + i] = pp.tb.sin_theta[i];
+            s_chan[3 * V + i] = pp.tb.cos_theta[i];
+            s_chan[4 * V + i] = __uint_as_float(pp.chan_perm[i]);
         }
-        if (i0 < i1) {
-            // ---- azimuth arc: the three vertex azimuths minus the largest gap between them; if that
-            //      gap is not larger than 180 deg the origin is inside the projection: full circle
-            const uint32_t az_first = pp.tb.az0, az_last = pp.tb.az0 + pp.tb.naz - 1u;
-            float phi_lo = 0.0f, span = 360.0f;
-            bool full = inside || !(fabsf(pp.step_deg) > 0.0f);
-            if (!full) {
-                float a = atan2f(v0.y, v0.x) * kRadToDeg, b = atan2f(v1.y, v1.x) * kRadToDeg, c = atan2f(v2.y, v2.x) * kRadToDeg;
-                float t;
-                if (a > b) { t = a; a = b; b = t; }
-                if (b > c) { t = b; b = c; c = t; }
-                if (a > b) { t = a; a = b; b = t; }
-                const float g0 = b - a, g1 = c - b, g2 = a + 360.0f - c;
-                float maxgap = g2;
-                phi_lo = a;                     // arc = [a, c]
-                if (g0 > maxgap) { maxgap = g0; phi_lo = b; }   // arc = [b, a+360]
-                if (g1 > maxgap) { maxgap = g1; phi_lo = c; }   // arc = [c, b+360]
-                span = 360.0f - maxgap;
-                if (!(maxgap > 180.0f + 2.0f * kAngleMarginDeg)) full = true;
-            }
-            const TriSetup ts = setup_tri(v0, v1, v2);
-            // column index (real) of an azimuth: u = (phi - begin) / step; the raster repeats every P columns
-            const float inv_step = full ? 0.0f : 1.0f / pp.step_deg;
-            const float P = full ? 0.0f : 360.0f * fabsf(inv_step);
-            float u_lo = 0.0f, u_hi = 0.0f;
-            int n_min = 0, n_max = 0;
-            if (!full) {
-                const float ua = (phi_lo - kAngleMarginDeg - pp.begin_deg) * inv_step;
-                const float ub = (phi_lo + span + kAngleMarginDeg - pp.begin_deg) * inv_step;
-                u_lo = fminf(ua, ub) - 1.0f;   // one column of slack on both sides
-                u_hi = fmaxf(ua, ub) + 1.0f;
-                n_min = (int)ceilf(((float)az_first - u_hi) / P);
-                n_max = (int)floorf(((float)az_last - u_lo) / P);
-                if (u_hi - u_lo >= P) { full = true; }
-            }
-            if (full) { n_min = n_max = 0; }
-            for (int n = n_min; n <= n_max; ++n) {
-                uint32_t h0 = az_first, h1 = az_last;
-                if (!full) {
-                    const float lo = ceilf(u_lo + (float)n * P), hi = floorf(u_hi + (float)n * P);
-                    if (hi < (float)az_first || lo > (float)az_last) continue;
-                    h0 = (uint32_t)fmaxf(lo, (float)az_first);
-                    h1 = (uint32_t)fminf(hi, (float)az_last);
-                    if (h0 > h1) continue;
+        ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V)};
+        __syncthreads();
+    }
+    uint32_t cells = 0;
+    if (k < src.ntris) {
+        const uint32_t a = src.idx[3 * (size_t)k + 0], b = src.idx[3 * (size_t)k + 1], c = src.idx[3 * (size_t)k + 2];
+        V3 v0, v1, v2;
+        if (src.xform) {
+            v0 = xform_vertex(src.m, src.verts + (size_t)a * src.stride);
+            v1 = xform_vertex(src.m, src.verts + (size_t)b * src.stride);
+            v2 = xform_vertex(src.m, src.verts + (size_t)c * src.stride);
+        } else {
+            const float *pa = reinterpret_cast<const float *>(src.verts + (size_t)a * src.stride);
+            const float *pb = reinterpret_cast<const float *>(src.verts + (size_t)b * src.stride);
+            const float *pc = reinterpret_cast<const float *>(src.verts + (size_t)c * src.stride);
+            v0 = {pa[0], pa[1], pa[2]}; v1 = {pb[0], pb[1], pb[2]}; v2 = {pc[0], pc[1], pc[2]};
+        }
+        if (pp.debug == 1) { if (v0.x + v1.y + v2.z == 12345.678f) best[0] = 0; return; }
+        const Foot f = footprint(pp, ct, v0, v1, v2);
+        cells = f.nch * (f.na + f.nb);
+        if (pp.debug == 2) { if (cells == 0xFFFFFFFFu) best[0] = 0; return; }
+        if (cells) {
+            const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
+            const float NgC = dot_fma(cross_fma(e2, e1), v0);
+            const uint32_t gid = src.gid_first + k;
+            bool queued = false;
+            if (cells > kBigCells) {
+                const uint32_t slot = atomicAdd(big_count, 1u);
+                if (slot < big_capacity) {
+                    BigItem it;
+                    it.v0[0] = v0.x; it.v0[1] = v0.y; it.v0[2] = v0.z;
+                    it.e1[0] = e1.x; it.e1[1] = e1.y; it.e1[2] = e1.z;
+                    it.e2[0] = e2.x; it.e2[1] = e2.y; it.e2[2] = e2.z;
+                    it.NgC = NgC; it.gid = gid; it.i0 = f.i0; it.nch = f.nch;
+                    it.h0a = f.h0a; it.na = f.na; it.h0b = f.h0b; it.nb = f.nb;
+                    it.pad[0] = it.pad[1] = it.pad[2] = 0;
+                    big[slot] = it;
+                    queued = true;
                 }
-                const uint32_t ncol = h1 - h0 + 1u;
-                for (uint32_t i = i0; i < i1; ++i) {
-                    const uint32_t v = pp.chan_perm[i];
-                    bool inline_row = ncol <= kInlineCols;
-                    if (!inline_row) {
-                        const uint32_t slot = atomicAdd(row_count, 1u);
-                        if (slot < row_capacity) rows[slot] = make_uint4(gid, v, h0, h1);
-                        else inline_row = true;  // queue full: correct, just slower
-                    }
-                    if (inline_row) {
-                        for (uint32_t h = h0; h <= h1; ++h) test_cell(pp, ts, gid, v, h, best);
-                        ntest += ncol;
-                    }
-                }
+            }
+            if (queued) {
+                cells = 0;
+            } else {
+                s_tri[w][0][lane] = v0.x; s_tri[w][1][lane] = v0.y; s_tri[w][2][lane] = v0.z;
+                s_tri[w][3][lane] = e1.x; s_tri[w][4][lane] = e1.y; s_tri[w][5][lane] = e1.z;
+                s_tri[w][6][lane] = e2.x; s_tri[w][7][lane] = e2.y; s_tri[w][8][lane] = e2.z;
+                s_tri[w][9][lane] = NgC;
+                s_meta[w][0][lane] = gid; s_meta[w][1][lane] = f.i0; s_meta[w][2][lane] = f.h0a;
+                s_meta[w][3][lane] = f.na; s_meta[w][4][lane] = f.h0b; s_meta[w][5][lane] = f.nb;
             }
         }
     }
-    if (stats) {
+    // wave-level inclusive scan of the cell counts
+    uint32_t incl = cells;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) ntest += __shfl_xor(ntest, off);
-        if ((threadIdx.x & 63u) == 0 && ntest) atomicAdd(&stats[0], (unsigned long long)ntest);
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += up;
     }
+    const uint32_t total = __shfl(incl, 63);
+    s_pref[w][lane] = incl - cells;
+    __syncthreads();
+    for (uint32_t j = lane; j < total; j += 64u) {
+        // the triangle that owns cell j: last lane whose exclusive prefix is <= j
+        uint32_t lo = 0, hi = 64;
+        while (hi - lo > 1) {
+            const uint32_t m = (lo + hi) >> 1;
+            if (s_pref[w][m] <= j) lo = m; else hi = m;
+        }
+        const uint32_t m = j - s_pref[w][lo];
+        uint32_t v, h;
+        foot_cell(ct, s_meta[w][1][lo], s_meta[w][2][lo], s_meta[w][3][lo], s_meta[w][4][lo], s_meta[w][5][lo], m, v, h);
+        test_cell(pp, ct, {s_tri[w][0][lo], s_tri[w][1][lo], s_tri[w][2][lo]}, {s_tri[w][3][lo], s_tri[w][4][lo], s_tri[w][5][lo]},
+                  {s_tri[w][6][lo], s_tri[w][7][lo], s_tri[w][8][lo]}, s_tri[w][9][lo], s_meta[w][0][lo], v, h, best);
+    }
+    if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
 }
 
-// ------------------------------------------------------------------------------------------
-// Long rows (large triangles): one wave per queued row, lanes stride over its columns.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_project_rows(ProjectParams pp, const float *__restrict__ verts,
-                                                         const uint32_t *__restrict__ tris,
-                                                         unsigned long long *__restrict__ best,
-                                                         const uint4 *__restrict__ rows, uint32_t row_capacity,
-                                                         const uint32_t *__restrict__ row_count,
-                                                         unsigned long long *__restrict__ stats)
+// Triangles with very large footprints: the whole grid strides over the cells of each queued item.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_project_big(ProjectParams pp, unsigned long long *__restrict__ best,
+                                                        const BigItem *__restrict__ big, uint32_t big_capacity,
+                                                        const uint32_t *__restrict__ big_count,
+                                                        unsigned long long *__restrict__ stats)
 {
-    const uint32_t n_rows = min(*row_count, row_capacity);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
-    uint32_t ntest = 0;
-    for (uint32_t r = wave; r < n_rows; r += n_waves) {
-        const uint4 row = rows[r];
-        V3 v0, v1, v2;
-        load_tri(verts, tris, row.x, v0, v1, v2);
-        const TriSetup ts = setup_tri(v0, v1, v2);
-        for (uint32_t h = row.z + lane; h <= row.w; h += 64u) test_cell(pp, ts, row.x, row.y, h, best);
-        if (lane == 0) ntest += row.w - row.z + 1u;
+    const uint32_t n_items = min(*big_count, big_capacity);
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, nthreads = gridDim.x * kBlock;
+    const ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
+    for (uint32_t r = 0; r < n_items; ++r) {
+        const BigItem it = big[r];
+        const uint32_t cells = it.nch * (it.na + it.nb);
+        for (uint32_t m = tid; m < cells; m += nthreads) {
+            uint32_t v, h;
+            foot_cell(ct, it.i0, it.h0a, it.na, it.h0b, it.nb, m, v, h);
+            test_cell(pp, ct, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
+                      it.NgC, it.gid, v, h, best);
+        }
+        if (COUNT && tid == 0) atomicAdd(&stats[0], (unsigned long long)cells);
     }
-    if (stats && lane == 0 && ntest) atomicAdd(&stats[0], (unsigned long long)ntest);
 }
 
-// per-ray closest-hit key -> dense t / gid arrays + hits per row of 64 rays (feeds the ordered pack)
-__global__ __launch_bounds__(kBlock) void k_project_resolve(const unsigned long long *__restrict__ best, uint32_t n,
+// Per-ray closest-hit key -> dense t / gid arrays + hits per 256-ray block (feeds the ordered pack).
+// Also re-arms the keys and the big-triangle queue for the next frame, so a frame needs no memset.
+__global__ __launch_bounds__(kBlock) void k_project_resolve(unsigned long long *__restrict__ best, uint32_t n,
                                                             float *__restrict__ t_out, uint32_t *__restrict__ gid_out,
-                                                            uint32_t *__restrict__ row_counts)
+                                                            uint32_t *__restrict__ row_counts,
+                                                            uint32_t *__restrict__ big_count)
 {
+    __shared__ uint32_t s_cnt[kBlock / 64];
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     bool hit = false;
     if (q < n) {
         const unsigned long long key = best[q];
+        best[q] = ~0ull;
         hit = key != ~0ull;
         t_out[q] = hit ? __uint_as_float((uint32_t)(key >> 32)) : -1.0f;
         gid_out[q] = hit ? (uint32_t)key : kInvalid;
     }
     const unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63u) == 0 && (q >> 6) < ((n + 63u) >> 6)) row_counts[q >> 6] = (uint32_t)__popcll(m);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) row_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];  // per 256-ray block
+    if (q == 0) *big_count = 0u;
 }
 
 }  // namespace
 
-void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *row_count)
+size_t project_big_item_bytes() { return sizeof(BigItem); }
+
+void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count)
 {
     const uint32_t nq = pp.tb.V * pp.tb.naz;
     if (!nq) return;
     (void)hipMemsetAsync(best, 0xFF, (size_t)nq * sizeof(unsigned long long), s);
-    (void)hipMemsetAsync(row_count, 0, sizeof(uint32_t), s);
+    (void)hipMemsetAsync(big_count, 0, sizeof(uint32_t), s);
 }
 
-void launch_project_tris(hipStream_t s, const ProjectParams &pp, const float *verts, const uint32_t *tris,
-                         uint32_t ntris, unsigned long long *best, uint4 *rows, uint32_t row_capacity,
-                         uint32_t *row_count, unsigned long long *stats)
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
+                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats)
 {
-    if (!ntris || !(pp.tb.V * pp.tb.naz)) return;
-    hipLaunchKernelGGL(k_project_tris, dim3((ntris + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pp, verts, tris, ntris,
-                       best, rows, row_capacity, row_count, stats);
+    if (!src.ntris || !(pp.tb.V * pp.tb.naz)) return;
+    const dim3 grid((src.ntris + kBlock - 1) / kBlock);
+    BigItem *bq = static_cast<BigItem *>(big);
+    const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
+    if (pp.tb.V <= 2048u) {  // channel tables fit in LDS (40 KB at most)
+        if (stats) hipLaunchKernelGGL((k_project<true, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
+        else hipLaunchKernelGGL((k_project<false, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_project<true, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
+        else hipLaunchKernelGGL((k_project<false, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
+    }
 }
 
-void launch_project_rows(hipStream_t s, const ProjectParams &pp, const float *verts, const uint32_t *tris,
-                         uint32_t ntris, unsigned long long *best, const uint4 *rows, uint32_t row_capacity,
-                         const uint32_t *row_count, uint32_t grid_blocks, unsigned long long *stats)
+void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
+                        uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
+                        unsigned long long *stats)
 {
-    if (!ntris || !(pp.tb.V * pp.tb.naz)) return;
-    hipLaunchKernelGGL(k_project_rows, dim3(grid_blocks), dim3(kBlock), 0, s, pp, verts, tris, best, rows, row_capacity,
-                       row_count, stats);
+    if (!(pp.tb.V * pp.tb.naz)) return;
+    if (stats)
+        hipLaunchKernelGGL(k_project_big<true>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best,
+                           static_cast<const BigItem *>(big), big_capacity, big_count, stats);
+    else
+        hipLaunchKernelGGL(k_project_big<false>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best,
+                           static_cast<const BigItem *>(big), big_capacity, big_count, stats);
 }
 
-void launch_project_resolve(hipStream_t s, const ProjectParams &pp, const unsigned long long *best, float *t_out,
-                            uint32_t *gid_out, uint32_t *row_counts)
+void launch_project_resolve(hipStream_t s, const ProjectParams &pp, unsigned long long *best, float *t_out,
+                            uint32_t *gid_out, uint32_t *row_counts, uint32_t *big_count)
 {
     const uint32_t nq = pp.tb.V * pp.tb.naz;
     if (!nq) return;
     hipLaunchKernelGGL(k_project_resolve, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, s, best, nq, t_out, gid_out,
-                       row_counts);
+                       row_counts, big_count);
 }
 
 }  // namespace ls

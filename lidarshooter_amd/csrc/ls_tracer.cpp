@@ -74,8 +74,13 @@ struct ls_tracer {
     DevBuf<ls::FatNode> nodes;
     DevBuf<float4> range_boxes;
     DevBuf<unsigned long long> best_keys;  // projection engine: per-ray (t bits, gid) closest-hit key
-    DevBuf<uint4> proj_rows;               // projection engine: queue of long cell rows
-    uint32_t *d_proj_row_count = nullptr;
+    DevBuf<uint8_t> big_queue;             // projection engine: triangles with very large footprints
+    uint32_t big_capacity = 0;
+    uint32_t *d_big_count = nullptr;
+    bool keys_armed = false;               // best_keys all ~0 and big_count 0 (k_project_resolve re-arms them)
+    bool scene_materialized = false;       // verts / tris hold the transformed scene of the last commit
+    struct LayoutEntry { std::string name; uint32_t vfirst, tfirst; };
+    std::vector<LayoutEntry> layout;
     bool projection_ok = true;             // all channel elevations within [-90, 90] degrees
     int engine = 0;                        // LS_OPT_ENGINE: 0 auto, 1 BVH, 2 projection
     bool bvh_built = false;
@@ -154,6 +159,8 @@ void release(DevBuf<T> &b)
     b.cap = 0;
 }
 
+constexpr float kProjectMarginDeg = 0.02f;  // ~3.5e-4 rad: atan2f / table rounding and triangle-test slop
+
 bool use_projection(const ls_tracer *tr) { return tr->engine == 2 || (tr->engine == 0 && tr->projection_ok); }
 
 ls::ProjectParams project_params(const ls_tracer *tr);
@@ -165,6 +172,7 @@ ls::SensorTables tables(const ls_tracer *tr)
     tb.cos_theta = tr->d_tables + tr->V;
     tb.sin_phi = tr->d_tables + 2 * (size_t)tr->V;
     tb.cos_phi = tr->d_tables + 2 * (size_t)tr->V + tr->H;
+    tb.cs_phi = reinterpret_cast<const float2 *>(tr->d_tables + 5 * (size_t)tr->V + 2 * (size_t)tr->H);
     tb.V = tr->V;
     tb.H = tr->H;
     tb.az0 = tr->az0;
@@ -176,10 +184,15 @@ ls::ProjectParams project_params(const ls_tracer *tr)
 {
     ls::ProjectParams pp;
     pp.tb = tables(tr);
-    pp.chan_sorted = tr->d_tables + 2 * (size_t)tr->V + 2 * (size_t)tr->H;
-    pp.chan_perm = reinterpret_cast<const uint32_t *>(pp.chan_sorted + tr->V);
+    pp.chan_tan_up = tr->d_tables + 2 * (size_t)tr->V + 2 * (size_t)tr->H;
+    pp.chan_tan_dn = pp.chan_tan_up + tr->V;
+    pp.chan_perm = reinterpret_cast<const uint32_t *>(pp.chan_tan_dn + tr->V);
     pp.begin_deg = tr->h_begin;
     pp.step_deg = (tr->h_end - tr->h_begin) / static_cast<float>(tr->H - 1u);  // LidarDevice.cpp:611
+    pp.inv_step_deg = pp.step_deg != 0.0f ? 1.0f / pp.step_deg : 0.0f;
+    pp.inv_period = std::fabs(pp.step_deg) / 360.0f;
+    pp.margin_deg = kProjectMarginDeg;
+    pp.debug = getenv("LS_PROJECT_DEBUG") ? atoi(getenv("LS_PROJECT_DEBUG")) : 0;
     return pp;
 }
 
@@ -193,8 +206,13 @@ int ensure_outputs(ls_tracer *tr)
     if ((rc = ensure(tr, tr->hit_gid, nr))) return rc;
     if ((rc = ensure(tr, tr->row_counts, nr / 64 + 4))) return rc;
     if (use_projection(tr)) {
+        const size_t cap0 = tr->best_keys.cap;
         if ((rc = ensure(tr, tr->best_keys, nr))) return rc;
-        if ((rc = ensure(tr, tr->proj_rows, (size_t)1 << 20))) return rc;
+        if (tr->best_keys.cap != cap0) tr->keys_armed = false;
+        if (!tr->big_queue.p) {
+            tr->big_capacity = 1u << 16;
+            if ((rc = ensure(tr, tr->big_queue, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
+        }
     } else {
         if ((rc = ensure(tr, tr->spill, ls::trace_spill_bytes(tr->trace_blocks) / 4))) return rc;
     }
@@ -238,7 +256,7 @@ void mark(ls_tracer *tr, int i)
 void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
 {
     const uint32_t V = tr->V, H = tr->H;
-    tab.resize(2 * (size_t)V + 2 * (size_t)H + 2 * (size_t)V);
+    tab.resize(2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V + 2 * (size_t)H);
     const float step = (tr->h_end - tr->h_begin) / static_cast<float>(H - 1u);  // LidarDevice.cpp:611
     for (uint32_t v = 0; v < V; ++v) {
         const float preChi = tr->vertical[v];
@@ -252,14 +270,25 @@ void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
         tab[2 * (size_t)V + h] = std::sin(phi);
         tab[2 * (size_t)V + H + h] = std::cos(phi);
     }
-    // projection engine: channel elevations (degrees above the horizon) ascending + permutation
+    // projection engine: channels by ascending elevation; tan(elevation +- margin), nudged outwards
     std::vector<uint32_t> perm(V);
     for (uint32_t v = 0; v < V; ++v) perm[v] = v;
     std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return tr->vertical[a] < tr->vertical[b]; });
-    float *sorted = tab.data() + 2 * (size_t)V + 2 * (size_t)H;
+    float *up = tab.data() + 2 * (size_t)V + 2 * (size_t)H, *dn = up + V;
     for (uint32_t i = 0; i < V; ++i) {
-        sorted[i] = tr->vertical[perm[i]];
-        std::memcpy(&sorted[V + i], &perm[i], 4);
+        const double chi = tr->vertical[perm[i]];
+        const double hi = chi + kProjectMarginDeg, lo = chi - kProjectMarginDeg;
+        float tu = hi >= 90.0 ? INFINITY : (hi <= -90.0 ? -INFINITY : static_cast<float>(std::tan(hi * M_PI / 180.0)));
+        float td = lo <= -90.0 ? -INFINITY : (lo >= 90.0 ? INFINITY : static_cast<float>(std::tan(lo * M_PI / 180.0)));
+        up[i] = std::nextafter(tu, INFINITY);
+        dn[i] = std::nextafter(td, -INFINITY);
+        std::memcpy(&dn[V + i], &perm[i], 4);
+    }
+    // (cos_phi, sin_phi) interleaved
+    float *cs = tab.data() + 2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V;
+    for (uint32_t h = 0; h < H; ++h) {
+        cs[2 * (size_t)h] = tab[2 * (size_t)V + H + h];
+        cs[2 * (size_t)h + 1] = tab[2 * (size_t)V + h];
     }
 }
 
@@ -347,10 +376,33 @@ void free_geometry(Geometry &g)
     g.d_idx = nullptr;
 }
 
+// (re)build the committed scene arrays (transformed vertices, rebased indices) on the device
+int materialize_scene(ls_tracer *tr, bool with_maxabs)
+{
+    int rc;
+    if ((rc = ensure(tr, tr->verts, (size_t)tr->n_verts * 3))) return rc;
+    if ((rc = ensure(tr, tr->tris, (size_t)tr->n_tris * 3))) return rc;
+    hipStream_t s = tr->stream;
+    if (with_maxabs) LS_HIP(hipMemsetAsync(tr->d_maxabs, 0, 4, s));
+    for (const auto &le : tr->layout) {
+        auto it = tr->geoms.find(le.name);
+        if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
+        Geometry &ge = it->second;
+        ls::launch_transform(s, ge.d_raw, ge.stride, ge.n_verts, ge.affine, tr->rinv, tr->t,
+                             tr->verts.p + 3 * (size_t)le.vfirst, tr->d_maxabs);
+        ls::launch_rebase(s, ge.d_idx, ge.n_tris * 3, le.vfirst, tr->tris.p + 3 * (size_t)le.tfirst);
+    }
+    LS_HIP(hipGetLastError());
+    tr->scene_materialized = true;
+    return LS_OK;
+}
+
 int commit_locked(ls_tracer *tr)
 {
     tr->committed = false;
     tr->traced = false;
+    tr->bvh_built = false;
+    tr->scene_materialized = false;
     // layout: geometries with data, in geomID order, so that the global triangle id orders
     // triangles by (geomID, primID) -- the tie-break key of equal-t hits.
     std::vector<Geometry *> order;
@@ -361,6 +413,7 @@ int commit_locked(ls_tracer *tr)
         tr->n_tris = tr->n_verts = tr->n_leaves = tr->n_slots = 0;
         tr->slot_geom_ids.clear();
         tr->slot_tri_first.assign(1, 0u);
+        tr->layout.clear();
         tr->layout_dirty = true;
         return -1;  // OptixTracer.cpp:266-267
     }
@@ -368,31 +421,22 @@ int commit_locked(ls_tracer *tr)
 
     std::vector<uint32_t> vfirst(order.size() + 1, 0u), tfirst(order.size() + 1, 0u);
     std::vector<int> ids(order.size());
+    tr->layout.clear();
     for (size_t k = 0; k < order.size(); ++k) {
         vfirst[k + 1] = vfirst[k] + order[k]->n_verts;
         tfirst[k + 1] = tfirst[k] + order[k]->n_tris;
         ids[k] = order[k]->id;
+        tr->layout.push_back({order[k]->name, vfirst[k], tfirst[k]});
     }
     const bool relayout = tr->layout_dirty || ids != tr->slot_geom_ids || tfirst != tr->slot_tri_first ||
                           tr->leaf_size != tr->committed_leaf_size;
     const uint32_t nv = vfirst.back(), nt = tfirst.back();
     const uint32_t g = tr->leaf_size;
     const uint32_t L = (nt + g - 1) / g;
+    tr->n_verts = nv;
+    tr->n_tris = nt;
 
     int rc;
-    if ((rc = ensure(tr, tr->verts, (size_t)nv * 3))) return rc;
-    if ((rc = ensure(tr, tr->tris, (size_t)nt * 3))) return rc;
-    const bool want_bvh = !use_projection(tr);
-    if (want_bvh) {
-        if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
-        if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
-        if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
-        if ((rc = ensure(tr, tr->vals_b, nt))) return rc;
-        if ((rc = ensure(tr, tr->records, (size_t)L * g))) return rc;
-        if ((rc = ensure(tr, tr->nodes, (size_t)L))) return rc;
-        if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
-    }
-
     if (relayout) {
         std::vector<uint32_t> table(tfirst);
         for (int id : ids) table.push_back((uint32_t)id);
@@ -414,36 +458,41 @@ int commit_locked(ls_tracer *tr)
         rt.levels = lev;
         tr->range_entries = off;
     }
-    if (want_bvh && (rc = ensure(tr, tr->range_boxes, 2 * (size_t)tr->range_entries + 2))) return rc;
 
     hipStream_t s = tr->stream;
+    const bool want_bvh = !use_projection(tr);
     mark(tr, 0);
-    LS_HIP(hipMemsetAsync(tr->d_maxabs, 0, 4, s));
-    for (size_t k = 0; k < order.size(); ++k) {
-        Geometry &ge = *order[k];
-        ls::launch_transform(s, ge.d_raw, ge.stride, ge.n_verts, ge.affine, tr->rinv, tr->t,
-                             tr->verts.p + 3 * (size_t)vfirst[k], tr->d_maxabs);
-        if (relayout || ge.idx_dirty) {
-            ls::launch_rebase(s, ge.d_idx, ge.n_tris * 3, vfirst[k], tr->tris.p + 3 * (size_t)tfirst[k]);
-            ge.idx_dirty = false;
-        }
+    if (want_bvh) {
+        // BVH engine: transform every geometry into the sensor frame, then a full LBVH rebuild
+        if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
+        if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
+        if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
+        if ((rc = ensure(tr, tr->vals_b, nt))) return rc;
+        if ((rc = ensure(tr, tr->records, (size_t)L * g))) return rc;
+        if ((rc = ensure(tr, tr->nodes, (size_t)L))) return rc;
+        if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
+        if ((rc = ensure(tr, tr->range_boxes, 2 * (size_t)tr->range_entries + 2))) return rc;
+        if ((rc = materialize_scene(tr, true))) return rc;
+        mark(tr, 1);
+        ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
+        mark(tr, 2);
+        ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
+        mark(tr, 3);
+        ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->range_boxes.p);
+        mark(tr, 4);
+        ls::launch_range_tree(s, tr->rt, tr->range_boxes.p);
+        mark(tr, 5);
+        ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
+        mark(tr, 6);
+        LS_HIP(hipGetLastError());
+        tr->bvh_built = true;
+    } else {
+        // projection engine: nothing to build -- the trace kernel streams the meshes as uploaded and
+        // applies the vertex transform on the fly
+        mark(tr, 1);
     }
-    mark(tr, 1);
-    if (want_bvh) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
-    mark(tr, 2);
-    if (want_bvh) ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
-    mark(tr, 3);
-    if (want_bvh) ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->range_boxes.p);
-    mark(tr, 4);
-    if (want_bvh) ls::launch_range_tree(s, tr->rt, tr->range_boxes.p);
-    mark(tr, 5);
-    if (want_bvh) ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
-    mark(tr, 6);
-    tr->bvh_built = want_bvh;
-    LS_HIP(hipGetLastError());
+    for (Geometry *ge : order) ge->idx_dirty = false;
 
-    tr->n_verts = nv;
-    tr->n_tris = nt;
     tr->n_leaves = L;
     tr->n_slots = L - 1;  // BVH2 nodes (64 B each)
     tr->committed_leaf_size = g;
@@ -477,14 +526,30 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         // sensor-space projection engine: stream the triangles once, test only the covered rays
         const ls::ProjectParams pp = project_params(tr);
         unsigned long long *stats = tr->opt_count ? tr->d_visits + 1 : nullptr;  // counts[1] = triangle tests
-        ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_proj_row_count);
+        if (!tr->keys_armed) {
+            ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count);
+            tr->keys_armed = true;
+        }
         mark(tr, 7);
-        ls::launch_project_tris(s, pp, tr->verts.p, tr->tris.p, tr->n_tris, tr->best_keys.p, tr->proj_rows.p,
-                                (uint32_t)tr->proj_rows.cap, tr->d_proj_row_count, stats);
+        for (const auto &le : tr->layout) {
+            auto it = tr->geoms.find(le.name);
+            if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
+            const Geometry &ge = it->second;
+            ls::GeomSource src;
+            src.verts = static_cast<const uint8_t *>(ge.d_raw);
+            src.stride = ge.stride;
+            src.idx = ge.d_idx;
+            src.ntris = ge.n_tris;
+            src.gid_first = le.tfirst;
+            src.xform = 1;
+            std::memcpy(src.m.a, ge.affine, sizeof(src.m.a));
+            std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
+            std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
+            ls::launch_project(s, pp, src, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, stats);
+        }
         mark(tr, 8);
-        ls::launch_project_rows(s, pp, tr->verts.p, tr->tris.p, tr->n_tris, tr->best_keys.p, tr->proj_rows.p,
-                                (uint32_t)tr->proj_rows.cap, tr->d_proj_row_count, 1024u, stats);
-        ls::launch_project_resolve(s, pp, tr->best_keys.p, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p);
+        ls::launch_project_big(s, pp, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, 128u, stats);
+        ls::launch_project_resolve(s, pp, tr->best_keys.p, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, tr->d_big_count);
     } else {
         if (!tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "the BVH engine was selected after the last commit");
         LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
@@ -578,7 +643,7 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_queue_heads), ls::kQueues * 16 * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
-    if (hipMalloc(reinterpret_cast<void **>(&tr->d_proj_row_count), 64) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_big_count), 64) != hipSuccess) return bail(LS_ERR_HIP);
     for (float chi : tr->vertical)
         if (!(chi >= -90.0f && chi <= 90.0f)) tr->projection_ok = false;  // elevation == channel angle only there
     if (!std::isfinite(tr->h_begin) || !std::isfinite(tr->h_end)) tr->projection_ok = false;
@@ -615,9 +680,9 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->d_visits) (void)hipFree(tr->d_visits);
     if (tr->d_n_points) (void)hipFree(tr->d_n_points);
     if (tr->d_queue_heads) (void)hipFree(tr->d_queue_heads);
-    if (tr->d_proj_row_count) (void)hipFree(tr->d_proj_row_count);
+    if (tr->d_big_count) (void)hipFree(tr->d_big_count);
     release(tr->best_keys);
-    release(tr->proj_rows);
+    release(tr->big_queue);
     release(tr->spill);
     if (tr->h_points) (void)hipHostFree(tr->h_points);
     if (tr->h_hits) (void)hipHostFree(tr->h_hits);
@@ -772,6 +837,7 @@ int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az)
     tr->az0 = first_az;
     tr->naz = n_az;
     tr->traced = false;
+    tr->keys_armed = false;
     return LS_OK;
 }
 
@@ -894,6 +960,7 @@ int ls_debug_trace_bruteforce(ls_tracer *tr, float *t, uint32_t *gid)
     LS_ENTER(tr);
     if (!t || !gid) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
     if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
+    if (!tr->scene_materialized) { const int rc = materialize_scene(tr, false); if (rc) return rc; }
     const uint32_t n = shard_rays(tr);
     float *dt = nullptr;
     uint32_t *dg = nullptr;
@@ -924,6 +991,7 @@ int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx)
 {
     LS_ENTER(tr);
     if (!tr->committed) return fail(tr, LS_ERR_NOT_COMMITTED, "scene not committed");
+    if (!tr->scene_materialized) { const int rc = materialize_scene(tr, false); if (rc) return rc; }
     LS_HIP(hipStreamSynchronize(tr->stream));
     if (verts_xyz) LS_HIP(hipMemcpy(verts_xyz, tr->verts.p, (size_t)tr->n_verts * 12, hipMemcpyDeviceToHost));
     if (tri_idx) LS_HIP(hipMemcpy(tri_idx, tr->tris.p, (size_t)tr->n_tris * 12, hipMemcpyDeviceToHost));
