@@ -166,8 +166,6 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1,2,4,8), default 1; takes effect at next commit  */
 #define LS_OPT_TIMING 2         /* 1: bracket every stage with hipEvents, 2: only the trace kernel        */
 #define LS_OPT_COUNT_VISITS 3   /* 1: trace kernel also counts node fetches / triangle tests              */
-#define LS_OPT_REFIT 4          /* 1: commit refits the BVH when the geometry set is unchanged
-                                 *    (OptixTracer.cpp:532-535 OPERATION_UPDATE); 0 (default): full rebuild */
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */

@@ -4,6 +4,6 @@ The product is the C-ABI shared library `liblidarshooter_hip.so` (sources in csr
 include/lidarshooter_hip.h) plus the C++ host mirror in host/.  The Python modules here are only
 the ctypes binding (`capi`) and synthetic workload generators (`synth`) used by tests and bench.
 """
-from . import capi, hostapi, synth  # noqa: F401
+from . import capi, hostapi, shards, synth  # noqa: F401
 
-__all__ = ["capi", "hostapi", "synth"]
+__all__ = ["capi", "hostapi", "shards", "synth"]

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblidarshooter_hip.so")
 INVALID = 0xFFFFFFFF
 
-LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_REFIT, LS_OPT_ENGINE = 1, 2, 3, 4, 5
+LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE = 1, 2, 3, 5
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
 STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "trace_aux", "pack")
 

@@ -109,7 +109,7 @@ struct ls_tracer {
 
     // options / measurement
     int opt_timing = 0;  // 0 off, 1 every stage, 2 only the trace kernel
-    bool opt_count = false, opt_refit = false;
+    bool opt_count = false;
     // hipEvent records: one TimingRecord per frame (commit marks 0..6, trace marks 7..9), kept until
     // ls_get_timings averages and recycles them, so that timing a run never synchronises inside it.
     struct TimingRecord {
@@ -887,7 +887,6 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         tr->trec_open = false;
         return LS_OK;
     case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
-    case LS_OPT_REFIT: tr->opt_refit = value != 0; return LS_OK;
     case LS_OPT_ENGINE:
         if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "engine must be 0 (auto), 1 (BVH) or 2 (projection)");
         if (value == 2 && !tr->projection_ok) return fail(tr, LS_ERR_INVALID_ARGUMENT, "projection engine needs channel angles within [-90, 90] degrees");

@@ -45,6 +45,5 @@ def syn_10m():
 
 def shard_columns(H: int, world: int, rank: int):
     """Contiguous azimuth sector of `rank` out of `world`: -> (first_az, n_az)."""
-    base, rem = divmod(H, world)
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
+    from .shards import shard_columns as _sc
+    return _sc(H, world, rank)

@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) gloo process groups run the same shard arithmetic,
+slot layout and single all-gather that bench.py runs over RCCL; the per-rank results come from the
+CPU oracle restricted to the rank's azimuth sector (no GPU here).  The gathered, decoded cloud
+must equal the oracle's full-frame cloud."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import DATA, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    from lidarshooter_amd import shards
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    s = O.load_sensor(os.path.join(DATA, "config", "hesai-pandar-XT-32-lidar_0000.json"))
+    ground = O.load_stl(os.path.join(DATA, "mesh", "ground.stl"))
+    ben = O.load_stl(os.path.join(DATA, "mesh", "ben.stl"))
+    ml = [(0, *ground, O.IDENTITY_AFFINE), (1, *ben, O.IDENTITY_AFFINE)]
+    full = O.trace_frame(s, ml)
+    # this rank's sector: keep the hits whose azimuth column is in [first, first+n)
+    first, n = shards.shard_columns(s.H, world, rank)
+    col = full["hits"][:, 0] % s.H
+    mine = (col >= first) & (col < first + n)
+    cap = shards.slot_capacity(s.V, s.H, world)
+    slot = np.zeros(shards.slot_bytes(cap), np.uint8)
+    shards.write_slot(slot, cap, full["points"][mine], full["hits"][mine])
+    t_slot = torch.from_numpy(slot)
+    gathered = torch.zeros(world * slot.shape[0], dtype=torch.uint8)
+    shards.all_gather_slots(t_slot, gathered)
+    pts, hts = shards.decode_gathered(gathered.numpy(), world, cap)
+    hits = hts.view(np.uint32).reshape(-1, 4)
+    order = np.argsort(hits[:, 0], kind="stable")
+    ok = np.array_equal(hits[order], full["hits"]) and np.array_equal(pts[order], full["points"])
+    # every rank must see the same gathered bytes
+    h = torch.tensor([int(np.frombuffer(gathered.numpy().tobytes()[:8], np.uint64)[0] % (1 << 62)), int(ok)])
+    hs = [torch.zeros_like(h) for _ in range(world)]
+    dist.all_gather(hs, h)
+    same = all(bool((x == hs[0]).all()) for x in hs)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+        fh.write(f"{int(ok)} {int(same)} {len(pts)}\n")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_equals_full_frame(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, same, n = open(tmp_path / f"rank{r}.txt").read().split()
+        assert ok == "1" and same == "1" and n == "1781"
+
+
+def test_shard_columns_partition():
+    from lidarshooter_amd import shards
+    for H in (150, 4096, 7):
+        for world in (1, 2, 3, 8):
+            cols = []
+            for r in range(world):
+                f, n = shards.shard_columns(H, world, r)
+                cols += list(range(f, f + n))
+            assert cols == list(range(H))
+    assert shards.slot_capacity(128, 4096, 8) == 128 * 512
+    assert shards.slot_bytes(10) == 64 + 480
