@@ -42,7 +42,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "xt32"])
+    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32"],
+                    help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size")
     ap.add_argument("--leaf", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
     ap.add_argument("--engine", default="auto", choices=["auto", "bvh", "projection"],
                     help="closest-hit engine (auto = the library default: sensor-space projection)")
@@ -63,8 +64,8 @@ def build_workload(name):
     d = dict(d)
     d["vertical"] = synth.syn_vertical(128)      # +15 .. -25 deg
     d["h_begin"], d["h_end"], d["h_count"] = np.float32(0.0), np.float32(360.0), 4096
-    v, t = synth.syn_1m()
-    return d, [("ground1m", v, t)]
+    v, t = synth.syn_10m() if name == "syn128x10m" else synth.syn_1m()
+    return d, [("ground", v, t)]
 
 
 def cpu_baseline(sensor, meshes, frames, total_rays):
@@ -229,21 +230,35 @@ def main():
     else:
         # k_project_tris: every triangle is streamed once (12 B indices + 36 B vertex gather) and every
         # hit folds 8 B into the per-ray key; the angle tables (V+H entries) stay in L1
-        kernel = "k_project_tris"
+        kernel = "k_project"
         b_launch = 48 * n_tris_total + 8 * n_hits
         units = {"triangles_per_launch": n_tris_total, "bytes_per_triangle": b_launch / max(1, n_tris_total),
                  "candidate_tests_per_launch": n_tri, "tests_per_triangle": n_tri / max(1, n_tris_total),
                  "rays_per_launch": shard_rays}
     achieved = b_launch / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+    # HBM bytes of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB);
+    # counters cannot be collected from inside this process, so the figure is the profiled one
+    traffic, traffic_src = None, None
+    prof = os.path.join(ROOT, "profiles", f"r01_{engine}_hbm.json")
+    if args.workload == "syn128x1m" and world == 1 and os.path.exists(prof):
+        try:
+            k = json.load(open(prof))["kernels"]
+            key = next((n for n in k if n.startswith(kernel) and "true" not in n), None)
+            if key:
+                traffic, traffic_src = k[key]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
+        except Exception:
+            pass
 
     out = {
-        "metric": "Mrays/s (full LiDAR frame: update + commit + trace + pack; 128ch x 4096az over 1M tris)"
-                  if args.workload == "syn128x1m" else "Mrays/s (XT-32 over ground+ben)",
+        "metric": {"syn128x1m": "Mrays/s (full LiDAR frame: update + commit + trace + pack; 128ch x 4096az over 1M tris)",
+                   "syn128x10m": "Mrays/s (full LiDAR frame; 128ch x 4096az over 10M tris)",
+                   "xt32": "Mrays/s (XT-32 over ground+ben)"}[args.workload],
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)"
-                   if args.workload == "syn128x1m" else "XT-32 lidar_0000 x ground.stl+ben.stl",
+        "config": {"workload": {"syn128x1m": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)",
+                                "syn128x10m": "SYN-128 x SYN-10M (9,998,244 tris)",
+                                "xt32": "XT-32 lidar_0000 x ground.stl+ben.stl"}[args.workload],
                    "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,
                    "frame": "updateGeometry(device) + commitScene + traceScene"
                             + (" (full BVH rebuild every frame)" if engine == "bvh" else ""),
@@ -253,7 +268,7 @@ def main():
         "hits_per_frame_rank0": n_hits,
         "roofline": dict({
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": trace_ms, "kernel_launches_timed": tm["frames"],
             "kernel_timing": "hipEvents on the tracer's stream around the kernel, in a second pass of the same K frames",
             "algorithmic_bytes_per_launch": b_launch}, **units),

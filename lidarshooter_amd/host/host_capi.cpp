@@ -6,6 +6,7 @@
 #include <string>
 
 #include "HipTracer.hpp"
+#include "Trajectory.hpp"
 
 using namespace lidarshooter;
 
@@ -141,5 +142,18 @@ const void* lsh_tracer_hits(lsh_tracer* t, unsigned* n)
     return t->p->getHits();
 }
 void* lsh_tracer_handle(lsh_tracer* t) { return t->p->handle(); }
+
+// Trajectory player: writes up to `cap` poses (6 floats each: linear xyz, angular xyz); returns the count
+int lsh_trajectory_play(const char* path, float period, float* out6, int cap)
+{
+    try {
+        const auto poses = Trajectory::load(path).play(period);
+        const int n = static_cast<int>(poses.size());
+        for (int i = 0; i < n && i < cap; ++i) {
+            for (int k = 0; k < 3; ++k) { out6[6 * i + k] = poses[i].linear[k]; out6[6 * i + 3 + k] = poses[i].angular[k]; }
+        }
+        return n;
+    } catch (const std::exception& e) { g_err = e.what(); return -100; }
+}
 
 }  // extern "C"

@@ -71,6 +71,7 @@ def load() -> C.CDLL:
     L.lsh_tracer_hits.restype = vp
     L.lsh_tracer_handle.argtypes = [vp]
     L.lsh_tracer_handle.restype = vp
+    L.lsh_trajectory_play.argtypes = [C.c_char_p, C.c_float, f32p, C.c_int]
     _lib = L
     return L
 
@@ -254,3 +255,15 @@ class HipTracer:
         if not n.value:
             return np.zeros(0, capi.HIT_DTYPE)
         return np.frombuffer(C.string_at(p, n.value * 16), capi.HIT_DTYPE).copy()
+
+
+def trajectory_play(path: str, period: float = 0.1) -> np.ndarray:
+    """lidarshooter::Trajectory::play (host/Trajectory.hpp): -> float32[n, 6] = (linear xyz, angular xyz)
+    after each twist message, per the reference's AffineMesh::joystickCallback rule."""
+    L = load()
+    n = L.lsh_trajectory_play(path.encode(), period, None, 0)
+    if n < 0:
+        raise capi.LidarShooterHipError(L.lsh_last_error().decode())
+    out = np.zeros((n, 6), np.float32)
+    L.lsh_trajectory_play(path.encode(), period, _f32p(out), n)
+    return out

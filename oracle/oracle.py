@@ -243,6 +243,27 @@ def affine_from_components(lin, ang) -> np.ndarray:
 IDENTITY_AFFINE = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
 
 
+def play_trajectory(path: str, period: float = 0.1) -> np.ndarray:
+    """config/trajectory.json through AffineMesh::joystickCallback (AffineMesh.cpp:107-128, :275-284):
+    lin += (Rz*Ry*Rx)(ang) * twist.linear; ang += twist.angular, one message per `period` seconds,
+    round(dt/period) messages per segment.  -> float32[n,6] poses (linear, angular)."""
+    with open(path, "r") as fh:
+        j = json.loads(strip_json_comments(fh.read()))
+    lin = np.zeros(3, np.float32)
+    ang = np.zeros(3, np.float32)
+    out = []
+    for seg in j["trajectory"]:
+        tl = np.array([np.float32(x) for x in seg["linear"]], np.float32)
+        ta = np.array([np.float32(x) for x in seg["angular"]], np.float32)
+        for _ in range(int(round(float(np.float32(seg["dt"])) / period))):
+            R = affine_from_components(np.zeros(3, np.float32), ang).reshape(3, 4)[:, :3]
+            g = np.float32(np.float32(np.float32(R[:, 0] * tl[0]) + np.float32(R[:, 1] * tl[1])) + np.float32(R[:, 2] * tl[2]))
+            lin = (lin + g).astype(np.float32)
+            ang = (ang + ta).astype(np.float32)
+            out.append(np.concatenate([lin, ang]))
+    return np.array(out, np.float32).reshape(-1, 6)
+
+
 def transform_vertices(verts: np.ndarray, affine: np.ndarray, sensor: Sensor, stride: int | None = None):
     verts = np.ascontiguousarray(verts)
     if stride is None:

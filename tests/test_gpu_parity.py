@@ -444,3 +444,58 @@ def test_host_mirror_hiptracer(oracle, sensors, meshes):
     assert tr.commitScene() == -1 and tr.traceScene(2) == -1
     assert tr.getTraceCloud()["width"] == 0 and tr.getGeometryCount() == 0
     tr.close()
+
+
+def test_trajectory_animated_frames(oracle, capi, sensors, meshes, engine):
+    """BASELINE.json configs[4]'s moving instance: ben driven by config/trajectory.json through the
+    reference's pose rule (AffineMesh.cpp:107-128), one updateGeometry(name, translation, rotation,
+    mesh) + commit + trace per frame (MeshProjector.cpp:446-464); every frame equals the oracle."""
+    from conftest import DATA
+    s = sensors["0001"]
+    poses = oracle.play_trajectory(os.path.join(DATA, "config", "trajectory.json"), 0.1)
+    tr = make_tracer(capi, s, engine)
+    _add(tr, "ground", meshes["ground"])
+    _add(tr, "face", meshes["ben"])
+    seen = set()
+    for frame in (0, 1, 2, 3, 5, 8, 13, 40, 99, 100, 149):
+        lin, ang = poses[frame, :3] * np.float32(0.05), poses[frame, 3:]     # keep ben inside the scene
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+        tr.updateGeometryComponents("face", lin, ang, *meshes["ben"])
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(frame)
+        A = oracle.affine_from_components(lin, ang)
+        _assert_parity(oracle, s, tr, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)], pts, hits)
+        seen.add(len(pts))
+    assert len(seen) > 3                                   # the cloud really changes from frame to frame
+    tr.close()
+
+
+def test_syn_10m_engines_agree(capi, oracle, sensors):
+    """BASELINE.json configs[4] scene size: 9 998 244 triangles.  Both engines agree on every ray of
+    the 128 x 4096 sensor; a 64-column sector is checked against the exhaustive GPU kernel."""
+    from lidarshooter_amd import synth
+    v, t = synth.syn_10m()
+    assert t.shape[0] == 9998244
+    s = _syn_sensor(oracle, sensors, V=128, H=4096)
+    out = {}
+    for eng in ("projection", "bvh"):
+        tr = make_tracer(capi, s, eng)
+        tr.addGeometry("g", v.shape[0], t.shape[0])
+        tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(0)
+        assert rc == 0
+        out[eng] = (tr.denseHits(), pts, hits)
+        if eng == "projection":
+            tr.setShard(2040, 64)
+            tr.commitScene()
+            tr.traceScene(1)
+            st, sg = tr.denseHits()
+            bt, bg = tr.bruteForce()
+            assert np.array_equal(sg, bg) and np.array_equal(st, bt)
+        tr.close()
+    (tp, gp), pp, hp = out["projection"]
+    (tb, gb), pb, hb = out["bvh"]
+    assert np.array_equal(gp, gb) and np.array_equal(tp, tb)
+    assert np.array_equal(pp, pb) and np.array_equal(hp, hb)
+    assert 200000 < len(pp) < 300000

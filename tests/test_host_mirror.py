@@ -68,3 +68,14 @@ def test_stl_ingest(hostapi, meshes, name, nv, nt):
     assert m.numPoints() == nv and m.numPolygons() == nt and m.pointStep() == 16
     assert np.array_equal(m.points(), meshes[name][0])
     assert np.array_equal(m.polygons(), meshes[name][1])
+
+
+def test_trajectory_player(hostapi, oracle):
+    # config/trajectory.json: 10 s of (0,5,0)/(0,0,1) then 5 s of (1,0,0)/(0,0,-1), 10 Hz messages
+    path = os.path.join(DATA, "config", "trajectory.json")
+    poses = hostapi.trajectory_play(path, 0.1)
+    ref = oracle.play_trajectory(path, 0.1)
+    assert poses.shape == (150, 6)
+    assert np.array_equal(poses, ref)
+    assert np.allclose(poses[0], [0, 5, 0, 0, 0, 1])            # first message: no rotation yet
+    assert np.allclose(poses[99, 3:], [0, 0, 100]) and np.allclose(poses[-1, 3:], [0, 0, 50])
