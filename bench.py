@@ -151,9 +151,12 @@ def main():
     tr.setOutputBuffers(base + o_pts, base + o_hits, base + o_n, cap)
     ident = capi.IDENTITY_AFFINE
 
-    def frame(i):
-        for name, dv, dt in d_meshes:                      # MeshProjector.cpp:448-461
-            tr.updateGeometryDevice(name, ident, dv.data_ptr(), 12, dt.data_ptr())
+    def frame(i, copy=False):
+        for name, dv, dt in d_meshes:                      # MeshProjector.cpp:448-461: every mesh, every frame
+            if copy:   # defensive D2D copy of the mesh into library-owned buffers (18 MB per frame at 1M triangles)
+                tr.updateGeometryDevice(name, ident, dv.data_ptr(), 12, dt.data_ptr())
+            else:      # the mesh is read in place from the caller's HBM buffers (vertex transform fused into the trace)
+                tr.updateGeometryDeviceShared(name, ident, dv.data_ptr(), 12, dt.data_ptr())
         tr.commitScene()
         tr.traceSceneAsync(i)
         if world > 1:
@@ -215,6 +218,14 @@ def main():
             tr.traceSceneAsync(i)
         sync()
         trace_only_s = (time.perf_counter() - t1) / args.steps
+        # the same frame with the mesh copied into library-owned buffers on every update
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            frame(i, copy=True)
+        sync()
+        copy_frame_s = (time.perf_counter() - t1) / args.steps
+        frame(0)
+        sync()
 
     total_rays = V * H
     ms_per_step = elapsed / args.steps * 1e3
@@ -260,7 +271,7 @@ def main():
                                 "syn128x10m": "SYN-128 x SYN-10M (9,998,244 tris)",
                                 "xt32": "XT-32 lidar_0000 x ground.stl+ben.stl"}[args.workload],
                    "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,
-                   "frame": "updateGeometry(device) + commitScene + traceScene"
+                   "frame": "updateGeometry(device, in place) + commitScene + traceScene"
                             + (" (full BVH rebuild every frame)" if engine == "bvh" else ""),
                    "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, all-gather of hit slots"
                    if world > 1 else "single GPU"},
@@ -275,6 +286,7 @@ def main():
     }
     if breakdown is not None:
         out["stage_ms"] = {k: round(v, 5) for k, v in breakdown.items() if k != "frames"}
+        out["copy_update_ms_per_step"] = copy_frame_s * 1e3
         out["trace_only_ms"] = trace_only_s * 1e3
         out["trace_only_mrays_per_s"] = shard_rays / trace_only_s / 1e6
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -115,6 +115,14 @@ int ls_update_geometry_components(ls_tracer *tr, const char *name, const float l
 int ls_update_geometry_device(ls_tracer *tr, const char *name, const float affine3x4[12], const void *d_verts,
                               uint32_t vert_stride, const uint32_t *d_tri_idx);
 
+/* Zero-copy variant: the library keeps the two device pointers and READS THE CALLER'S BUFFERS IN PLACE
+ * during the following commitScene / traceScene calls (the vertex transform is fused into the trace
+ * kernel, so nothing needs to be staged).  The caller must leave the buffers unchanged and alive until
+ * that traceScene has completed on the handle's stream, or until the next update of this geometry.
+ * d_tri_idx = NULL keeps the previously shared / copied indices. */
+int ls_update_geometry_device_shared(ls_tracer *tr, const char *name, const float affine3x4[12], const void *d_verts,
+                                     uint32_t vert_stride, const uint32_t *d_tri_idx);
+
 /* Only the rigid transform of an already uploaded mesh changes (AffineMesh pose integration,
  * AffineMesh.cpp:108-128): no vertex traffic at all. */
 int ls_update_geometry_transform(ls_tracer *tr, const char *name, const float affine3x4[12]);

@@ -24,7 +24,7 @@ STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "t
 SYMBOLS = (
     "ls_abi_version", "ls_tracer_create", "ls_tracer_destroy", "ls_add_geometry", "ls_remove_geometry",
     "ls_update_geometry", "ls_update_geometry_components", "ls_update_geometry_device",
-    "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
+    "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
     "ls_tracer_synchronize", "ls_tracer_set_output_buffers", "ls_tracer_set_option", "ls_get_timings",
@@ -87,6 +87,7 @@ def load() -> C.CDLL:
     L.ls_update_geometry.argtypes = [vp, C.c_char_p, f32p, vp, u32, vp]
     L.ls_update_geometry_components.argtypes = [vp, C.c_char_p, f32p, f32p, vp, u32, vp]
     L.ls_update_geometry_device.argtypes = [vp, C.c_char_p, f32p, vp, u32, vp]
+    L.ls_update_geometry_device_shared.argtypes = [vp, C.c_char_p, f32p, vp, u32, vp]
     L.ls_update_geometry_transform.argtypes = [vp, C.c_char_p, f32p]
     L.ls_commit_scene.argtypes = [vp]
     L.ls_trace_scene.argtypes = [vp, u32, C.POINTER(Frame)]
@@ -204,6 +205,11 @@ class Tracer:
         A = np.ascontiguousarray(affine, np.float32).reshape(12)
         return self._check(self.L.ls_update_geometry_device(self.h, name.encode(), _f32p(A), d_verts, stride, d_tris),
                            "ls_update_geometry_device")
+
+    def updateGeometryDeviceShared(self, name: str, affine, d_verts: int, stride: int, d_tris: int | None):
+        A = np.ascontiguousarray(affine, np.float32).reshape(12)
+        return self._check(self.L.ls_update_geometry_device_shared(self.h, name.encode(), _f32p(A), d_verts, stride, d_tris),
+                           "ls_update_geometry_device_shared")
 
     def updateGeometryTransform(self, name: str, affine):
         A = np.ascontiguousarray(affine, np.float32).reshape(12)

@@ -121,19 +121,23 @@ void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, c
                   uint32_t ntris, float *t_out, uint32_t *gid_out, uint32_t *spill,
                   unsigned long long *visit_counts /* nullptr = do not count */);
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts);
-void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
-                 const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits,
-                 uint32_t *n_points);
+void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,
+                 const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points);
+// projection engine: pack straight from the closest-hit keys (also re-arms keys, counters, queue)
+void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
+                      const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
+                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points);
 // projection engine: per-geometry streaming kernel, big-footprint kernel, resolve (+ row counts)
 size_t project_big_item_bytes();
-void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count);
-void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
-                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats);
-void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
-                        uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
+void launch_count_keys(hipStream_t s, const unsigned long long *best, uint32_t n, uint32_t *block_counts);
+void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,
+                         uint32_t *block_counts2 /* two frame-parity arrays of ceil(rays/256) words */);
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best,
+                    uint32_t *block_counts, void *big, uint32_t big_capacity, uint32_t *big_count,
+                    unsigned long long *stats);
+void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *block_counts,
+                        const void *big, uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
                         unsigned long long *stats);
-void launch_project_resolve(hipStream_t s, const ProjectParams &pp, unsigned long long *best, float *t_out,
-                            uint32_t *gid_out, uint32_t *row_counts, uint32_t *big_count);
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz);
 void launch_bruteforce(hipStream_t s, const SensorTables &tb, const float *verts, const uint32_t *tris,
                        uint32_t ntris, float *t_out, uint32_t *gid_out);

@@ -456,10 +456,15 @@ __global__ __launch_bounds__(kBlock) void k_rowcount(const uint32_t *__restrict_
 // PointCloud2 record and the 16-byte ls_hit, both in ray-index order.
 // Bytes per hit: 8 (t,gid) + 48 written.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *__restrict__ t_in,
-                                                 const uint32_t *__restrict__ gid_in,
-                                                 const uint32_t *__restrict__ block_counts, GeomTable gt,
-                                                 float4 *__restrict__ points, uint4 *__restrict__ hits,
+// FROM_KEYS (projection engine): the per-ray results are the 64-bit closest-hit keys; the kernel also
+// writes the dense t / gid arrays, re-arms the keys, zeroes the OTHER frame-parity's block counters
+// and the big-triangle queue length, so that a frame needs no memset and no resolve pass.
+template <bool FROM_KEYS>
+__global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restrict__ t_io, uint32_t *__restrict__ gid_io,
+                                                 unsigned long long *__restrict__ keys,
+                                                 const uint32_t *__restrict__ block_counts,
+                                                 uint32_t *__restrict__ next_block_counts, uint32_t *__restrict__ big_count,
+                                                 GeomTable gt, float4 *__restrict__ points, uint4 *__restrict__ hits,
                                                  uint32_t *__restrict__ n_points)
 {
     __shared__ uint32_t s_part[kBlock / 64];
@@ -473,7 +478,24 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *_
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
 
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t gid = q < nq ? gid_in[q] : kInvalid;
+    uint32_t gid = kInvalid;
+    float t = -1.0f;
+    if (q < nq) {
+        if (FROM_KEYS) {
+            const unsigned long long key = keys[q];
+            keys[q] = ~0ull;
+            if (key != ~0ull) { gid = (uint32_t)key; t = __uint_as_float((uint32_t)(key >> 32)); }
+            t_io[q] = t;
+            gid_io[q] = gid;
+        } else {
+            gid = gid_io[q];
+            t = t_io[q];
+        }
+    }
+    if (FROM_KEYS) {
+        if (threadIdx.x == 0) next_block_counts[blockIdx.x] = 0u;
+        if (q == 0) *big_count = 0u;
+    }
     const bool hit = gid != kInvalid;
     const unsigned long long m = __ballot(hit);
     if (lane == 0) { s_part[w] = acc; s_wave[w] = (uint32_t)__popcll(m); }
@@ -486,7 +508,6 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, const float *_
     const uint32_t dst = base + rank;
 
     const uint32_t v = q / tb.naz, h = tb.az0 + (q - v * tb.naz);
-    const float t = t_in[q];
     const float st = tb.sin_theta[v];
     const float2 cs = tb.cs_phi[h];
     // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
@@ -678,13 +699,26 @@ void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_
     hipLaunchKernelGGL(k_rowcount, dim3(blocks_for(nrays)), dim3(kBlock), 0, s, gid, nrays, row_counts);
 }
 
-void launch_pack(hipStream_t s, const SensorTables &tb, const float *t, const uint32_t *gid,
-                 const uint32_t *row_counts, const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
+void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,
+                 const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
 {
     const uint32_t nq = tb.V * tb.naz;
     if (!nq) return;
-    hipLaunchKernelGGL(k_pack, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, row_counts, gt,
-                       reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);
+    hipLaunchKernelGGL(k_pack<false>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid,
+                       static_cast<unsigned long long *>(nullptr), block_counts, static_cast<uint32_t *>(nullptr),
+                       static_cast<uint32_t *>(nullptr), gt, reinterpret_cast<float4 *>(points32),
+                       reinterpret_cast<uint4 *>(hits), n_points);
+}
+
+void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
+                      const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
+                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
+{
+    const uint32_t nq = tb.V * tb.naz;
+    if (!nq) return;
+    hipLaunchKernelGGL(k_pack<true>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts,
+                       next_block_counts, big_count, gt, reinterpret_cast<float4 *>(points32),
+                       reinterpret_cast<uint4 *>(hits), n_points);
 }
 
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz)

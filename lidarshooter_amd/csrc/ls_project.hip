@@ -179,7 +179,8 @@ __device__ __forceinline__ void foot_cell(const ChanTables &ct, uint32_t i0, uin
 
 // exact test of ray (v, h) against the triangle; fold a hit into the ray's closest-hit key
 __device__ __forceinline__ void test_cell(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 e1, V3 e2, float NgC,
-                                          uint32_t gid, uint32_t v, uint32_t h, unsigned long long *__restrict__ best)
+                                          uint32_t gid, uint32_t v, uint32_t h, unsigned long long *__restrict__ best,
+                                          uint32_t *__restrict__ block_counts)
 {
     // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
     const float st = ct.sin_theta[v];
@@ -188,6 +189,7 @@ __device__ __forceinline__ void test_cell(const ProjectParams &pp, const ChanTab
     float t;
     if (tri_test(d, v0, e1, e2, NgC, t)) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | gid;  // t > 0: bits order like t
+        // no-return atomic: nothing in the loop waits for it (a returning one costs a round trip per iteration)
         atomicMin(&best[(size_t)v * pp.tb.naz + (h - pp.tb.az0)], key);
     }
 }
@@ -206,7 +208,8 @@ static_assert(sizeof(BigItem) == 80, "BigItem must be 80 bytes");
 // ------------------------------------------------------------------------------------------
 template <bool COUNT, bool LDS_TABLES>
 __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource src,
-                                                    unsigned long long *__restrict__ best, BigItem *__restrict__ big,
+                                                    unsigned long long *__restrict__ best,
+                                                    uint32_t *__restrict__ block_counts, BigItem *__restrict__ big,
                                                     uint32_t big_capacity, uint32_t *__restrict__ big_count,
                                                     unsigned long long *__restrict__ stats)
 {
@@ -299,7 +302,8 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource
         uint32_t v, h;
         foot_cell(ct, s_meta[w][1][lo], s_meta[w][2][lo], s_meta[w][3][lo], s_meta[w][4][lo], s_meta[w][5][lo], m, v, h);
         test_cell(pp, ct, {s_tri[w][0][lo], s_tri[w][1][lo], s_tri[w][2][lo]}, {s_tri[w][3][lo], s_tri[w][4][lo], s_tri[w][5][lo]},
-                  {s_tri[w][6][lo], s_tri[w][7][lo], s_tri[w][8][lo]}, s_tri[w][9][lo], s_meta[w][0][lo], v, h, best);
+                  {s_tri[w][6][lo], s_tri[w][7][lo], s_tri[w][8][lo]}, s_tri[w][9][lo], s_meta[w][0][lo], v, h, best,
+                  block_counts);
     }
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
 }
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource
 // Triangles with very large footprints: the whole grid strides over the cells of each queued item.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_project_big(ProjectParams pp, unsigned long long *__restrict__ best,
+                                                        uint32_t *__restrict__ block_counts,
                                                         const BigItem *__restrict__ big, uint32_t big_capacity,
                                                         const uint32_t *__restrict__ big_count,
                                                         unsigned long long *__restrict__ stats)
@@ -321,84 +326,73 @@ __global__ __launch_bounds__(kBlock) void k_project_big(ProjectParams pp, unsign
             uint32_t v, h;
             foot_cell(ct, it.i0, it.h0a, it.na, it.h0b, it.nb, m, v, h);
             test_cell(pp, ct, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
-                      it.NgC, it.gid, v, h, best);
+                      it.NgC, it.gid, v, h, best, block_counts);
         }
         if (COUNT && tid == 0) atomicAdd(&stats[0], (unsigned long long)cells);
     }
 }
 
-// Per-ray closest-hit key -> dense t / gid arrays + hits per 256-ray block (feeds the ordered pack).
-// Also re-arms the keys and the big-triangle queue for the next frame, so a frame needs no memset.
-__global__ __launch_bounds__(kBlock) void k_project_resolve(unsigned long long *__restrict__ best, uint32_t n,
-                                                            float *__restrict__ t_out, uint32_t *__restrict__ gid_out,
-                                                            uint32_t *__restrict__ row_counts,
-                                                            uint32_t *__restrict__ big_count)
+// hits per 256-ray block straight from the keys (feeds the ordered pack)
+__global__ __launch_bounds__(kBlock) void k_count_keys(const unsigned long long *__restrict__ best, uint32_t n,
+                                                       uint32_t *__restrict__ block_counts)
 {
     __shared__ uint32_t s_cnt[kBlock / 64];
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
-    bool hit = false;
-    if (q < n) {
-        const unsigned long long key = best[q];
-        best[q] = ~0ull;
-        hit = key != ~0ull;
-        t_out[q] = hit ? __uint_as_float((uint32_t)(key >> 32)) : -1.0f;
-        gid_out[q] = hit ? (uint32_t)key : kInvalid;
-    }
+    const bool hit = q < n && best[q] != ~0ull;
     const unsigned long long m = __ballot(hit);
     if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) row_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];  // per 256-ray block
-    if (q == 0) *big_count = 0u;
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 }  // namespace
 
+void launch_count_keys(hipStream_t s, const unsigned long long *best, uint32_t n, uint32_t *block_counts)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_count_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, best, n, block_counts);
+}
+
 size_t project_big_item_bytes() { return sizeof(BigItem); }
 
-void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count)
+void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,
+                         uint32_t *block_counts2)
 {
     const uint32_t nq = pp.tb.V * pp.tb.naz;
     if (!nq) return;
     (void)hipMemsetAsync(best, 0xFF, (size_t)nq * sizeof(unsigned long long), s);
     (void)hipMemsetAsync(big_count, 0, sizeof(uint32_t), s);
+    (void)hipMemsetAsync(block_counts2, 0, 2 * (size_t)((nq + kBlock - 1) / kBlock) * sizeof(uint32_t), s);
 }
 
-void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
-                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats)
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best,
+                    uint32_t *block_counts, void *big, uint32_t big_capacity, uint32_t *big_count,
+                    unsigned long long *stats)
 {
     if (!src.ntris || !(pp.tb.V * pp.tb.naz)) return;
     const dim3 grid((src.ntris + kBlock - 1) / kBlock);
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
     if (pp.tb.V <= 2048u) {  // channel tables fit in LDS (40 KB at most)
-        if (stats) hipLaunchKernelGGL((k_project<true, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
-        else hipLaunchKernelGGL((k_project<false, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
+        if (stats) hipLaunchKernelGGL((k_project<true, true>), grid, dim3(kBlock), lds, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
+        else hipLaunchKernelGGL((k_project<false, true>), grid, dim3(kBlock), lds, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
     } else {
-        if (stats) hipLaunchKernelGGL((k_project<true, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
-        else hipLaunchKernelGGL((k_project<false, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
+        if (stats) hipLaunchKernelGGL((k_project<true, false>), grid, dim3(kBlock), 0, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
+        else hipLaunchKernelGGL((k_project<false, false>), grid, dim3(kBlock), 0, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
     }
 }
 
-void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
-                        uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
+void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *block_counts,
+                        const void *big, uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
                         unsigned long long *stats)
 {
     if (!(pp.tb.V * pp.tb.naz)) return;
     if (stats)
-        hipLaunchKernelGGL(k_project_big<true>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best,
+        hipLaunchKernelGGL(k_project_big<true>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best, block_counts,
                            static_cast<const BigItem *>(big), big_capacity, big_count, stats);
     else
-        hipLaunchKernelGGL(k_project_big<false>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best,
+        hipLaunchKernelGGL(k_project_big<false>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best, block_counts,
                            static_cast<const BigItem *>(big), big_capacity, big_count, stats);
-}
-
-void launch_project_resolve(hipStream_t s, const ProjectParams &pp, unsigned long long *best, float *t_out,
-                            uint32_t *gid_out, uint32_t *row_counts, uint32_t *big_count)
-{
-    const uint32_t nq = pp.tb.V * pp.tb.naz;
-    if (!nq) return;
-    hipLaunchKernelGGL(k_project_resolve, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, s, best, nq, t_out, gid_out,
-                       row_counts, big_count);
 }
 
 }  // namespace ls

@@ -31,7 +31,11 @@ struct Geometry {
     size_t raw_cap = 0;
     uint32_t stride = 0;
     uint32_t *d_idx = nullptr;  // 3*n_tris mesh-local vertex indices
+    const void *shared_raw = nullptr;       // ls_update_geometry_device_shared: caller-owned device buffers
+    const uint32_t *shared_idx = nullptr;   // read in place by the kernels, never copied or freed
     bool has_verts = false, has_idx = false, idx_dirty = true;
+    const void *raw() const { return shared_raw ? shared_raw : d_raw; }
+    const uint32_t *idx() const { return shared_idx ? shared_idx : d_idx; }
     float affine[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 };
 
@@ -77,7 +81,8 @@ struct ls_tracer {
     DevBuf<uint8_t> big_queue;             // projection engine: triangles with very large footprints
     uint32_t big_capacity = 0;
     uint32_t *d_big_count = nullptr;
-    bool keys_armed = false;               // best_keys all ~0 and big_count 0 (k_project_resolve re-arms them)
+    bool keys_armed = false;               // best_keys all ~0, counters 0 (k_pack re-arms them every frame)
+    uint32_t frame_parity = 0;             // which of the two block-counter arrays this frame adds into
     bool scene_materialized = false;       // verts / tris hold the transformed scene of the last commit
     struct LayoutEntry { std::string name; uint32_t vfirst, tfirst; };
     std::vector<LayoutEntry> layout;
@@ -204,7 +209,11 @@ int ensure_outputs(ls_tracer *tr)
     int rc;
     if ((rc = ensure(tr, tr->hit_t, nr))) return rc;
     if ((rc = ensure(tr, tr->hit_gid, nr))) return rc;
-    if ((rc = ensure(tr, tr->row_counts, nr / 64 + 4))) return rc;
+    {
+        const size_t c0 = tr->row_counts.cap;
+        if ((rc = ensure(tr, tr->row_counts, 2 * ((nr + 255) / 256) + 8))) return rc;  // two frame-parity arrays
+        if (tr->row_counts.cap != c0) tr->keys_armed = false;
+    }
     if (use_projection(tr)) {
         const size_t cap0 = tr->best_keys.cap;
         if ((rc = ensure(tr, tr->best_keys, nr))) return rc;
@@ -333,14 +342,24 @@ void affine_from_components(const float *lin, const float *ang, float *A)
 }
 
 int update_common(ls_tracer *tr, const char *name, const float *affine, const void *verts, uint32_t stride,
-                  const uint32_t *idx, hipMemcpyKind kind)
+                  const uint32_t *idx, hipMemcpyKind kind, bool shared = false)
 {
     if (!name || !affine) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
     auto it = tr->geoms.find(name);
     if (it == tr->geoms.end()) return fail(tr, LS_ERR_UNKNOWN_GEOMETRY, "geometry key does not exist");
     Geometry &g = it->second;
     std::memcpy(g.affine, affine, sizeof(g.affine));
+    if (shared) {
+        if (stride < 12 || (stride & 3u)) return fail(tr, LS_ERR_INVALID_ARGUMENT, "vertex stride must be >= 12 and a multiple of 4");
+        if (!g.has_verts || (idx && !g.has_idx)) tr->layout_dirty = true;
+        g.shared_raw = verts;
+        g.stride = stride;
+        g.has_verts = true;
+        if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; }
+        return LS_OK;
+    }
     if (verts) {
+        g.shared_raw = nullptr;
         if (stride < 12 || (stride & 3u)) return fail(tr, LS_ERR_INVALID_ARGUMENT, "vertex stride must be >= 12 and a multiple of 4");
         const size_t bytes = (size_t)g.n_verts * stride;
         if (bytes > g.raw_cap) {
@@ -356,6 +375,7 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         g.has_verts = true;
     }
     if (idx) {
+        g.shared_idx = nullptr;
         const size_t bytes = (size_t)g.n_tris * 12;
         if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), bytes ? bytes : 4));
         if (bytes) LS_HIP(hipMemcpyAsync(g.d_idx, idx, bytes, kind, tr->stream));
@@ -388,9 +408,9 @@ int materialize_scene(ls_tracer *tr, bool with_maxabs)
         auto it = tr->geoms.find(le.name);
         if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
         Geometry &ge = it->second;
-        ls::launch_transform(s, ge.d_raw, ge.stride, ge.n_verts, ge.affine, tr->rinv, tr->t,
+        ls::launch_transform(s, ge.raw(), ge.stride, ge.n_verts, ge.affine, tr->rinv, tr->t,
                              tr->verts.p + 3 * (size_t)le.vfirst, tr->d_maxabs);
-        ls::launch_rebase(s, ge.d_idx, ge.n_tris * 3, le.vfirst, tr->tris.p + 3 * (size_t)le.tfirst);
+        ls::launch_rebase(s, ge.idx(), ge.n_tris * 3, le.vfirst, tr->tris.p + 3 * (size_t)le.tfirst);
     }
     LS_HIP(hipGetLastError());
     tr->scene_materialized = true;
@@ -526,30 +546,43 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         // sensor-space projection engine: stream the triangles once, test only the covered rays
         const ls::ProjectParams pp = project_params(tr);
         unsigned long long *stats = tr->opt_count ? tr->d_visits + 1 : nullptr;  // counts[1] = triangle tests
+        const uint32_t n_blocks = (shard_rays(tr) + 255u) / 256u;
         if (!tr->keys_armed) {
-            ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count);
+            ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count, tr->row_counts.p);
             tr->keys_armed = true;
+            tr->frame_parity = 0;
         }
+        uint32_t *counts = tr->row_counts.p + (size_t)tr->frame_parity * n_blocks;
+        uint32_t *next_counts = tr->row_counts.p + (size_t)(1u - tr->frame_parity) * n_blocks;
         mark(tr, 7);
         for (const auto &le : tr->layout) {
             auto it = tr->geoms.find(le.name);
             if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
             const Geometry &ge = it->second;
             ls::GeomSource src;
-            src.verts = static_cast<const uint8_t *>(ge.d_raw);
+            src.verts = static_cast<const uint8_t *>(ge.raw());
             src.stride = ge.stride;
-            src.idx = ge.d_idx;
+            src.idx = ge.idx();
             src.ntris = ge.n_tris;
             src.gid_first = le.tfirst;
             src.xform = 1;
             std::memcpy(src.m.a, ge.affine, sizeof(src.m.a));
             std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
             std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
-            ls::launch_project(s, pp, src, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, stats);
+            ls::launch_project(s, pp, src, tr->best_keys.p, counts, tr->big_queue.p, tr->big_capacity, tr->d_big_count, stats);
         }
         mark(tr, 8);
-        ls::launch_project_big(s, pp, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, 128u, stats);
-        ls::launch_project_resolve(s, pp, tr->best_keys.p, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, tr->d_big_count);
+        ls::launch_project_big(s, pp, tr->best_keys.p, counts, tr->big_queue.p, tr->big_capacity, tr->d_big_count, 16u, stats);
+        ls::launch_count_keys(s, tr->best_keys.p, shard_rays(tr), counts);
+        mark(tr, 9);
+        ls::GeomTable gt;
+        gt.n = (uint32_t)tr->slot_geom_ids.size();
+        gt.tri_first = tr->geom_table.p;
+        gt.geom_ids = tr->geom_table.p + gt.n + 1;
+        ls::launch_pack_keys(s, tb, tr->best_keys.p, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, tr->d_big_count, gt,
+                             d_points, d_hits, d_n);
+        mark(tr, 10);
+        tr->frame_parity ^= 1u;
     } else {
         if (!tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "the BVH engine was selected after the last commit");
         LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
@@ -562,14 +595,15 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                          tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
         mark(tr, 8);
         ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p);
+        tr->keys_armed = false;  // the counter array was just used with the BVH layout
+        mark(tr, 9);
+        ls::GeomTable gt;
+        gt.n = (uint32_t)tr->slot_geom_ids.size();
+        gt.tri_first = tr->geom_table.p;
+        gt.geom_ids = tr->geom_table.p + gt.n + 1;
+        ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n);
+        mark(tr, 10);
     }
-    mark(tr, 9);
-    ls::GeomTable gt;
-    gt.n = (uint32_t)tr->slot_geom_ids.size();
-    gt.tri_first = tr->geom_table.p;
-    gt.geom_ids = tr->geom_table.p + gt.n + 1;
-    ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n);
-    mark(tr, 10);
     LS_HIP(hipGetLastError());
     tr->traced = true;
     out->d_points32 = d_points;
@@ -768,6 +802,16 @@ int ls_update_geometry_device(ls_tracer *tr, const char *name, const float affin
     LS_ENTER(tr);
     if (!d_verts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null vertices");
     return update_common(tr, name, affine3x4, d_verts, vert_stride, d_tri_idx, hipMemcpyDeviceToDevice);
+}
+
+int ls_update_geometry_device_shared(ls_tracer *tr, const char *name, const float affine3x4[12], const void *d_verts,
+                                     uint32_t vert_stride, const uint32_t *d_tri_idx)
+{
+    LS_ENTER(tr);
+    if (!d_verts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null vertices");
+    auto it = tr->geoms.find(name ? name : "");
+    if (it != tr->geoms.end() && !d_tri_idx && !it->second.has_idx) return fail(tr, LS_ERR_INVALID_ARGUMENT, "no indices yet");
+    return update_common(tr, name, affine3x4, d_verts, vert_stride, d_tri_idx, hipMemcpyDeviceToDevice, true);
 }
 
 int ls_update_geometry_transform(ls_tracer *tr, const char *name, const float affine3x4[12])
