@@ -81,6 +81,7 @@ struct ProjectParams {
     const float *chan_tan_up;      // [V] tan(elevation + margin) of the channels, ascending elevation
     const float *chan_tan_dn;      // [V] tan(elevation - margin), same order
     const uint32_t *chan_perm;     // [V] position in that order -> channel index
+    const uint32_t *chan_rank;     // [V] channel index -> position in that order (inverse of chan_perm)
     float begin_deg, step_deg;     // azimuth of column h = begin + step*h (LidarDevice.cpp:306)
     float inv_step_deg, inv_period; // 1/step and |step|/360 (0 when step is 0)
     float margin_deg;              // angular slack of the footprint bounds
@@ -129,15 +130,14 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
                       const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points);
 // projection engine: per-geometry streaming kernel, big-footprint kernel, resolve (+ row counts)
 size_t project_big_item_bytes();
-void launch_count_keys(hipStream_t s, const unsigned long long *best, uint32_t n, uint32_t *block_counts);
 void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,
                          uint32_t *block_counts2 /* two frame-parity arrays of ceil(rays/256) words */);
-void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best,
-                    uint32_t *block_counts, void *big, uint32_t big_capacity, uint32_t *big_count,
-                    unsigned long long *stats);
-void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *block_counts,
-                        const void *big, uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
-                        unsigned long long *stats);
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
+                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats);
+// per ray: gather the queued big-footprint triangles, then hits per 256-ray block
+void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
+                           uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,
+                           unsigned long long *stats);
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz);
 void launch_bruteforce(hipStream_t s, const SensorTables &tb, const float *verts, const uint32_t *tris,
                        uint32_t ntris, float *t_out, uint32_t *gid_out);

@@ -179,8 +179,7 @@ __device__ __forceinline__ void foot_cell(const ChanTables &ct, uint32_t i0, uin
 
 // exact test of ray (v, h) against the triangle; fold a hit into the ray's closest-hit key
 __device__ __forceinline__ void test_cell(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 e1, V3 e2, float NgC,
-                                          uint32_t gid, uint32_t v, uint32_t h, unsigned long long *__restrict__ best,
-                                          uint32_t *__restrict__ block_counts)
+                                          uint32_t gid, uint32_t v, uint32_t h, unsigned long long *__restrict__ best)
 {
     // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
     const float st = ct.sin_theta[v];
@@ -208,8 +207,7 @@ static_assert(sizeof(BigItem) == 80, "BigItem must be 80 bytes");
 // ------------------------------------------------------------------------------------------
 template <bool COUNT, bool LDS_TABLES>
 __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource src,
-                                                    unsigned long long *__restrict__ best,
-                                                    uint32_t *__restrict__ block_counts, BigItem *__restrict__ big,
+                                                    unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                                     uint32_t big_capacity, uint32_t *__restrict__ big_count,
                                                     unsigned long long *__restrict__ stats)
 {
@@ -302,43 +300,53 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource
         uint32_t v, h;
         foot_cell(ct, s_meta[w][1][lo], s_meta[w][2][lo], s_meta[w][3][lo], s_meta[w][4][lo], s_meta[w][5][lo], m, v, h);
         test_cell(pp, ct, {s_tri[w][0][lo], s_tri[w][1][lo], s_tri[w][2][lo]}, {s_tri[w][3][lo], s_tri[w][4][lo], s_tri[w][5][lo]},
-                  {s_tri[w][6][lo], s_tri[w][7][lo], s_tri[w][8][lo]}, s_tri[w][9][lo], s_meta[w][0][lo], v, h, best,
-                  block_counts);
+                  {s_tri[w][6][lo], s_tri[w][7][lo], s_tri[w][8][lo]}, s_tri[w][9][lo], s_meta[w][0][lo], v, h, best);
     }
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
 }
 
-// Triangles with very large footprints: the whole grid strides over the cells of each queued item.
+// Finish pass, one thread per ray: (1) triangles whose footprint was too large for one wave were
+// queued by k_project; here every ray walks that (normally empty) queue itself -- a gather, so no
+// atomics and no dependency between blocks -- and folds the hits into its own key; (2) hits per
+// 256-ray block, which the ordered pack needs.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_project_big(ProjectParams pp, unsigned long long *__restrict__ best,
-                                                        uint32_t *__restrict__ block_counts,
-                                                        const BigItem *__restrict__ big, uint32_t big_capacity,
-                                                        const uint32_t *__restrict__ big_count,
-                                                        unsigned long long *__restrict__ stats)
-{
-    const uint32_t n_items = min(*big_count, big_capacity);
-    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, nthreads = gridDim.x * kBlock;
-    const ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
-    for (uint32_t r = 0; r < n_items; ++r) {
-        const BigItem it = big[r];
-        const uint32_t cells = it.nch * (it.na + it.nb);
-        for (uint32_t m = tid; m < cells; m += nthreads) {
-            uint32_t v, h;
-            foot_cell(ct, it.i0, it.h0a, it.na, it.h0b, it.nb, m, v, h);
-            test_cell(pp, ct, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
-                      it.NgC, it.gid, v, h, best, block_counts);
-        }
-        if (COUNT && tid == 0) atomicAdd(&stats[0], (unsigned long long)cells);
-    }
-}
-
-// hits per 256-ray block straight from the keys (feeds the ordered pack)
-__global__ __launch_bounds__(kBlock) void k_count_keys(const unsigned long long *__restrict__ best, uint32_t n,
-                                                       uint32_t *__restrict__ block_counts)
+__global__ __launch_bounds__(kBlock) void k_project_finish(ProjectParams pp, unsigned long long *__restrict__ best,
+                                                           const BigItem *__restrict__ big, uint32_t big_capacity,
+                                                           const uint32_t *__restrict__ big_count,
+                                                           uint32_t *__restrict__ block_counts,
+                                                           unsigned long long *__restrict__ stats)
 {
     __shared__ uint32_t s_cnt[kBlock / 64];
+    const uint32_t n = pp.tb.V * pp.tb.naz;
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
-    const bool hit = q < n && best[q] != ~0ull;
+    const uint32_t n_big = min(*big_count, big_capacity);
+    bool hit = false;
+    if (q < n) {
+        unsigned long long key = best[q];
+        if (n_big) {
+            const uint32_t v = q / pp.tb.naz, h = pp.tb.az0 + (q - v * pp.tb.naz);
+            const uint32_t rank = pp.chan_rank[v];  // position of channel v in the elevation-sorted table
+            const float st = pp.tb.sin_theta[v];
+            const float2 cs = pp.tb.cs_phi[h];
+            const V3 d = {st * cs.x, st * cs.y, pp.tb.cos_theta[v]};
+            uint32_t ntest = 0;
+            for (uint32_t r = 0; r < n_big; ++r) {
+                const BigItem &it = big[r];
+                if (rank - it.i0 >= it.nch) continue;
+                if (h - it.h0a >= it.na && h - it.h0b >= it.nb) continue;
+                ++ntest;
+                float t;
+                if (tri_test(d, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
+                             it.NgC, t)) {
+                    const unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | it.gid;
+                    key = k2 < key ? k2 : key;
+                }
+            }
+            best[q] = key;
+            if (COUNT && ntest) atomicAdd(&stats[0], (unsigned long long)ntest);
+        }
+        hit = key != ~0ull;
+    }
     const unsigned long long m = __ballot(hit);
     if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -347,10 +355,19 @@ __global__ __launch_bounds__(kBlock) void k_count_keys(const unsigned long long 
 
 }  // namespace
 
-void launch_count_keys(hipStream_t s, const unsigned long long *best, uint32_t n, uint32_t *block_counts)
+void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
+                           uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,
+                           unsigned long long *stats)
 {
+    const uint32_t n = pp.tb.V * pp.tb.naz;
     if (!n) return;
-    hipLaunchKernelGGL(k_count_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, best, n, block_counts);
+    const dim3 grid((n + kBlock - 1) / kBlock);
+    if (stats)
+        hipLaunchKernelGGL(k_project_finish<true>, grid, dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big),
+                           big_capacity, big_count, block_counts, stats);
+    else
+        hipLaunchKernelGGL(k_project_finish<false>, grid, dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big),
+                           big_capacity, big_count, block_counts, stats);
 }
 
 size_t project_big_item_bytes() { return sizeof(BigItem); }
@@ -365,34 +382,20 @@ void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long l
     (void)hipMemsetAsync(block_counts2, 0, 2 * (size_t)((nq + kBlock - 1) / kBlock) * sizeof(uint32_t), s);
 }
 
-void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best,
-                    uint32_t *block_counts, void *big, uint32_t big_capacity, uint32_t *big_count,
-                    unsigned long long *stats)
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
+                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats)
 {
     if (!src.ntris || !(pp.tb.V * pp.tb.naz)) return;
     const dim3 grid((src.ntris + kBlock - 1) / kBlock);
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
     if (pp.tb.V <= 2048u) {  // channel tables fit in LDS (40 KB at most)
-        if (stats) hipLaunchKernelGGL((k_project<true, true>), grid, dim3(kBlock), lds, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
-        else hipLaunchKernelGGL((k_project<false, true>), grid, dim3(kBlock), lds, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
+        if (stats) hipLaunchKernelGGL((k_project<true, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
+        else hipLaunchKernelGGL((k_project<false, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
     } else {
-        if (stats) hipLaunchKernelGGL((k_project<true, false>), grid, dim3(kBlock), 0, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
-        else hipLaunchKernelGGL((k_project<false, false>), grid, dim3(kBlock), 0, s, pp, src, best, block_counts, bq, big_capacity, big_count, stats);
+        if (stats) hipLaunchKernelGGL((k_project<true, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
+        else hipLaunchKernelGGL((k_project<false, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
     }
-}
-
-void launch_project_big(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *block_counts,
-                        const void *big, uint32_t big_capacity, const uint32_t *big_count, uint32_t grid_blocks,
-                        unsigned long long *stats)
-{
-    if (!(pp.tb.V * pp.tb.naz)) return;
-    if (stats)
-        hipLaunchKernelGGL(k_project_big<true>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best, block_counts,
-                           static_cast<const BigItem *>(big), big_capacity, big_count, stats);
-    else
-        hipLaunchKernelGGL(k_project_big<false>, dim3(grid_blocks), dim3(kBlock), 0, s, pp, best, block_counts,
-                           static_cast<const BigItem *>(big), big_capacity, big_count, stats);
 }
 
 }  // namespace ls

@@ -192,6 +192,7 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     pp.chan_tan_up = tr->d_tables + 2 * (size_t)tr->V + 2 * (size_t)tr->H;
     pp.chan_tan_dn = pp.chan_tan_up + tr->V;
     pp.chan_perm = reinterpret_cast<const uint32_t *>(pp.chan_tan_dn + tr->V);
+    pp.chan_rank = reinterpret_cast<const uint32_t *>(tr->d_tables + 5 * (size_t)tr->V + 4 * (size_t)tr->H);
     pp.begin_deg = tr->h_begin;
     pp.step_deg = (tr->h_end - tr->h_begin) / static_cast<float>(tr->H - 1u);  // LidarDevice.cpp:611
     pp.inv_step_deg = pp.step_deg != 0.0f ? 1.0f / pp.step_deg : 0.0f;
@@ -265,7 +266,7 @@ void mark(ls_tracer *tr, int i)
 void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
 {
     const uint32_t V = tr->V, H = tr->H;
-    tab.resize(2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V + 2 * (size_t)H);
+    tab.resize(2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V + 2 * (size_t)H + (size_t)V);
     const float step = (tr->h_end - tr->h_begin) / static_cast<float>(H - 1u);  // LidarDevice.cpp:611
     for (uint32_t v = 0; v < V; ++v) {
         const float preChi = tr->vertical[v];
@@ -298,6 +299,12 @@ void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
     for (uint32_t h = 0; h < H; ++h) {
         cs[2 * (size_t)h] = tab[2 * (size_t)V + H + h];
         cs[2 * (size_t)h + 1] = tab[2 * (size_t)V + h];
+    }
+    // inverse channel permutation
+    float *rank = cs + 2 * (size_t)H;
+    for (uint32_t i = 0; i < V; ++i) {
+        const uint32_t pos = i;
+        std::memcpy(&rank[perm[i]], &pos, 4);
     }
 }
 
@@ -569,11 +576,10 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             std::memcpy(src.m.a, ge.affine, sizeof(src.m.a));
             std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
             std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
-            ls::launch_project(s, pp, src, tr->best_keys.p, counts, tr->big_queue.p, tr->big_capacity, tr->d_big_count, stats);
+            ls::launch_project(s, pp, src, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, stats);
         }
         mark(tr, 8);
-        ls::launch_project_big(s, pp, tr->best_keys.p, counts, tr->big_queue.p, tr->big_capacity, tr->d_big_count, 16u, stats);
-        ls::launch_count_keys(s, tr->best_keys.p, shard_rays(tr), counts);
+        ls::launch_project_finish(s, pp, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, counts, stats);
         mark(tr, 9);
         ls::GeomTable gt;
         gt.n = (uint32_t)tr->slot_geom_ids.size();

@@ -499,3 +499,31 @@ def test_syn_10m_engines_agree(capi, oracle, sensors):
     assert np.array_equal(gp, gb) and np.array_equal(tp, tb)
     assert np.array_equal(pp, pb) and np.array_equal(hp, hb)
     assert 200000 < len(pp) < 300000
+
+
+def test_big_footprint_triangles(oracle, capi, sensors, engine):
+    """Two triangles that each cover a large part of the raster (a 400 m ground quad under a 64 x 512
+    sensor: > 8192 cells per triangle, the projection engine's big-footprint queue) plus a wall right
+    in front of the sensor and small clutter."""
+    s = _syn_sensor(oracle, sensors, V=64, H=512)
+    s = oracle.Sensor(uid="big", vertical=s.vertical, h_begin=s.h_begin, h_end=s.h_end, h_count=s.h_count,
+                      R=np.eye(3, dtype=np.float32).reshape(9), Rinv=np.eye(3, dtype=np.float32).reshape(9),
+                      t=np.zeros(3, np.float32))
+    quad = np.array([[-200, -200, -3], [200, -200, -3], [200, 200, -3], [-200, 200, -3]], np.float32)
+    wall = np.array([[2, -30, -10], [2, 30, -10], [2, 0, 40]], np.float32)
+    rng = np.random.default_rng(9)
+    cv, ct = _random_soup(rng, 400, 6.0)
+    v = np.concatenate([quad, wall, cv])
+    t = np.concatenate([np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6]], np.uint32), ct + np.uint32(7)])
+    ml = [(0, v, t, oracle.IDENTITY_AFFINE)]
+    ref = oracle.trace_frame(s, ml)
+    assert int((ref["gid"] != oracle.INVALID).sum()) > 15000
+    assert int((ref["gid"] < 3).sum()) > 8000              # the three big triangles own most of the hits
+    tr = make_tracer(capi, s, engine)
+    tr.addGeometry("m", v.shape[0], t.shape[0])
+    tr.updateGeometry("m", oracle.IDENTITY_AFFINE, v, t)
+    assert tr.commitScene() == 0
+    for frame in range(3):                                  # the queue must re-arm between frames
+        rc, pts, hits = tr.traceScene(frame)
+        _assert_parity(oracle, s, tr, ml, pts, hits)
+    tr.close()
