@@ -687,6 +687,7 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
     for (float chi : tr->vertical)
         if (!(chi >= -90.0f && chi <= 90.0f)) tr->projection_ok = false;  // elevation == channel angle only there
     if (!std::isfinite(tr->h_begin) || !std::isfinite(tr->h_end)) tr->projection_ok = false;
+    if (tr->V > 32767u) tr->projection_ok = false;  // channel range is packed into 16+15 bits
     tr->trace_blocks = ls::trace_grid_blocks(hip_device);
     {
         // channel visiting order (j * chan_mul) % V: a stride near 0.38 V that is coprime with V, so
