@@ -73,6 +73,12 @@ def cpu_baseline(sensor, meshes, frames, total_rays):
     the host cores for the SAME frame definition: transform + full BVH build + trace + pack."""
     from oracle import oracle as O
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a cgroup CPU quota (the GPU box gives one GPU's share of the host) bounds the useful thread count
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
     s = O.Sensor(uid="bench", vertical=sensor["vertical"], h_begin=sensor["h_begin"], h_end=sensor["h_end"],
                  h_count=sensor["h_count"], R=np.eye(3, dtype=np.float32).reshape(9), Rinv=sensor["Rinv"], t=sensor["t"])
     ml = [(i, v, t, O.IDENTITY_AFFINE) for i, (_, v, t) in enumerate(meshes)]
@@ -187,6 +193,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         frame(i)
+    enqueue_s = time.perf_counter() - t0     # host time to enqueue K frames (diagnostic: host- or GPU-bound?)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -276,6 +283,7 @@ def main():
                    "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, all-gather of hit slots"
                    if world > 1 else "single GPU"},
         "frames_per_s": args.steps / elapsed,
+        "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         "hits_per_frame_rank0": n_hits,
         "roofline": dict({
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -45,6 +45,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <time.h>
+
+static double lso_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -324,6 +328,8 @@ typedef struct {
     uint32_t *prim;     /* permutation: slot -> global triangle id */
     float *tv;          /* 9 floats per slot: v0,v1,v2 */
     uint32_t ntris;
+    uint32_t *scratch;  /* build only: partition buffer for the parallel top-level splits */
+    int nthreads;       /* build only */
 } lso_bvh;
 
 typedef struct { float lo[3], hi[3], c[3]; } prim_info;
@@ -341,6 +347,85 @@ static float box_area(const float *lo, const float *hi)
 }
 
 #define NBINS 16
+#define PAR_MIN_PRIMS 65536u  /* nodes at least this large are split by all threads together */
+#define PAR_MAX_THREADS 64
+
+typedef struct {
+    float lo[3], hi[3], clo[3], chi[3];                       /* phase 0: bounds */
+    float blo[3][NBINS][3], bhi[3][NBINS][3]; uint32_t bc[3][NBINS];  /* phase 1: bins per axis */
+    uint32_t nleft;                                           /* phase 2: partition counts */
+} par_local;
+
+typedef struct {
+    const prim_info *pi; uint32_t *idx, *scratch; uint32_t first, n; int P, phase;
+    float clo[3], scale[3]; int axis, split; uint32_t left_off[PAR_MAX_THREADS], right_off[PAR_MAX_THREADS];
+    par_local loc[PAR_MAX_THREADS];
+} par_ctx;
+
+typedef struct { par_ctx *c; int t; } par_arg;
+
+static inline int bin_of(float c, float clo, float scale)
+{
+    int k = (int)((c - clo) * scale);
+    if (k >= NBINS) k = NBINS - 1;
+    if (k < 0) k = 0;
+    return k;
+}
+
+static void *par_worker(void *p)
+{
+    par_arg *a = (par_arg *)p;
+    par_ctx *c = a->c;
+    const uint32_t i0 = c->first + (uint32_t)((uint64_t)c->n * a->t / c->P);
+    const uint32_t i1 = c->first + (uint32_t)((uint64_t)c->n * (a->t + 1) / c->P);
+    par_local *L = &c->loc[a->t];
+    if (c->phase == 0) {
+        box_init(L->lo, L->hi);
+        box_init(L->clo, L->chi);
+        for (uint32_t i = i0; i < i1; ++i) {
+            const prim_info *q = &c->pi[c->idx[i]];
+            box_grow(L->lo, L->hi, q->lo, q->hi);
+            box_grow(L->clo, L->chi, q->c, q->c);
+        }
+    } else if (c->phase == 1) {
+        for (int ax = 0; ax < 3; ++ax)
+            for (int k = 0; k < NBINS; ++k) { box_init(L->blo[ax][k], L->bhi[ax][k]); L->bc[ax][k] = 0; }
+        for (uint32_t i = i0; i < i1; ++i) {
+            const prim_info *q = &c->pi[c->idx[i]];
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!(c->scale[ax] > 0.f)) continue;
+                const int k = bin_of(q->c[ax], c->clo[ax], c->scale[ax]);
+                box_grow(L->blo[ax][k], L->bhi[ax][k], q->lo, q->hi);
+                L->bc[ax][k]++;
+            }
+        }
+    } else if (c->phase == 2) {
+        uint32_t nl = 0;
+        for (uint32_t i = i0; i < i1; ++i)
+            if (bin_of(c->pi[c->idx[i]].c[c->axis], c->clo[c->axis], c->scale[c->axis]) <= c->split) ++nl;
+        L->nleft = nl;
+    } else if (c->phase == 3) {
+        uint32_t l = c->left_off[a->t], r = c->right_off[a->t];
+        for (uint32_t i = i0; i < i1; ++i) {
+            const uint32_t id = c->idx[i];
+            if (bin_of(c->pi[id].c[c->axis], c->clo[c->axis], c->scale[c->axis]) <= c->split) c->scratch[l++] = id;
+            else c->scratch[r++] = id;
+        }
+    } else {
+        memcpy(c->idx + i0, c->scratch + i0, sizeof(uint32_t) * (i1 - i0));
+    }
+    return NULL;
+}
+
+static void par_run(par_ctx *c, int phase)
+{
+    pthread_t th[PAR_MAX_THREADS];
+    par_arg args[PAR_MAX_THREADS];
+    c->phase = phase;
+    for (int t = 0; t < c->P; ++t) { args[t].c = c; args[t].t = t; pthread_create(&th[t], NULL, par_worker, &args[t]); }
+    for (int t = 0; t < c->P; ++t) pthread_join(th[t], NULL);
+}
+
 typedef struct { lso_bvh *b; const prim_info *pi; uint32_t *idx; uint32_t node, first, n; int par; } build_job;
 static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t node, uint32_t first, uint32_t n, int par);
 static void *build_thread(void *p)
@@ -357,10 +442,29 @@ static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t n
     float clo[3], chi[3];
     box_init(nd->lo, nd->hi);
     box_init(clo, chi);
-    for (uint32_t i = first; i < first + n; ++i) {
-        const prim_info *p = &pi[idx[i]];
-        box_grow(nd->lo, nd->hi, p->lo, p->hi);
-        box_grow(clo, chi, p->c, p->c);
+    /* large nodes (the top of the tree) are split by all threads together; the arithmetic and the
+     * resulting tree are the same as the serial path below up to the order of primitives in a side */
+    par_ctx *pc = NULL;
+    if (n >= PAR_MIN_PRIMS && b->nthreads > 1 && b->scratch) {
+        pc = (par_ctx *)malloc(sizeof(par_ctx));
+        pc->pi = pi; pc->idx = idx; pc->scratch = b->scratch; pc->first = first; pc->n = n;
+        pc->P = b->nthreads < 16 ? b->nthreads : 16;  /* thread creation costs ~0.1 ms: keep the fan-out modest */
+        par_run(pc, 0);
+        for (int t = 0; t < pc->P; ++t) {
+            box_grow(nd->lo, nd->hi, pc->loc[t].lo, pc->loc[t].hi);
+            box_grow(clo, chi, pc->loc[t].clo, pc->loc[t].chi);
+        }
+        for (int a = 0; a < 3; ++a) {
+            pc->clo[a] = clo[a];
+            pc->scale[a] = (chi[a] - clo[a] > 0.f) ? (float)NBINS / (chi[a] - clo[a]) : 0.f;
+        }
+        par_run(pc, 1);
+    } else {
+        for (uint32_t i = first; i < first + n; ++i) {
+            const prim_info *p = &pi[idx[i]];
+            box_grow(nd->lo, nd->hi, p->lo, p->hi);
+            box_grow(clo, chi, p->c, p->c);
+        }
     }
     if (n <= 4) { nd->left = first; nd->count = n; return; }
     int bestAxis = -1, bestSplit = -1;
@@ -372,6 +476,13 @@ static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t n
         uint32_t bc[NBINS];
         for (int k = 0; k < NBINS; ++k) { box_init(blo[k], bhi[k]); bc[k] = 0; }
         const float scale = (float)NBINS / ext;
+        if (pc) {
+            for (int t = 0; t < pc->P; ++t)
+                for (int k = 0; k < NBINS; ++k) {
+                    box_grow(blo[k], bhi[k], pc->loc[t].blo[a][k], pc->loc[t].bhi[a][k]);
+                    bc[k] += pc->loc[t].bc[a][k];
+                }
+        } else
         for (uint32_t i = first; i < first + n; ++i) {
             const prim_info *p = &pi[idx[i]];
             int k = (int)((p->c[a] - clo[a]) * scale);
@@ -404,6 +515,21 @@ static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t n
     uint32_t mid;
     if (bestAxis < 0) {
         mid = first + n / 2; /* all centroids equal: median split by position */
+    } else if (pc) {
+        pc->axis = bestAxis; pc->split = bestSplit;
+        par_run(pc, 2);
+        uint32_t nl = 0;
+        for (int t = 0; t < pc->P; ++t) nl += pc->loc[t].nleft;
+        uint32_t l = first, r = first + nl;
+        for (int t = 0; t < pc->P; ++t) {
+            const uint32_t c0 = (uint32_t)((uint64_t)n * t / pc->P), c1 = (uint32_t)((uint64_t)n * (t + 1) / pc->P);
+            pc->left_off[t] = l; pc->right_off[t] = r;
+            l += pc->loc[t].nleft; r += (c1 - c0) - pc->loc[t].nleft;
+        }
+        par_run(pc, 3);
+        par_run(pc, 4);
+        mid = first + nl;
+        if (mid == first || mid == first + n) mid = first + n / 2;
     } else {
         const float ext = chi[bestAxis] - clo[bestAxis];
         const float scale = (float)NBINS / ext;
@@ -419,6 +545,7 @@ static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t n
         mid = i;
         if (mid == first || mid == first + n) mid = first + n / 2;
     }
+    free(pc);
     const uint32_t left = __atomic_fetch_add(&b->nnodes, 2u, __ATOMIC_RELAXED);
     nd->left = left;
     nd->count = 0;
@@ -437,6 +564,7 @@ static void build_rec(lso_bvh *b, const prim_info *pi, uint32_t *idx, uint32_t n
 
 lso_bvh *lso_bvh_build(const float *verts, const uint32_t *tris, uint32_t ntris, int nthreads)
 {
+    const double t_0 = lso_now();
     int par = 0;
     while ((1 << par) < nthreads && par < 8) ++par;
     lso_bvh *b = (lso_bvh *)calloc(1, sizeof(lso_bvh));
@@ -459,15 +587,24 @@ lso_bvh *lso_bvh_build(const float *verts, const uint32_t *tris, uint32_t ntris,
         for (int a = 0; a < 3; ++a) { pi[k].lo[a] -= pad; pi[k].hi[a] += pad; }
         idx[k] = k;
     }
+    const double t_a = lso_now();
     b->nodes = (cpu_node *)malloc(sizeof(cpu_node) * (2 * (size_t)ntris + 1));
     b->nnodes = 1;
+    b->nthreads = nthreads;
+    b->scratch = (nthreads > 1 && ntris >= PAR_MIN_PRIMS) ? (uint32_t *)malloc(sizeof(uint32_t) * ntris) : NULL;
     build_rec(b, pi, idx, 0, 0, ntris, par);
+    free(b->scratch);
+    b->scratch = NULL;
+    const double t_b = lso_now();
     b->prim = idx;
     b->tv = (float *)malloc(sizeof(float) * 9 * (size_t)ntris);
     for (uint32_t s = 0; s < ntris; ++s)
         for (int c = 0; c < 3; ++c)
             memcpy(b->tv + 9 * (size_t)s + 3 * c, verts + 3 * (size_t)tris[3 * idx[s] + c], 12);
     free(pi);
+    if (getenv("LSO_BUILD_TIMING"))
+        fprintf(stderr, "lso_bvh_build: setup %.1f ms, recursion %.1f ms, gather %.1f ms\n", (t_a - t_0) * 1e3,
+                (t_b - t_a) * 1e3, (lso_now() - t_b) * 1e3);
     return b;
 }
 
