@@ -527,3 +527,37 @@ def test_big_footprint_triangles(oracle, capi, sensors, engine):
         rc, pts, hits = tr.traceScene(frame)
         _assert_parity(oracle, s, tr, ml, pts, hits)
     tr.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_projection_footprints_never_lose_a_hit(oracle, capi, sensors, seed):
+    """Randomised stress of the projection engine's conservative footprints against the exhaustive
+    GPU kernel: random sensor rasters (channel sets, azimuth ranges, sweep direction, shard), random
+    poses, triangle soups over six orders of magnitude in size and distance."""
+    rng = np.random.default_rng(1000 + seed)
+    V = int(rng.integers(1, 48))
+    H = int(rng.integers(2, 400))
+    vert = np.sort(rng.uniform(-89.0, 89.0, size=V))[::-1] if seed % 3 else rng.uniform(-60.0, 60.0, size=V)
+    begin = float(rng.uniform(-360.0, 360.0))
+    span = float(rng.choice([360.0, -360.0, rng.uniform(5.0, 359.0), -rng.uniform(5.0, 359.0), 720.0]))
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    R, Rinv = oracle.pose_from_quat(*q)
+    s = oracle.Sensor(uid="rnd", vertical=vert.astype(np.float32), h_begin=np.float32(begin), h_end=np.float32(begin + span),
+                      h_count=H, R=R, Rinv=Rinv, t=rng.normal(0.0, 3.0, size=3).astype(np.float32))
+    scale = float(np.exp(rng.uniform(np.log(0.05), np.log(500.0))))
+    v, t = _random_soup(rng, 4000, scale)
+    tr = make_tracer(capi, s, "projection")
+    if H > 8 and seed % 2:
+        first = int(rng.integers(0, H - 4))
+        tr.setShard(first, int(rng.integers(1, H - first + 1)))
+    tr.addGeometry("soup", v.shape[0], t.shape[0])
+    A = oracle.affine_from_components(rng.normal(0, scale, size=3), rng.uniform(-3, 3, size=3))
+    tr.updateGeometry("soup", A, v, t)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    pt, pg = tr.denseHits()
+    bt, bg = tr.bruteForce()
+    assert np.array_equal(pg, bg) and np.array_equal(pt, bt)
+    assert len(pts) == int((bg != oracle.INVALID).sum())
+    tr.close()
