@@ -118,10 +118,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LS_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo -- only to rehearse the N > 1 code path on
+    # a one-GPU box (RCCL refuses two ranks on one device); never used for a reported number
+    rehearsal = os.environ.get("LS_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     sensor, meshes = build_workload(args.workload)
     V, H = int(sensor["vertical"].shape[0]), int(sensor["h_count"])
@@ -129,7 +136,7 @@ def main():
     cap = shards.slot_capacity(V, H, world)  # records per slot
 
     tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"],
-                     device=local_rank)
+                     device=dev_index)
     if args.leaf:
         tr.setOption(capi.LS_OPT_LEAF_SIZE, args.leaf)
     tr.setOption(capi.LS_OPT_ENGINE, {"auto": 0, "bvh": 1, "projection": 2}[args.engine])
@@ -148,16 +155,27 @@ def main():
         dt = torch.from_numpy(np.ascontiguousarray(t, np.uint32).view(np.int32)).to(device)
         assert tr.addGeometry(name, v.shape[0], t.shape[0]) >= 0
         d_meshes.append((name, dv, dt))
-    # one slot = [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap]; gathered slots for N > 1
-    slot_bytes = shards.slot_bytes(cap)
-    slot = torch.zeros(slot_bytes, dtype=torch.uint8, device=device)
-    gathered = torch.zeros(world * slot_bytes, dtype=torch.uint8, device=device) if world > 1 else None
-    base = slot.data_ptr()
-    o_n, o_pts, o_hits = shards.slot_offsets(cap)
-    tr.setOutputBuffers(base + o_pts, base + o_hits, base + o_n, cap)
     ident = capi.IDENTITY_AFFINE
+    if world == 1:
+        # single GPU: [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap] in one caller-owned buffer
+        out_buf = torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=device)
+        base = out_buf.data_ptr()
+        tr.setOutputBuffers(base + 64, base + 64 + 32 * cap, base, cap)
+        count_words = [out_buf]
+    else:
+        # N > 1: the travelling slot holds the count word and the 16-byte hit records only (shards.py);
+        # two slots / two gather buffers alternate so that the all-gather of frame i overlaps frame i+1
+        sb = shards.slot_bytes(cap)
+        slots = [torch.zeros(sb, dtype=torch.uint8, device=device) for _ in range(2)]
+        gathered = [torch.zeros(world * sb, dtype=torch.uint8, device=device) for _ in range(2)]
+        local_points = torch.zeros(32 * cap, dtype=torch.uint8, device=device)
+        cloud_points = torch.zeros(32 * cap * world, dtype=torch.uint8, device=device)
+        cloud_hits = torch.zeros(16 * cap * world, dtype=torch.uint8, device=device)
+        cloud_n = torch.zeros(16, dtype=torch.int32, device=device)
+        works = [None, None]
+        count_words = slots
 
-    def frame(i, copy=False):
+    def update_and_trace(i, copy):
         for name, dv, dt in d_meshes:                      # MeshProjector.cpp:448-461: every mesh, every frame
             if copy:   # defensive D2D copy of the mesh into library-owned buffers (18 MB per frame at 1M triangles)
                 tr.updateGeometryDevice(name, ident, dv.data_ptr(), 12, dt.data_ptr())
@@ -165,10 +183,33 @@ def main():
                 tr.updateGeometryDeviceShared(name, ident, dv.data_ptr(), 12, dt.data_ptr())
         tr.commitScene()
         tr.traceSceneAsync(i)
+
+    def collect(b):
+        """finish the gather that was started from slot b: wait, then compact the world's slots into one cloud"""
+        if works[b] is not None:
+            works[b].wait()                                # the tracer's stream waits for the collective
+            works[b] = None
+            tr.expandGatheredHits(gathered[b].data_ptr(), world, cap, cloud_points.data_ptr(), cloud_hits.data_ptr(),
+                                  cloud_n.data_ptr())
+
+    def frame(i, copy=False):
+        if world == 1:
+            update_and_trace(i, copy)
+            return
+        b = i & 1
+        collect(b)                                         # slot b is free again (its gather is two frames old)
+        tr.setOutputBuffers(local_points.data_ptr(), slots[b].data_ptr() + shards.HEADER, slots[b].data_ptr(), cap)
+        update_and_trace(i, copy)                          # runs while the previous frame's gather is in flight
+        collect(b ^ 1)                                     # previous frame: gather done -> its cloud
+        works[b] = shards.all_gather_slots(slots[b], gathered[b], async_op=True)
+
+    def flush():
         if world > 1:
-            shards.all_gather_slots(slot, gathered)
+            collect(0)
+            collect(1)
 
     def sync():
+        flush()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -181,7 +222,7 @@ def main():
     n_node, n_tri, wave_trips, max_trips = tr.visitStats()
     tr.setOption(capi.LS_OPT_COUNT_VISITS, 0)
     shard_rays = tr.getTotalRays()
-    n_hits = int(slot[:4].view(torch.int32).item())
+    n_hits = int(count_words[0][:4].view(torch.int32).item())
     info = tr.sceneSize()
     n_tris_total = info["n_tris"]
 
@@ -280,11 +321,13 @@ def main():
                    "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,
                    "frame": "updateGeometry(device, in place) + commitScene + traceScene"
                             + (" (full BVH rebuild every frame)" if engine == "bvh" else ""),
-                   "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, all-gather of hit slots"
+                   "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
+                                  f"hit-record slots per frame (overlapped with the next frame), cloud rebuilt on every rank"
                    if world > 1 else "single GPU"},
         "frames_per_s": args.steps / elapsed,
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         "hits_per_frame_rank0": n_hits,
+        "rehearsal_gloo_shared_gpu": True if rehearsal else None,
         "roofline": dict({
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

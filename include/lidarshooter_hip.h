@@ -160,6 +160,15 @@ int ls_abi_version(void);
  * channel.  Ray indices in ls_hit stay global.  Default: the full revolution. */
 int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az);
 
+/* Multi-GPU collection (the all-gatherv of hit records).  Each rank points its outputs
+ * (ls_tracer_set_output_buffers) into a slot of 64 + 16*capacity bytes: [n_points u32 | pad to 64 B |
+ * capacity ls_hit records] -- the 32-byte points need not travel, they are a function of (ray, t).
+ * After one all-gather of the slots (RCCL, in rank order), this call compacts the `world` slots at
+ * d_gathered into one contiguous cloud on the device: d_hits (all records, ascending azimuth
+ * sector), d_points32 (rebuilt points), *d_n_points.  Stream-ordered on the handle's stream. */
+int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
+                            void *d_hits, uint32_t *d_n_points);
+
 /* Run all device work of this handle on `hip_stream` (a hipStream_t; NULL = the handle's own
  * stream).  Lets the caller order its collectives after ls_trace_scene_async. */
 int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream);

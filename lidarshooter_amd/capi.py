@@ -27,7 +27,7 @@ SYMBOLS = (
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
-    "ls_tracer_synchronize", "ls_tracer_set_output_buffers", "ls_tracer_set_option", "ls_get_timings",
+    "ls_tracer_synchronize", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_debug_dense_hits", "ls_debug_trace_bruteforce",
     "ls_debug_scene_size", "ls_debug_download_scene", "ls_debug_download_bvh",
 )
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     L.ls_tracer_set_stream.argtypes = [vp, vp]
     L.ls_tracer_synchronize.argtypes = [vp]
     L.ls_tracer_set_output_buffers.argtypes = [vp, vp, vp, vp, u32]
+    L.ls_expand_gathered_hits.argtypes = [vp, vp, u32, u32, vp, vp, vp]
     L.ls_tracer_set_option.argtypes = [vp, i32, i32]
     L.ls_get_timings.argtypes = [vp, f32p]
     L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -268,6 +269,10 @@ class Tracer:
     def setOutputBuffers(self, d_points: int | None, d_hits: int | None, d_n: int | None, capacity: int):
         return self._check(self.L.ls_tracer_set_output_buffers(self.h, d_points, d_hits, d_n, capacity),
                            "ls_tracer_set_output_buffers")
+
+    def expandGatheredHits(self, d_gathered: int, world: int, capacity: int, d_points: int, d_hits: int, d_n: int):
+        return self._check(self.L.ls_expand_gathered_hits(self.h, d_gathered, world, capacity, d_points, d_hits, d_n),
+                           "ls_expand_gathered_hits")
 
     def setOption(self, option: int, value: int):
         return self._check(self.L.ls_tracer_set_option(self.h, option, value), "ls_tracer_set_option")

@@ -522,6 +522,36 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     hits[dst] = make_uint4(v * tb.H + h, gt.geom_ids[lo], gid - gt.tri_first[lo], __float_as_uint(t));
 }
 
+// Multi-GPU: turn gathered per-rank hit slots into one contiguous cloud.  Slot r (slot_words uint32 each)
+// = [n_r | 15 words pad | n_r..cap ls_hit records]; output = all records in rank order (ascending
+// azimuth sector) + their 32-byte points rebuilt from (ray, t): xyz = t * dir(ray) (EmbreeTracer.cpp:341-345).
+__global__ __launch_bounds__(kBlock) void k_expand_slots(SensorTables tb, const uint32_t *__restrict__ gathered,
+                                                         uint32_t world, uint32_t cap, uint32_t slot_words,
+                                                         float4 *__restrict__ points, uint4 *__restrict__ hits,
+                                                         uint32_t *__restrict__ n_points)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= world * cap) return;
+    const uint32_t r = i / cap, j = i - r * cap;
+    uint32_t off = 0, total = 0;
+    for (uint32_t k = 0; k < world; ++k) {
+        const uint32_t c = min(gathered[(size_t)k * slot_words], cap);
+        if (k < r) off += c;
+        total += c;
+    }
+    if (i == 0) *n_points = total;
+    if (j >= min(gathered[(size_t)r * slot_words], cap)) return;
+    const uint4 rec = reinterpret_cast<const uint4 *>(gathered + (size_t)r * slot_words + 16)[j];
+    const uint32_t v = rec.x / tb.H, h = rec.x - v * tb.H;
+    const float t = __uint_as_float(rec.w);
+    const float st = tb.sin_theta[v];
+    const float2 cs = tb.cs_phi[h];
+    const uint32_t dst = off + j;
+    hits[dst] = rec;
+    points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * tb.cos_theta[v], 0.0f);
+    points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+}
+
 // LidarDevice::allRaysGPU (LidarDeviceKernels.cu:25-52): directions as SoA, shard-compact order.
 __global__ __launch_bounds__(kBlock) void k_raygen(SensorTables tb, float *__restrict__ dx, float *__restrict__ dy,
                                                    float *__restrict__ dz)
@@ -719,6 +749,14 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
     hipLaunchKernelGGL(k_pack<true>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts,
                        next_block_counts, big_count, gt, reinterpret_cast<float4 *>(points32),
                        reinterpret_cast<uint4 *>(hits), n_points);
+}
+
+void launch_expand_slots(hipStream_t s, const SensorTables &tb, const uint32_t *gathered, uint32_t world, uint32_t cap,
+                         uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points)
+{
+    if (!world || !cap) return;
+    hipLaunchKernelGGL(k_expand_slots, dim3(blocks_for(world * cap)), dim3(kBlock), 0, s, tb, gathered, world, cap,
+                       slot_words, reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);
 }
 
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz)

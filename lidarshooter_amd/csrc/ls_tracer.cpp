@@ -981,6 +981,18 @@ int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[4])
     return LS_OK;
 }
 
+int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
+                            void *d_hits, uint32_t *d_n_points)
+{
+    LS_ENTER(tr);
+    if (!d_gathered || !d_points32 || !d_hits || !d_n_points || !world || !capacity)
+        return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
+    ls::launch_expand_slots(tr->stream, tables(tr), static_cast<const uint32_t *>(d_gathered), world, capacity,
+                            16u + 4u * capacity, static_cast<uint8_t *>(d_points32), d_hits, d_n_points);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
 int ls_generate_rays(ls_tracer *tr, float *dx, float *dy, float *dz)
 {
     LS_ENTER(tr);

@@ -561,3 +561,47 @@ def test_projection_footprints_never_lose_a_hit(oracle, capi, sensors, seed):
     assert np.array_equal(pg, bg) and np.array_equal(pt, bt)
     assert len(pts) == int((bg != oracle.INVALID).sum())
     tr.close()
+
+
+def test_expand_gathered_hits(oracle, capi, sensors, meshes):
+    """The receiving side of the multi-GPU all-gather: per-rank slots [count | hit records] are
+    compacted into one cloud and the 32-byte points rebuilt from (ray, t) -- equals the full frame."""
+    import torch
+    from lidarshooter_amd import shards
+    s = sensors["0000"]
+    ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)]
+    ref = oracle.trace_frame(s, ml)
+    world = 3
+    cap = shards.slot_capacity(s.V, s.H, world)
+    sb = shards.slot_bytes(cap)
+    gathered = torch.zeros(world * sb, dtype=torch.uint8, device="cuda:0")
+    scratch_pts = torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0")
+    trs = []
+    for rank in range(world):                              # each "rank" traces its sector straight into its slot
+        tr = make_tracer(capi, s, "projection")
+        first, n = shards.shard_columns(s.H, world, rank)
+        tr.setShard(first, n)
+        _add(tr, "ground", meshes["ground"])
+        _add(tr, "face", meshes["ben"])
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+        tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+        assert tr.commitScene() == 0
+        base = gathered.data_ptr() + rank * sb
+        tr.setOutputBuffers(scratch_pts.data_ptr(), base + shards.HEADER, base, cap)
+        tr.traceSceneAsync(0)
+        tr.synchronize()
+        trs.append(tr)
+    pts = torch.zeros(32 * cap * world, dtype=torch.uint8, device="cuda:0")
+    hts = torch.zeros(16 * cap * world, dtype=torch.uint8, device="cuda:0")
+    n = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    trs[0].expandGatheredHits(gathered.data_ptr(), world, cap, pts.data_ptr(), hts.data_ptr(), n.data_ptr())
+    trs[0].synchronize()
+    k = int(n[0].item())
+    assert k == 1781
+    hits = hts.cpu().numpy()[:16 * k].view(np.uint32).reshape(k, 4)
+    points = pts.cpu().numpy()[:32 * k].reshape(k, 32)
+    order = np.argsort(hits[:, 0], kind="stable")
+    assert np.array_equal(hits[order], ref["hits"]) and np.array_equal(points[order], ref["points"])
+    assert np.array_equal(shards.decode_gathered(gathered.cpu().numpy(), world, cap).view(np.uint32).reshape(-1, 4), hits)
+    for tr in trs:
+        tr.close()

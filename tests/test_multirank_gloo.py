@@ -39,21 +39,26 @@ def _worker(rank, world, port, out_dir):
     mine = (col >= first) & (col < first + n)
     cap = shards.slot_capacity(s.V, s.H, world)
     slot = np.zeros(shards.slot_bytes(cap), np.uint8)
-    shards.write_slot(slot, cap, full["points"][mine], full["hits"][mine])
+    shards.write_slot(slot, cap, full["hits"][mine])
     t_slot = torch.from_numpy(slot)
     gathered = torch.zeros(world * slot.shape[0], dtype=torch.uint8)
-    shards.all_gather_slots(t_slot, gathered)
-    pts, hts = shards.decode_gathered(gathered.numpy(), world, cap)
+    work = shards.all_gather_slots(t_slot, gathered, async_op=True)     # the asynchronous form bench.py uses
+    work.wait()
+    hts = shards.decode_gathered(gathered.numpy(), world, cap)
     hits = hts.view(np.uint32).reshape(-1, 4)
     order = np.argsort(hits[:, 0], kind="stable")
-    ok = np.array_equal(hits[order], full["hits"]) and np.array_equal(pts[order], full["points"])
+    # points are rebuilt on the receiving side from (ray, t): xyz = t * dir(ray)
+    t = hits[order][:, 3].view(np.float32)
+    xyz = (t[:, None] * full["dirs"][hits[order][:, 0]]).astype(np.float32)
+    ok = np.array_equal(hits[order], full["hits"]) and np.array_equal(
+        xyz, full["points"].view(np.float32).reshape(-1, 8)[:, :3])
     # every rank must see the same gathered bytes
     h = torch.tensor([int(np.frombuffer(gathered.numpy().tobytes()[:8], np.uint64)[0] % (1 << 62)), int(ok)])
     hs = [torch.zeros_like(h) for _ in range(world)]
     dist.all_gather(hs, h)
     same = all(bool((x == hs[0]).all()) for x in hs)
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
-        fh.write(f"{int(ok)} {int(same)} {len(pts)}\n")
+        fh.write(f"{int(ok)} {int(same)} {len(hits)}\n")
     dist.destroy_process_group()
 
 
@@ -76,4 +81,4 @@ def test_shard_columns_partition():
                 cols += list(range(f, f + n))
             assert cols == list(range(H))
     assert shards.slot_capacity(128, 4096, 8) == 128 * 512
-    assert shards.slot_bytes(10) == 64 + 480
+    assert shards.slot_bytes(10) == 64 + 160
