@@ -605,3 +605,94 @@ def test_expand_gathered_hits(oracle, capi, sensors, meshes):
     assert np.array_equal(shards.decode_gathered(gathered.cpu().numpy(), world, cap).view(np.uint32).reshape(-1, 4), hits)
     for tr in trs:
         tr.close()
+
+
+def test_edge_cases(oracle, capi, sensors, engine):
+    """Degenerate inputs: one-triangle scene (a BVH with no internal node), coincident triangles in two
+    geometries (equal t: lowest geomID wins), a geometry with zero triangles next to a real one, a
+    degenerate (zero-area) triangle, a one-column shard, a two-column one-channel sensor."""
+    s0 = sensors["0000"]
+    d = oracle.ray_dirs(s0)[31 * s0.H + 10].astype(np.float64)          # a downward ray of lidar_0000
+    c = d * 20.0
+    u = np.cross(d, [0, 0, 1.0]); u /= np.linalg.norm(u)
+    w = np.cross(d, u)
+    tri_sensor = np.array([c + 4 * u, c - 2 * u + 4 * w, c - 2 * u - 4 * w], np.float64)
+    # put it in the world frame so that the library's transform brings it back: v_world = R * v_sensor + t
+    R = s0.R.reshape(3, 3).astype(np.float64)
+    tri = (tri_sensor @ R.T + s0.t.astype(np.float64)).astype(np.float32)
+    idx = np.array([[0, 1, 2]], np.uint32)
+
+    # one triangle
+    tr = make_tracer(capi, s0, engine)
+    tr.addGeometry("one", 3, 1)
+    tr.updateGeometry("one", oracle.IDENTITY_AFFINE, tri, idx)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    ref = _assert_parity(oracle, s0, tr, [(0, tri, idx, oracle.IDENTITY_AFFINE)], pts, hits)
+    assert len(pts) > 0
+    # the same triangle again as a second geometry: every hit keeps geomID 0
+    tr.addGeometry("two", 3, 1)
+    tr.updateGeometry("one", oracle.IDENTITY_AFFINE, tri, idx)
+    tr.updateGeometry("two", oracle.IDENTITY_AFFINE, tri, idx)
+    assert tr.commitScene() == 0
+    rc, pts2, hits2 = tr.traceScene(1)
+    assert len(pts2) == len(pts) and np.all(hits2["geom"] == 0)
+    _assert_parity(oracle, s0, tr, [(0, tri, idx, oracle.IDENTITY_AFFINE), (1, tri, idx, oracle.IDENTITY_AFFINE)], pts2, hits2)
+    # remove geometry 0: now geomID 1 owns the hits
+    assert tr.removeGeometry("one") == 0
+    tr.updateGeometry("two", oracle.IDENTITY_AFFINE, tri, idx)
+    assert tr.commitScene() == 0
+    rc, pts3, hits3 = tr.traceScene(2)
+    assert len(pts3) == len(pts) and np.all(hits3["geom"] == 1)
+    # an empty geometry (0 vertices, 0 triangles) and a degenerate triangle change nothing
+    tr.addGeometry("empty", 0, 0)
+    tr.updateGeometry("empty", oracle.IDENTITY_AFFINE, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    deg = np.array([tri[0], tri[0], tri[1]], np.float32)
+    tr.addGeometry("degenerate", 3, 1)
+    tr.updateGeometry("degenerate", oracle.IDENTITY_AFFINE, deg, idx)
+    tr.updateGeometry("two", oracle.IDENTITY_AFFINE, tri, idx)
+    assert tr.commitScene() == 0
+    rc, pts4, hits4 = tr.traceScene(3)
+    assert np.array_equal(pts4, pts3) and np.array_equal(hits4, hits3)
+    # one-column shard
+    tr.setShard(10, 1)
+    assert tr.getTotalRays() == s0.V
+    assert tr.commitScene() == 0
+    rc, pts5, hits5 = tr.traceScene(4)
+    assert np.array_equal(hits5["ray"] % s0.H, np.full(len(hits5), 10))
+    assert len(pts5) == int((ref["hits"][:, 0] % s0.H == 10).sum())
+    tr.close()
+
+    # smallest raster the reference's formulas allow: 1 channel x 2 columns (step = end - begin)
+    s1 = oracle.Sensor(uid="tiny", vertical=np.array([-30.0], np.float32), h_begin=np.float32(10.0), h_end=np.float32(50.0),
+                       h_count=2, R=s0.R, Rinv=s0.Rinv, t=s0.t)
+    from lidarshooter_amd import synth
+    v, t = synth.grid_mesh(20, 20, half=40.0, seed=2)
+    tr = make_tracer(capi, s1, engine)
+    tr.addGeometry("g", v.shape[0], t.shape[0])
+    tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    _assert_parity(oracle, s1, tr, [(0, v, t, oracle.IDENTITY_AFFINE)], pts, hits)
+    tr.close()
+
+
+def test_argument_errors(capi, sensors):
+    s = sensors["0000"]
+    tr = make_tracer(capi, s)
+    tr.addGeometry("m", 3, 1)
+    v = np.zeros((3, 3), np.float32)
+    with pytest.raises(capi.LidarShooterHipError):
+        tr.updateGeometry("nope", capi.IDENTITY_AFFINE, v, np.zeros((1, 3), np.uint32))      # unknown name
+    with pytest.raises(capi.LidarShooterHipError):
+        tr.updateGeometry("m", capi.IDENTITY_AFFINE, np.zeros(12, np.uint8), None, stride=10)  # bad stride
+    with pytest.raises(capi.LidarShooterHipError):
+        tr.setShard(140, 20)                                                                  # beyond H = 150
+    with pytest.raises(capi.LidarShooterHipError):
+        tr.setOption(capi.LS_OPT_LEAF_SIZE, 3)
+    with pytest.raises(capi.LidarShooterHipError):
+        capi.Tracer(s.vertical, s.h_begin, s.h_end, 1, s.Rinv, s.t)                           # H < 2
+    with pytest.raises(capi.LidarShooterHipError):
+        capi.Tracer(s.vertical, s.h_begin, s.h_end, s.h_count, s.Rinv, s.t, device=99)        # no such GPU
+    assert tr.commitScene() == -1 and tr.traceScene(0)[0] == -1                               # nothing uploaded yet
+    tr.close()
