@@ -64,5 +64,18 @@ __device__ __forceinline__ V3 xform_vertex(const Affine &m, const uint8_t *rec)
     return {o[0], o[1], o[2]};
 }
 
+// The same with A == identity exactly: A*v reproduces v (1*x, +0*y, +0*z, +0 are exact; only the sign
+// of a zero coordinate can differ, which no comparison or product downstream can see), so the first
+// matrix product is skipped.
+__device__ __forceinline__ V3 xform_vertex_sensor_only(const Affine &m, const uint8_t *rec)
+{
+    const float *p = reinterpret_cast<const float *>(rec);
+    const float a = p[0] - m.t[0], b = p[1] - m.t[1], c = p[2] - m.t[2];
+    float o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = (m.rinv[3 * i + 0] * a + m.rinv[3 * i + 1] * b) + m.rinv[3 * i + 2] * c;
+    return {o[0], o[1], o[2]};
+}
+
 }  // namespace
 }  // namespace ls

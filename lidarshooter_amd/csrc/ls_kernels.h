@@ -95,7 +95,7 @@ struct GeomSource {
     const uint32_t *idx;           // 3 * ntris vertex indices into verts
     uint32_t ntris;
     uint32_t gid_first;            // global triangle id of triangle 0
-    int xform;
+    int xform;                     // 0: verts already in the sensor frame, 1: full transform, 2: A is the identity
     Affine m;
 };
 

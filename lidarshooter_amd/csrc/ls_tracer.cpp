@@ -572,7 +572,8 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             src.idx = ge.idx();
             src.ntris = ge.n_tris;
             src.gid_first = le.tfirst;
-            src.xform = 1;
+            static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            src.xform = std::memcmp(ge.affine, kIdentity, sizeof(kIdentity)) == 0 ? 2 : 1;
             std::memcpy(src.m.a, ge.affine, sizeof(src.m.a));
             std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
             std::memcpy(src.m.t, tr->t, sizeof(src.m.t));

@@ -3,3 +3,6 @@ import json,os; d=json.load(open('/tmp/o.json')); r=d['roofline']; print('$1', '
 LS_PROJECT_DEBUG=0 run full
 LS_PROJECT_DEBUG=1 run loads_only
 LS_PROJECT_DEBUG=2 run loads_footprint
+LS_PROJECT_DEBUG=3 run all_but_tests
+LS_PROJECT_EXTRA_LDS=20000 run occupancy_4blocks
+LS_PROJECT_EXTRA_LDS=60000 run occupancy_2blocks
