@@ -234,10 +234,14 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource
     if (k < src.ntris) {
         const uint32_t a = src.idx[3 * (size_t)k + 0], b = src.idx[3 * (size_t)k + 1], c = src.idx[3 * (size_t)k + 2];
         V3 v0, v1, v2;
-        if (src.xform) {
+        if (src.xform == 1) {
             v0 = xform_vertex(src.m, src.verts + (size_t)a * src.stride);
             v1 = xform_vertex(src.m, src.verts + (size_t)b * src.stride);
             v2 = xform_vertex(src.m, src.verts + (size_t)c * src.stride);
+        } else if (src.xform == 2) {  // mesh transform is exactly the identity: sensor pose only
+            v0 = xform_vertex_sensor_only(src.m, src.verts + (size_t)a * src.stride);
+            v1 = xform_vertex_sensor_only(src.m, src.verts + (size_t)b * src.stride);
+            v2 = xform_vertex_sensor_only(src.m, src.verts + (size_t)c * src.stride);
         } else {
             const float *pa = reinterpret_cast<const float *>(src.verts + (size_t)a * src.stride);
             const float *pb = reinterpret_cast<const float *>(src.verts + (size_t)b * src.stride);
