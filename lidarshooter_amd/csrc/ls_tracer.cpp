@@ -164,7 +164,7 @@ void release(DevBuf<T> &b)
     b.cap = 0;
 }
 
-constexpr float kProjectMarginDeg = 0.02f;  // ~3.5e-4 rad: atan2f / table rounding and triangle-test slop
+constexpr float kProjectMarginDeg = 0.005f;  // ~8.7e-5 rad: 5x the polynomial atan2 error (1e-3 deg) + table / test rounding
 
 bool use_projection(const ls_tracer *tr) { return tr->engine == 2 || (tr->engine == 0 && tr->projection_ok); }
 
