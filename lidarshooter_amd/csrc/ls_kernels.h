@@ -85,6 +85,7 @@ struct ProjectParams {
     float begin_deg, step_deg;     // azimuth of column h = begin + step*h (LidarDevice.cpp:306)
     float inv_step_deg, inv_period; // 1/step and |step|/360 (0 when step is 0)
     float margin_deg;              // angular slack of the footprint bounds
+    uint32_t big_cells;            // footprints above this many cells go to the gather queue
     int debug;                     // diagnostic: 1 = stop after the vertex loads, 2 = after the footprints
 };
 

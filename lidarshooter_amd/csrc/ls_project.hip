@@ -26,7 +26,6 @@ namespace ls {
 namespace {
 
 constexpr float kRadToDeg = 57.29577951308232f;
-constexpr uint32_t kBigCells = 8192;   // footprints above this go to the big-triangle queue
 
 // The footprint bounds only have to be conservative, not exact: they use the hardware's 1-ulp
 // reciprocal / square root and a polynomial arctangent, and every use carries explicit slack
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource
             const float NgC = dot_fma(cross_fma(e2, e1), v0);
             const uint32_t gid = src.gid_first + k;
             bool queued = false;
-            if (cells > kBigCells) {
+            if (cells > pp.big_cells) {
                 const uint32_t slot = atomicAdd(big_count, 1u);
                 if (slot < big_capacity) {
                     BigItem it;

@@ -198,6 +198,7 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     pp.inv_step_deg = pp.step_deg != 0.0f ? 1.0f / pp.step_deg : 0.0f;
     pp.inv_period = std::fabs(pp.step_deg) / 360.0f;
     pp.margin_deg = kProjectMarginDeg;
+    pp.big_cells = getenv("LS_PROJECT_BIG_CELLS") ? (uint32_t)atoi(getenv("LS_PROJECT_BIG_CELLS")) : 128u;
     pp.debug = getenv("LS_PROJECT_DEBUG") ? atoi(getenv("LS_PROJECT_DEBUG")) : 0;
     return pp;
 }
@@ -220,7 +221,7 @@ int ensure_outputs(ls_tracer *tr)
         if ((rc = ensure(tr, tr->best_keys, nr))) return rc;
         if (tr->best_keys.cap != cap0) tr->keys_armed = false;
         if (!tr->big_queue.p) {
-            tr->big_capacity = 1u << 16;
+            tr->big_capacity = 512u;  // every ray walks the whole queue: keep it short, overflow is expanded in place
             if ((rc = ensure(tr, tr->big_queue, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
         }
     } else {
