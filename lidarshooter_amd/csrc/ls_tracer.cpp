@@ -656,6 +656,7 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
     if (!out) return LS_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return LS_ERR_INVALID_ARGUMENT;
+    if ((unsigned long long)sd->n_vertical * sd->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;  // ray indices are 32-bit
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
         return LS_ERR_NO_DEVICE;
