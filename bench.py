@@ -42,8 +42,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32"],
-                    help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size")
+    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5"],
+                    help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size; "
+                         "cfg5 = configs[4] itself: one SYN-128 sensor per GPU on a 20 m circle over SYN-10M + ben "
+                         "animated by config/trajectory.json, replicas only (weak scaling, no collective)")
     ap.add_argument("--leaf", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
     ap.add_argument("--engine", default="auto", choices=["auto", "bvh", "projection"],
                     help="closest-hit engine (auto = the library default: sensor-space projection)")
@@ -53,7 +55,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_workload(name):
+def build_workload(name, rank=0):
     """-> (sensor dict for capi.Tracer, list of (mesh name, verts f32[n,3], tris u32[m,3]))."""
     dev = hostapi.LidarDevice(os.path.join(DATA, "config", "hesai-pandar-XT-32-lidar_0000.json"))
     d = dev.desc()
@@ -64,8 +66,23 @@ def build_workload(name):
     d = dict(d)
     d["vertical"] = synth.syn_vertical(128)      # +15 .. -25 deg
     d["h_begin"], d["h_end"], d["h_count"] = np.float32(0.0), np.float32(360.0), 4096
-    v, t = synth.syn_10m() if name == "syn128x10m" else synth.syn_1m()
+    v, t = synth.syn_10m() if name in ("syn128x10m", "cfg5") else synth.syn_1m()
+    if name == "cfg5":
+        ang = 2.0 * np.pi * rank / 8.0            # 8 sensor poses on a 20 m circle around lidar_0000's
+        d["t"] = (d["t"] + np.array([20.0 * np.cos(ang), 20.0 * np.sin(ang), 0.0], np.float32)).astype(np.float32)
+        b = hostapi.PolygonMesh(os.path.join(DATA, "mesh", "ben.stl"))
+        return d, [("ground", v, t), ("face", b.points(), b.polygons())]
     return d, [("ground", v, t)]
+
+
+def _affine(lin, ang):
+    """Translation(lin) * Rz * Ry * Rx as row-major 3x4 (MeshTransformer.cpp:467-477), built on the host."""
+    cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], np.float32)
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], np.float32)
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], np.float32)
+    m = (rz @ ry @ rx).astype(np.float32)
+    return np.concatenate([m, np.asarray(lin, np.float32).reshape(3, 1)], axis=1).reshape(12)
 
 
 def cpu_baseline(sensor, meshes, frames, total_rays):
@@ -130,10 +147,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    sensor, meshes = build_workload(args.workload)
+    sensor, meshes = build_workload(args.workload, rank)
+    replicas = args.workload == "cfg5"               # every rank traces its own full sensor: no shards, no collective
+    if replicas:  # the AffineMesh pose rule played over config/trajectory.json, scaled to keep ben inside the scene
+        poses = hostapi.trajectory_play(os.path.join(DATA, "config", "trajectory.json"), 0.1)
+        affines = [_affine(p[:3] * np.float32(0.05), p[3:]) for p in poses]
     V, H = int(sensor["vertical"].shape[0]), int(sensor["h_count"])
-    first_az, n_az = shards.shard_columns(H, world, rank)
-    cap = shards.slot_capacity(V, H, world)  # records per slot
+    first_az, n_az = (0, H) if replicas else shards.shard_columns(H, world, rank)
+    cap = V * H if replicas else shards.slot_capacity(V, H, world)  # records per slot
 
     tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"],
                      device=dev_index)
@@ -156,7 +177,8 @@ def main():
         assert tr.addGeometry(name, v.shape[0], t.shape[0]) >= 0
         d_meshes.append((name, dv, dt))
     ident = capi.IDENTITY_AFFINE
-    if world == 1:
+    single = world == 1 or replicas
+    if single:
         # single GPU: [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap] in one caller-owned buffer
         out_buf = torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=device)
         base = out_buf.data_ptr()
@@ -177,6 +199,9 @@ def main():
 
     def update_and_trace(i, copy):
         for name, dv, dt in d_meshes:                      # MeshProjector.cpp:448-461: every mesh, every frame
+            if replicas and name == "face":                # the animated instance: a new pose every frame
+                tr.updateGeometryDeviceShared(name, affines[i % len(affines)], dv.data_ptr(), 12, dt.data_ptr())
+                continue
             if copy:   # defensive D2D copy of the mesh into library-owned buffers (18 MB per frame at 1M triangles)
                 tr.updateGeometryDevice(name, ident, dv.data_ptr(), 12, dt.data_ptr())
             else:      # the mesh is read in place from the caller's HBM buffers (vertex transform fused into the trace)
@@ -193,7 +218,7 @@ def main():
                                   cloud_n.data_ptr())
 
     def frame(i, copy=False):
-        if world == 1:
+        if single:
             update_and_trace(i, copy)
             return
         b = i & 1
@@ -204,7 +229,7 @@ def main():
         works[b] = shards.all_gather_slots(slots[b], gathered[b], async_op=True)
 
     def flush():
-        if world > 1:
+        if not single:
             collect(0)
             collect(1)
 
@@ -252,7 +277,7 @@ def main():
     tr.setOption(capi.LS_OPT_TIMING, 0)
 
     breakdown = None
-    if args.breakdown or world == 1:
+    if (args.breakdown or world == 1) and not replicas:
         tr.setOption(capi.LS_OPT_TIMING, 1)
         tr.timings()
         for i in range(min(args.steps, 50)):
@@ -288,7 +313,7 @@ def main():
         frame(0)
         sync()
 
-    total_rays = V * H
+    total_rays = V * H * (world if replicas else 1)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays * args.steps / elapsed / 1e6
     trace_ms = tm["trace"]
@@ -312,7 +337,7 @@ def main():
     # counters cannot be collected from inside this process, so the figure is the profiled one
     traffic, traffic_src = None, None
     prof = os.path.join(ROOT, "profiles", f"r01_{engine}_hbm.json")
-    if args.workload == "syn128x1m" and world == 1 and os.path.exists(prof):
+    if args.workload == "syn128x1m" and world == 1 and os.path.exists(prof):  # only the profiled configuration
         try:
             k = json.load(open(prof))["kernels"]
             key = next((n for n in k if n.startswith(kernel) and "true" not in n), None)
@@ -324,19 +349,22 @@ def main():
     out = {
         "metric": {"syn128x1m": "Mrays/s (full LiDAR frame: update + commit + trace + pack; 128ch x 4096az over 1M tris)",
                    "syn128x10m": "Mrays/s (full LiDAR frame; 128ch x 4096az over 10M tris)",
+                   "cfg5": "Mrays/s (one 128ch x 4096az sensor per GPU over a shared 10M-tri scene + animated instance)",
                    "xt32": "Mrays/s (XT-32 over ground+ben)"}[args.workload],
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"syn128x1m": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)",
                                 "syn128x10m": "SYN-128 x SYN-10M (9,998,244 tris)",
+                                "cfg5": "8-pose SYN-128 ring x (SYN-10M + ben.stl animated by trajectory.json), replicas only",
                                 "xt32": "XT-32 lidar_0000 x ground.stl+ben.stl"}[args.workload],
                    "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,
                    "frame": "updateGeometry(device, in place) + commitScene + traceScene"
                             + (" (full BVH rebuild every frame)" if engine == "bvh" else ""),
                    "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
                                   f"hit-record slots per frame (overlapped with the next frame), cloud rebuilt on every rank"
-                   if world > 1 else "single GPU"},
+                   if not single else ("single GPU" if world == 1 else
+                                       f"{world} independent replicas (one sensor pose per GPU), no collective")},
         "frames_per_s": args.steps / elapsed,
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         "hits_per_frame_rank0": n_hits,
@@ -354,7 +382,7 @@ def main():
         out["host_buffers_ms_per_step"] = host_frame_s * 1e3   # PCIe-inclusive, synchronous ITracer-style frame
         out["trace_only_ms"] = trace_only_s * 1e3
         out["trace_only_mrays_per_s"] = shard_rays / trace_only_s / 1e6
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not replicas:
         out["cpu_baseline"] = cpu_baseline(sensor, meshes, args.cpu_frames, total_rays)
     if rank == 0:
         print(json.dumps(out), flush=True)
