@@ -13,7 +13,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblidarshooter_hip.so")
+# LS_LIB_PATH: kernel-variant experiments (tools/) load another build of the same library
+LIB_PATH = os.environ.get("LS_LIB_PATH") or os.path.join(_HERE, "liblidarshooter_hip.so")
 INVALID = 0xFFFFFFFF
 
 LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE = 1, 2, 3, 5

@@ -35,17 +35,6 @@ __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sq
 
 __device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
 
-// squared distance from the 2-D origin to segment a-b (approximate to a few ulp)
-__device__ __forceinline__ float seg_dist2(float ax, float ay, float bx, float by)
-{
-    const float dx = bx - ax, dy = by - ay;
-    const float len2 = dx * dx + dy * dy;
-    float s = len2 > 0.0f ? -(ax * dx + ay * dy) * fast_rcp(len2) : 0.0f;
-    s = fminf(fmaxf(s, 0.0f), 1.0f);
-    const float px = ax + s * dx, py = ay + s * dy;
-    return px * px + py * py;
-}
-
 // atan2 in degrees, |error| < 1e-3 deg (Abramowitz & Stegun 4.4.49 on [0,1] + octant folding)
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -78,17 +67,20 @@ __device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTab
     Foot f = {0, 0, 0, 0, 0, 0};
     // ---- elevation band in tangent space: tan(e) = z / rho over the triangle lies inside
     //      [zmin / (zmin >= 0 ? rho_max : rho_min), zmax / (zmax > 0 ? rho_min : rho_max)]
+    // rho_max = largest vertex rho.  rho_min: for the unit vector u towards the centroid (2-D), every
+    // point p of the triangle has |p| >= p.u >= min_i v_i.u -- exact to second order in the angle the
+    // triangle subtends, and <= 0 (-> 0) whenever the vertical axis pierces the triangle.
     const float zmin = fminf(v0.z, fminf(v1.z, v2.z)), zmax = fmaxf(v0.z, fmaxf(v1.z, v2.z));
     const float r0 = v0.x * v0.x + v0.y * v0.y, r1 = v1.x * v1.x + v1.y * v1.y, r2 = v2.x * v2.x + v2.y * v2.y;
     const float rho_max = fast_sqrt(fmaxf(r0, fmaxf(r1, r2))) * 1.0001f;
-    const float c0 = cross2(v0.x, v0.y, v1.x, v1.y), c1 = cross2(v1.x, v1.y, v2.x, v2.y),
-                c2 = cross2(v2.x, v2.y, v0.x, v0.y);
-    const float ctol = 1e-6f * rho_max * rho_max;
-    const bool inside = (c0 >= -ctol && c1 >= -ctol && c2 >= -ctol) || (c0 <= ctol && c1 <= ctol && c2 <= ctol);
+    const float cx = (v0.x + v1.x) + v2.x, cy = (v0.y + v1.y) + v2.y;
+    const float cc = cx * cx + cy * cy;
     float rho_min = 0.0f;
-    if (!inside)
-        rho_min = 0.9999f * fast_sqrt(fminf(seg_dist2(v0.x, v0.y, v1.x, v1.y),
-                                            fminf(seg_dist2(v1.x, v1.y, v2.x, v2.y), seg_dist2(v2.x, v2.y, v0.x, v0.y))));
+    if (cc > 1e-30f) {
+        const float p0 = v0.x * cx + v0.y * cy, p1 = v1.x * cx + v1.y * cy, p2 = v2.x * cx + v2.y * cy;
+        // 1e-4 relative for the reciprocal square root and |u|, 1e-6 rho_max absolute for the rounding of the dots
+        rho_min = fmaxf(fminf(p0, fminf(p1, p2)) * __builtin_amdgcn_rsqf(cc) * 0.9999f - 1e-6f * rho_max, 0.0f);
+    }
     float tan_lo = -INFINITY, tan_hi = INFINITY;
     if (rho_max > 0.0f) {
         // quotients rounded outwards by 1e-5 relative (the reciprocal is good to 1 ulp)
@@ -107,24 +99,46 @@ __device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTab
     while (i1 < pp.tb.V && ct.tan_dn[i1] <= tan_hi) ++i1;
     if (i0 >= i1) return f;
 
-    // ---- azimuth arc: the three vertex azimuths minus the largest gap between them; if that gap is
-    //      not larger than 180 deg the origin is inside the projection: full circle
+    // ---- azimuth arc.  Small triangles (both other vertices within 14 deg of vertex 0 as seen from
+    //      the vertical axis -- the bulk of a large scene) need one arctangent: the offsets come from
+    //      tan(delta) = cross / dot, bounded by the alternating series.  Otherwise: the three vertex
+    //      azimuths minus the largest gap between them; if that gap is not larger than 180 deg the
+    //      axis pierces the triangle: full circle.
     const uint32_t az_first = pp.tb.az0, az_last = pp.tb.az0 + pp.tb.naz - 1u;
-    bool full = inside || !(fabsf(pp.step_deg) > 0.0f);
+    bool full = !(fabsf(pp.step_deg) > 0.0f);
     float phi_lo = 0.0f, span = 360.0f;
     if (!full) {
-        float a = fast_atan2_deg(v0.y, v0.x), b = fast_atan2_deg(v1.y, v1.x), c = fast_atan2_deg(v2.y, v2.x);
-        float t;
-        if (a > b) { t = a; a = b; b = t; }
-        if (b > c) { t = b; b = c; c = t; }
-        if (a > b) { t = a; a = b; b = t; }
-        const float g0 = b - a, g1 = c - b, g2 = a + 360.0f - c;
-        float maxgap = g2;
-        phi_lo = a;                                    // arc [a, c]
-        if (g0 > maxgap) { maxgap = g0; phi_lo = b; }  // arc [b, a + 360]
-        if (g1 > maxgap) { maxgap = g1; phi_lo = c; }  // arc [c, b + 360]
-        span = 360.0f - maxgap;
-        if (!(maxgap > 180.0f + 2.0f * pp.margin_deg)) full = true;
+        const float d1 = v0.x * v1.x + v0.y * v1.y, c1 = cross2(v0.x, v0.y, v1.x, v1.y);
+        const float d2 = v0.x * v2.x + v0.y * v2.y, c2 = cross2(v0.x, v0.y, v2.x, v2.y);
+        if (d1 > 0.0f && d2 > 0.0f && fabsf(c1) <= 0.25f * d1 && fabsf(c2) <= 0.25f * d2) {
+            // |atan x| <= |x (1 - x^2/3 + x^4/5)| for |x| < 1 (truncated after a positive term)
+            const float x1 = c1 * fast_rcp(d1), x2 = c2 * fast_rcp(d2);
+            const float s1 = x1 * x1, s2 = x2 * x2;
+            const float q1 = x1 * (1.0f - s1 * (0.3333333f - s1 * 0.2f)), q2 = x2 * (1.0f - s2 * (0.3333333f - s2 * 0.2f));
+            const float lo = fminf(0.0f, fminf(q1, q2)), hi = fmaxf(0.0f, fmaxf(q1, q2));
+            phi_lo = fast_atan2_deg(v0.y, v0.x) + lo * (kRadToDeg * 1.0001f);
+            span = (hi - lo) * (kRadToDeg * 1.0001f);
+        } else {
+            const float ctol = 1e-6f * rho_max * rho_max;
+            const float c3 = cross2(v1.x, v1.y, v2.x, v2.y);   // v0 x v1 = c1, v1 x v2 = c3, v2 x v0 = -c2
+            const bool inside = (c1 >= -ctol && c3 >= -ctol && -c2 >= -ctol) || (c1 <= ctol && c3 <= ctol && -c2 <= ctol);
+            if (inside) {
+                full = true;
+            } else {
+                float a = fast_atan2_deg(v0.y, v0.x), b = fast_atan2_deg(v1.y, v1.x), c = fast_atan2_deg(v2.y, v2.x);
+                float t;
+                if (a > b) { t = a; a = b; b = t; }
+                if (b > c) { t = b; b = c; c = t; }
+                if (a > b) { t = a; a = b; b = t; }
+                const float g0 = b - a, g1 = c - b, g2 = a + 360.0f - c;
+                float maxgap = g2;
+                phi_lo = a;                                    // arc [a, c]
+                if (g0 > maxgap) { maxgap = g0; phi_lo = b; }  // arc [b, a + 360]
+                if (g1 > maxgap) { maxgap = g1; phi_lo = c; }  // arc [c, b + 360]
+                span = 360.0f - maxgap;
+                if (!(maxgap > 180.0f + 2.0f * pp.margin_deg)) full = true;
+            }
+        }
     }
     f.i0 = i0;
     f.nch = i1 - i0;

@@ -1,10 +1,7 @@
 #!/bin/bash
-# k_project ablation: LS_PROJECT_DEBUG stops the kernel after a phase (1 = vertex loads, 2 = stage 1,
-# 3 = stage 2 footprints); prints frame and kernel time for each.
+# bench the library variants under build/var/ (built by hand with -D switches), default library first
 W=${W:-syn128x1m}
 run() { python bench.py --workload $W --steps 100 --warmup 10 --no-cpu-baseline > /tmp/o.json 2>/dev/null; python3 -c "
 import json,os; d=json.load(open('/tmp/o.json')); r=d['roofline']; print('$1', 'frame', round(d['ms_per_step'],4), 'kernel', round(r['kernel_ms'],4), 'tests', r.get('candidate_tests_per_launch'))"; }
-LS_PROJECT_DEBUG=0 run full
-LS_PROJECT_DEBUG=1 run loads_only
-LS_PROJECT_DEBUG=2 run stage1
-LS_PROJECT_DEBUG=3 run stage2_footprints
+run default
+for f in build/var/lib_*.so; do LS_LIB_PATH=$PWD/$f run $(basename $f); done
