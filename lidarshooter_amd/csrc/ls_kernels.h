@@ -100,6 +100,15 @@ struct GeomSource {
     Affine m;
 };
 
+// the geometries of one k_project launch (kernel argument: no upload)
+constexpr int kGeomsPerLaunch = 16;
+struct GeomBatch {
+    uint32_t n;
+    uint32_t block_first[kGeomsPerLaunch + 1];   // first workgroup of geometry i; [n] = grid size
+    uint32_t tris_per_wave[kGeomsPerLaunch];     // 64, or less for a small mesh
+    GeomSource g[kGeomsPerLaunch];
+};
+
 // ---- build ---------------------------------------------------------------------------------
 void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t n, const float *affine12,
                       const float *rinv9, const float *t3, float *out_xyz, uint32_t *d_maxabs_bits);
@@ -133,8 +142,8 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
 size_t project_big_item_bytes();
 void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,
                          uint32_t *block_counts2 /* two frame-parity arrays of ceil(rays/256) words */);
-void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
-                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats);
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
+                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats);
 // per ray: gather the queued big-footprint triangles, then hits per 256-ray block
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
                            uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,

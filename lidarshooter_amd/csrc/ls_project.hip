@@ -18,6 +18,8 @@
 // Replaces (with the BVH engine in ls_kernels.hip as the general-ray alternative):
 // rtcIntersect16 over the committed scene (EmbreeTracer.cpp:297-367, :472-480) / optixLaunch
 // (OptixTracer.cpp:317-328, OptixTracerModules.cu:26-86).
+#include <algorithm>
+#include <cstdlib>
 #include "ls_kernels.h"
 #include "ls_device.h"
 
@@ -218,8 +220,8 @@ static_assert(sizeof(BigItem) == 80, "BigItem must be 80 bytes");
 // lanes (prefix sum + search), so a wave's cost is its total cell count / 64, not its largest
 // footprint.  Algorithmic bytes per triangle: 12 (indices) + 36 (vertex gather); per hit 8.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, bool LDS_TABLES>
-__global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource src,
+template <bool COUNT, bool LDS_TABLES, bool MULTI>
+__global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomBatch batch,
                                                     unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                                     uint32_t big_capacity, uint32_t *__restrict__ big_count,
                                                     unsigned long long *__restrict__ stats)
@@ -229,7 +231,16 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomSource
     __shared__ uint32_t s_pref[kBlock / 64][64];      // exclusive prefix of the cell counts
     extern __shared__ float s_chan[];                 // LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    // one launch covers up to kGeomsPerLaunch geometries: the workgroup finds its own (uniform)
+    uint32_t gi = 0;
+    if (MULTI)
+        while (gi + 1u < batch.n && blockIdx.x >= batch.block_first[gi + 1u]) ++gi;
+    const GeomSource &src = batch.g[gi];
+    // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
+    // join the cell tests): its footprints are large, and the cells are what takes the time
+    const uint32_t tris_per_wave = batch.tris_per_wave[gi];
+    const uint32_t block = MULTI ? blockIdx.x - batch.block_first[gi] : blockIdx.x;
+    const uint32_t k = lane < tris_per_wave ? (block * (kBlock / 64) + w) * tris_per_wave + lane : 0xFFFFFFFFu;
     ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
     if (LDS_TABLES) {
         const uint32_t V = pp.tb.V;
@@ -399,19 +410,45 @@ void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long l
     (void)hipMemsetAsync(block_counts2, 0, 2 * (size_t)((nq + kBlock - 1) / kBlock) * sizeof(uint32_t), s);
 }
 
-void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource &src, unsigned long long *best, void *big,
-                    uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats)
+void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
+                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats)
 {
-    if (!src.ntris || !(pp.tb.V * pp.tb.naz)) return;
-    const dim3 grid((src.ntris + kBlock - 1) / kBlock);
+    if (!(pp.tb.V * pp.tb.naz)) return;
+    // 64 triangles per wave when that still gives every SIMD a few waves; fewer for small meshes
+    static const uint32_t min_tpw = getenv("LS_PROJECT_MIN_TPW") ? (uint32_t)std::max(1, atoi(getenv("LS_PROJECT_MIN_TPW"))) : 1u;
+    static const uint32_t tpw_waves = getenv("LS_PROJECT_TPW_WAVES") ? (uint32_t)atoi(getenv("LS_PROJECT_TPW_WAVES")) : 8192u;
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
-    if (pp.tb.V <= 2048u) {  // channel tables fit in LDS (40 KB at most)
-        if (stats) hipLaunchKernelGGL((k_project<true, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
-        else hipLaunchKernelGGL((k_project<false, true>), grid, dim3(kBlock), lds, s, pp, src, best, bq, big_capacity, big_count, stats);
-    } else {
-        if (stats) hipLaunchKernelGGL((k_project<true, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
-        else hipLaunchKernelGGL((k_project<false, false>), grid, dim3(kBlock), 0, s, pp, src, best, bq, big_capacity, big_count, stats);
+    uint32_t at = 0;
+    while (at < n_srcs) {
+        GeomBatch batch;
+        batch.n = 0;
+        uint32_t blocks = 0;
+        for (; at < n_srcs && batch.n < (uint32_t)kGeomsPerLaunch; ++at) {
+            const GeomSource &src = srcs[at];
+            if (!src.ntris) continue;
+            uint32_t tpw = 64u;
+            while (tpw > min_tpw && (src.ntris + tpw - 1u) / tpw < tpw_waves) tpw >>= 1;
+            const uint32_t per_block = tpw * (kBlock / 64);
+            batch.block_first[batch.n] = blocks;
+            batch.tris_per_wave[batch.n] = tpw;
+            batch.g[batch.n] = src;
+            blocks += (src.ntris + per_block - 1) / per_block;
+            ++batch.n;
+        }
+        if (!batch.n) break;
+        batch.block_first[batch.n] = blocks;
+        const dim3 grid(blocks);
+        const bool multi = batch.n > 1;
+#define LS_LAUNCH(C, L, M) hipLaunchKernelGGL((k_project<C, L, M>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, best, bq, big_capacity, big_count, stats)
+        if (pp.tb.V <= 2048u) {  // channel tables fit in LDS (40 KB at most)
+            if (stats) { if (multi) LS_LAUNCH(true, true, true); else LS_LAUNCH(true, true, false); }
+            else { if (multi) LS_LAUNCH(false, true, true); else LS_LAUNCH(false, true, false); }
+        } else {
+            if (stats) { if (multi) LS_LAUNCH(true, false, true); else LS_LAUNCH(true, false, false); }
+            else { if (multi) LS_LAUNCH(false, false, true); else LS_LAUNCH(false, false, false); }
+        }
+#undef LS_LAUNCH
     }
 }
 

@@ -92,6 +92,7 @@ struct ls_tracer {
     DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
     uint32_t *d_queue_heads = nullptr;
     uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 24;
+    std::vector<ls::GeomSource> project_srcs;  // scratch of trace_locked
     ls::RangeTree rt{};
     uint32_t range_entries = 0;
     uint32_t *d_maxabs = nullptr;
@@ -563,6 +564,8 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         uint32_t *counts = tr->row_counts.p + (size_t)tr->frame_parity * n_blocks;
         uint32_t *next_counts = tr->row_counts.p + (size_t)(1u - tr->frame_parity) * n_blocks;
         mark(tr, 7);
+        std::vector<ls::GeomSource> &srcs = tr->project_srcs;
+        srcs.clear();
         for (const auto &le : tr->layout) {
             auto it = tr->geoms.find(le.name);
             if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
@@ -578,8 +581,11 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             std::memcpy(src.m.a, ge.affine, sizeof(src.m.a));
             std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
             std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
-            ls::launch_project(s, pp, src, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, stats);
+            srcs.push_back(src);
         }
+        // one launch per 16 geometries (the descriptors travel as kernel arguments)
+        ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), tr->best_keys.p, tr->big_queue.p, tr->big_capacity,
+                           tr->d_big_count, stats);
         mark(tr, 8);
         ls::launch_project_finish(s, pp, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, counts, stats);
         mark(tr, 9);
