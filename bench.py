@@ -340,7 +340,8 @@ def main():
     if args.workload == "syn128x1m" and world == 1 and os.path.exists(prof):  # only the profiled configuration
         try:
             k = json.load(open(prof))["kernels"]
-            key = next((n for n in k if n.startswith(kernel) and "true" not in n), None)
+            # the timed variant: template argument COUNT (the first one) is false
+            key = next((n for n in k if n.split("<")[0] == kernel and not n.split("<")[-1].startswith("true")), None)
             if key:
                 traffic, traffic_src = k[key]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
         except Exception:

@@ -148,6 +148,9 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
                            uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,
                            unsigned long long *stats);
+// dense per-ray (t, global triangle id) arrays rebuilt from the packed hit records (debug view)
+void launch_dense_from_hits(hipStream_t s, const SensorTables &tb, const void *hits, const uint32_t *n_points,
+                            const GeomTable &gt, float *t, uint32_t *gid);
 void launch_expand_slots(hipStream_t s, const SensorTables &tb, const uint32_t *gathered, uint32_t world, uint32_t cap,
                          uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points);
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz);

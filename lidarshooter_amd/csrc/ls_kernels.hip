@@ -485,8 +485,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
             const unsigned long long key = keys[q];
             keys[q] = ~0ull;
             if (key != ~0ull) { gid = (uint32_t)key; t = __uint_as_float((uint32_t)(key >> 32)); }
-            t_io[q] = t;
-            gid_io[q] = gid;
+            // no dense per-ray arrays on this path: ls_debug_dense_hits rebuilds them from the records
         } else {
             gid = gid_io[q];
             t = t_io[q];
@@ -520,6 +519,32 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
     }
     hits[dst] = make_uint4(v * tb.H + h, gt.geom_ids[lo], gid - gt.tri_first[lo], __float_as_uint(t));
+}
+
+// Debug view of the projection engine's result: dense per-ray (t, global triangle id) arrays from
+// the packed hit records (ls_debug_dense_hits); k_dense_clear first, then one thread per record.
+__global__ __launch_bounds__(kBlock) void k_dense_clear(uint32_t nq, float *__restrict__ t, uint32_t *__restrict__ gid)
+{
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q < nq) { t[q] = -1.0f; gid[q] = kInvalid; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_dense_from_hits(SensorTables tb, const uint4 *__restrict__ hits,
+                                                            const uint32_t *__restrict__ n_points, GeomTable gt,
+                                                            float *__restrict__ t, uint32_t *__restrict__ gid)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *n_points) return;
+    const uint4 rec = hits[i];                        // (ray, geomID, primID, bits(t))
+    const uint32_t v = rec.x / tb.H, h = rec.x - v * tb.H;
+    uint32_t lo = 0, hi = gt.n;                       // geometry slot of geomID (slots ascend by id)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (gt.geom_ids[mid] <= rec.y) lo = mid; else hi = mid;
+    }
+    const uint32_t q = v * tb.naz + (h - tb.az0);
+    t[q] = __uint_as_float(rec.w);
+    gid[q] = gt.tri_first[lo] + rec.z;
 }
 
 // Multi-GPU: turn gathered per-rank hit slots into one contiguous cloud.  Slot r (slot_words uint32 each)
@@ -749,6 +774,16 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
     hipLaunchKernelGGL(k_pack<true>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts,
                        next_block_counts, big_count, gt, reinterpret_cast<float4 *>(points32),
                        reinterpret_cast<uint4 *>(hits), n_points);
+}
+
+void launch_dense_from_hits(hipStream_t s, const SensorTables &tb, const void *hits, const uint32_t *n_points,
+                            const GeomTable &gt, float *t, uint32_t *gid)
+{
+    const uint32_t nq = tb.V * tb.naz;
+    if (!nq) return;
+    hipLaunchKernelGGL(k_dense_clear, dim3(blocks_for(nq)), dim3(kBlock), 0, s, nq, t, gid);
+    hipLaunchKernelGGL(k_dense_from_hits, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, static_cast<const uint4 *>(hits), n_points,
+                       gt, t, gid);
 }
 
 void launch_expand_slots(hipStream_t s, const SensorTables &tb, const uint32_t *gathered, uint32_t world, uint32_t cap,

@@ -92,6 +92,9 @@ struct ls_tracer {
     DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
     uint32_t *d_queue_heads = nullptr;
     uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 24;
+    bool traced_projection = false;        // the last trace ran on the projection engine (dense arrays on demand)
+    const void *last_d_hits = nullptr;     // its hit records and count (device)
+    const uint32_t *last_d_n = nullptr;
     std::vector<ls::GeomSource> project_srcs;  // scratch of trace_locked
     ls::RangeTree rt{};
     uint32_t range_entries = 0;
@@ -597,6 +600,9 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                              d_points, d_hits, d_n);
         mark(tr, 10);
         tr->frame_parity ^= 1u;
+        tr->traced_projection = true;
+        tr->last_d_hits = d_hits;
+        tr->last_d_n = d_n;
     } else {
         if (!tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "the BVH engine was selected after the last commit");
         LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
@@ -616,6 +622,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         gt.tri_first = tr->geom_table.p;
         gt.geom_ids = tr->geom_table.p + gt.n + 1;
         ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n);
+        tr->traced_projection = false;
         mark(tr, 10);
     }
     LS_HIP(hipGetLastError());
@@ -1019,6 +1026,15 @@ int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid)
     if (!tr->traced) {
         for (uint32_t q = 0; q < n; ++q) { t[q] = -1.0f; gid[q] = ls::kInvalid; }
         return LS_OK;
+    }
+    if (tr->traced_projection) {
+        // the projection engine keeps no dense arrays: rebuild them from the frame's hit records
+        ls::GeomTable gt;
+        gt.n = (uint32_t)tr->slot_geom_ids.size();
+        gt.tri_first = tr->geom_table.p;
+        gt.geom_ids = tr->geom_table.p + gt.n + 1;
+        ls::launch_dense_from_hits(tr->stream, tables(tr), tr->last_d_hits, tr->last_d_n, gt, tr->hit_t.p, tr->hit_gid.p);
+        LS_HIP(hipGetLastError());
     }
     LS_HIP(hipStreamSynchronize(tr->stream));
     LS_HIP(hipMemcpy(t, tr->hit_t.p, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -18,7 +18,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_]+)(<\w+>)?", name)
+    m = re.search(r"(k_[a-z_]+)(<[^>]*>)?", name)
     if m:
         return m.group(1) + (m.group(2) or "")
     m = re.search(r"wrapped_(\w+?)_config", name)
