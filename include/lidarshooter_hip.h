@@ -169,6 +169,20 @@ int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az);
 int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
                             void *d_hits, uint32_t *d_n_points);
 
+/* The step after the tracer: the sensor-frame cloud into the world frame, on the
+ * device.  Replaces CloudTransformer::applyInverseTransform (CloudTransformer.cpp:283-318) +
+ * LidarDevice::originToSensorInverse (LidarDevice.cpp:393-401): p_world = R * (T * p) + t for the
+ * x,y,z of every 32-byte point; T = affine3x4 (row-major, NULL = identity), R = the sensor's
+ * sensorToBase rotation (row-major; the handle only holds its inverse), t = the handle's translation.
+ * d_points32_in holds *d_n_points records (as ls_trace_scene_async leaves them); they are written to
+ * d_points32_out starting at record *d_out_base (NULL = 0) -- in == out with base 0 transforms in
+ * place -- and *d_out_total (NULL = not wanted) receives *d_out_base + *d_n_points, so the clouds of
+ * several sensors merge into one buffer by chaining total -> base.  Records that would not fit
+ * out_capacity are dropped.  Stream-ordered on the handle's stream. */
+int ls_cloud_to_world(ls_tracer *tr, const float *affine3x4, const float *R, const void *d_points32_in,
+                      const uint32_t *d_n_points, void *d_points32_out, const uint32_t *d_out_base,
+                      uint32_t *d_out_total, uint32_t out_capacity);
+
 /* Run all device work of this handle on `hip_stream` (a hipStream_t; NULL = the handle's own
  * stream).  Lets the caller order its collectives after ls_trace_scene_async. */
 int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream);

@@ -28,7 +28,7 @@ SYMBOLS = (
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
-    "ls_tracer_synchronize", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_tracer_set_option", "ls_get_timings",
+    "ls_tracer_synchronize", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_debug_dense_hits", "ls_debug_trace_bruteforce",
     "ls_debug_scene_size", "ls_debug_download_scene", "ls_debug_download_bvh",
 )
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
     L.ls_tracer_synchronize.argtypes = [vp]
     L.ls_tracer_set_output_buffers.argtypes = [vp, vp, vp, vp, u32]
     L.ls_expand_gathered_hits.argtypes = [vp, vp, u32, u32, vp, vp, vp]
+    L.ls_cloud_to_world.argtypes = [vp, f32p, f32p, vp, vp, vp, vp, vp, u32]
     L.ls_tracer_set_option.argtypes = [vp, i32, i32]
     L.ls_get_timings.argtypes = [vp, f32p]
     L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -274,6 +275,15 @@ class Tracer:
     def expandGatheredHits(self, d_gathered: int, world: int, capacity: int, d_points: int, d_hits: int, d_n: int):
         return self._check(self.L.ls_expand_gathered_hits(self.h, d_gathered, world, capacity, d_points, d_hits, d_n),
                            "ls_expand_gathered_hits")
+
+    def cloudToWorld(self, R, d_points_in: int, d_n_points: int, d_points_out: int, out_capacity: int, affine=None,
+                     d_out_base: int | None = None, d_out_total: int | None = None):
+        """ls_cloud_to_world: sensor-frame points (device) -> world frame, appended at *d_out_base."""
+        R = np.ascontiguousarray(R, np.float32).reshape(9)
+        A = None if affine is None else np.ascontiguousarray(affine, np.float32).reshape(12)
+        return self._check(self.L.ls_cloud_to_world(self.h, None if A is None else _f32p(A), _f32p(R), d_points_in, d_n_points,
+                                                    d_points_out, d_out_base, d_out_total, out_capacity),
+                           "ls_cloud_to_world")
 
     def setOption(self, option: int, value: int):
         return self._check(self.L.ls_tracer_set_option(self.h, option, value), "ls_tracer_set_option")

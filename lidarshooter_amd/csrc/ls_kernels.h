@@ -148,6 +148,9 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
                            uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,
                            unsigned long long *stats);
+// sensor -> world transform of a packed cloud (m.a = A, m.rinv = R, m.t = t); max_points bounds the grid
+void launch_cloud_to_world(hipStream_t s, const Affine &m, const void *in, const uint32_t *n_points, void *out,
+                           const uint32_t *out_base, uint32_t *out_total, uint32_t capacity, uint32_t max_points);
 // dense per-ray (t, global triangle id) arrays rebuilt from the packed hit records (debug view)
 void launch_dense_from_hits(hipStream_t s, const SensorTables &tb, const void *hits, const uint32_t *n_points,
                             const GeomTable &gt, float *t, uint32_t *gid);

@@ -547,6 +547,29 @@ __global__ __launch_bounds__(kBlock) void k_dense_from_hits(SensorTables tb, con
     gid[q] = gt.tri_first[lo] + rec.z;
 }
 
+// Sensor frame -> world frame for the x,y,z of 32-byte points: p_world = R * (A * p) + t
+// (CloudTransformer.cpp:283-318 + LidarDevice.cpp:393-401, same operation order as the oracle).
+// One thread per point; the count and the output offset are read on the device.
+__global__ __launch_bounds__(kBlock) void k_cloud_to_world(Affine m /* a = A, rinv = R, t */, const float4 *__restrict__ in,
+                                                           const uint32_t *__restrict__ n_points, float4 *__restrict__ out,
+                                                           const uint32_t *__restrict__ out_base, uint32_t *__restrict__ out_total,
+                                                           uint32_t capacity, uint32_t max_points)
+{
+    const uint32_t n = min(*n_points, max_points);
+    const uint32_t base = out_base ? *out_base : 0u;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0 && out_total) *out_total = min(base + n, max(capacity, base));
+    if (i >= n || base + i >= capacity) return;
+    const float4 p = in[2 * (size_t)i], rest = in[2 * (size_t)i + 1];
+    float q[3], w[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q[r] = ((m.a[4 * r + 0] * p.x + m.a[4 * r + 1] * p.y) + m.a[4 * r + 2] * p.z) + m.a[4 * r + 3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) w[r] = ((m.rinv[3 * r + 0] * q[0] + m.rinv[3 * r + 1] * q[1]) + m.rinv[3 * r + 2] * q[2]) + m.t[r];
+    out[2 * (size_t)(base + i)] = make_float4(w[0], w[1], w[2], p.w);
+    out[2 * (size_t)(base + i) + 1] = rest;
+}
+
 // Multi-GPU: turn gathered per-rank hit slots into one contiguous cloud.  Slot r (slot_words uint32 each)
 // = [n_r | 15 words pad | n_r..cap ls_hit records]; output = all records in rank order (ascending
 // azimuth sector) + their 32-byte points rebuilt from (ray, t): xyz = t * dir(ray) (EmbreeTracer.cpp:341-345).
@@ -774,6 +797,14 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
     hipLaunchKernelGGL(k_pack<true>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts,
                        next_block_counts, big_count, gt, reinterpret_cast<float4 *>(points32),
                        reinterpret_cast<uint4 *>(hits), n_points);
+}
+
+void launch_cloud_to_world(hipStream_t s, const Affine &m, const void *in, const uint32_t *n_points, void *out,
+                           const uint32_t *out_base, uint32_t *out_total, uint32_t capacity, uint32_t max_points)
+{
+    if (!max_points) return;
+    hipLaunchKernelGGL(k_cloud_to_world, dim3(blocks_for(max_points)), dim3(kBlock), 0, s, m, static_cast<const float4 *>(in),
+                       n_points, static_cast<float4 *>(out), out_base, out_total, capacity, max_points);
 }
 
 void launch_dense_from_hits(hipStream_t s, const SensorTables &tb, const void *hits, const uint32_t *n_points,

@@ -908,6 +908,26 @@ int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az)
     return LS_OK;
 }
 
+int ls_cloud_to_world(ls_tracer *tr, const float *affine3x4, const float *R, const void *d_points32_in,
+                      const uint32_t *d_n_points, void *d_points32_out, const uint32_t *d_out_base,
+                      uint32_t *d_out_total, uint32_t out_capacity)
+{
+    LS_ENTER(tr);
+    if (!R || !d_points32_in || !d_n_points || !d_points32_out)
+        return fail(tr, LS_ERR_INVALID_ARGUMENT, "R, the input cloud, its count and the output cloud are required");
+    static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    ls::Affine m;
+    std::memcpy(m.a, affine3x4 ? affine3x4 : kIdentity, sizeof(m.a));
+    std::memcpy(m.rinv, R, sizeof(m.rinv));
+    std::memcpy(m.t, tr->t, sizeof(m.t));
+    // a traced cloud never holds more points than the sensor has rays; a merged input may: bound by the capacity
+    const uint32_t max_points = std::max(out_capacity, tr->V * tr->H);
+    ls::launch_cloud_to_world(tr->stream, m, d_points32_in, d_n_points, d_points32_out, d_out_base, d_out_total, out_capacity,
+                              max_points);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
 int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream)
 {
     LS_ENTER(tr);

@@ -198,6 +198,26 @@ void lso_transform_vertices(const void *verts, uint32_t stride, uint32_t n, cons
     }
 }
 
+/* f-4  Sensor -> world cloud transform.  CloudTransformer.cpp:283-318 (applyInverseTransform):
+ * ptrans = T * p (Eigen Affine3f * Vector3f: linear*p + translation), then
+ * LidarDevice.cpp:393-401 (originToSensorInverse): p_world = R * ptrans + (tx,ty,tz).
+ * points: 32-byte XYZIR records (XYZIRPoint.hpp:11-35); only x,y,z (bytes 0..11) change, the
+ * other 20 bytes are copied.  in == out is allowed. */
+void lso_cloud_to_world(const uint8_t *points_in, uint32_t n, const float *A, const float *R, const float *t,
+                        uint8_t *points_out)
+{
+    for (uint32_t j = 0; j < n; ++j) {
+        float p[3], q[3], w[3];
+        memcpy(p, points_in + 32 * (size_t)j, 12);
+        for (int i = 0; i < 3; ++i)
+            q[i] = ((A[4 * i + 0] * p[0] + A[4 * i + 1] * p[1]) + A[4 * i + 2] * p[2]) + A[4 * i + 3];
+        for (int i = 0; i < 3; ++i)
+            w[i] = ((R[3 * i + 0] * q[0] + R[3 * i + 1] * q[1]) + R[3 * i + 2] * q[2]) + t[i];
+        if (points_out != points_in) memcpy(points_out + 32 * (size_t)j, points_in + 32 * (size_t)j, 32);
+        memcpy(points_out + 32 * (size_t)j, w, 12);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * a-6  Ray/triangle test (Embree 3.13.4 Moeller-Trumbore, see header) and closest hit.
  * ------------------------------------------------------------------------------------------ */

@@ -53,6 +53,7 @@ def lib() -> C.CDLL:
         L.lso_ray_dirs.argtypes = [f32p, C.c_uint32, C.c_float, C.c_float, C.c_uint32, f32p]
         L.lso_affine_from_components.argtypes = [f32p, f32p, f32p]
         L.lso_transform_vertices.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, f32p, f32p, f32p]
+        L.lso_cloud_to_world.argtypes = [u8p, C.c_uint32, f32p, f32p, f32p, u8p]
         L.lso_tri_intersect.argtypes = [f32p] * 5 + [f32p]
         L.lso_tri_intersect.restype = C.c_int
         L.lso_trace_bruteforce.argtypes = [f32p, C.c_uint32, f32p, u32p, C.c_uint32, f32p, u32p, C.c_int]
@@ -275,6 +276,17 @@ def transform_vertices(verts: np.ndarray, affine: np.ndarray, sensor: Sensor, st
     A = np.ascontiguousarray(affine, np.float32)
     lib().lso_transform_vertices(verts.ctypes.data, stride, n, _p(A, C.c_float), _p(sensor.Rinv, C.c_float),
                                  _p(sensor.t, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def cloud_to_world(points: np.ndarray, sensor: Sensor, affine: np.ndarray | None = None) -> np.ndarray:
+    """f-4: CloudTransformer::applyInverseTransform (CloudTransformer.cpp:283-318) of a cloud of 32-byte
+    XYZIR records: p_world = R * (T * p) + (tx, ty, tz) (LidarDevice.cpp:393-401).  -> uint8[n, 32]."""
+    pts = np.ascontiguousarray(points, np.uint8).reshape(-1, 32)
+    out = np.empty_like(pts)
+    A = np.ascontiguousarray(IDENTITY_AFFINE if affine is None else affine, np.float32)
+    lib().lso_cloud_to_world(_p(pts, C.c_uint8), pts.shape[0], _p(A, C.c_float), _p(sensor.R, C.c_float),
+                             _p(sensor.t, C.c_float), _p(out, C.c_uint8))
     return out
 
 

@@ -634,6 +634,58 @@ def test_expand_gathered_hits(oracle, capi, sensors, meshes):
         tr.close()
 
 
+def test_cloud_to_world_two_sensors_merged(oracle, capi, sensors, meshes):
+    """the traced clouds of lidar_0000 and lidar_0001 go from their sensor frames to
+    the world frame on the device (CloudTransformer::applyInverseTransform + originToSensorInverse)
+    and land back to back in one buffer; bytes equal the oracle's, in place and with a mesh-style affine."""
+    import torch
+    ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)]
+    cap = 2 * 4800
+    merged = torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0")
+    counts = torch.zeros(8, dtype=torch.int32, device="cuda:0")      # [total after sensor 0, total after sensor 1]
+    expect, trs = [], []
+    for k, uid in enumerate(("0000", "0001")):
+        s = sensors[uid]
+        tr = make_tracer(capi, s, "projection")
+        _add(tr, "ground", meshes["ground"])
+        _add(tr, "face", meshes["ben"])
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+        tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+        assert tr.commitScene() == 0
+        f = tr.traceSceneAsync(0)
+        base = None if k == 0 else counts.data_ptr()
+        tr.cloudToWorld(s.R, f.d_points32, f.d_n_points, merged.data_ptr(), cap, d_out_base=base,
+                        d_out_total=counts.data_ptr() + 4 * k)
+        tr.synchronize()
+        expect.append(oracle.cloud_to_world(oracle.trace_frame(s, ml)["points"], s))
+        trs.append(tr)
+    n0, n1 = int(counts[0].item()), int(counts[1].item())
+    assert (n0, n1 - n0) == (1781, 1769)
+    got = merged.cpu().numpy()[:32 * n1].reshape(n1, 32)
+    assert np.array_equal(got[:n0], expect[0]) and np.array_equal(got[n0:], expect[1])
+    # the world-frame ground points are on the ground plane again (ground.stl is z = 0)
+    z = got[:, 8:12].copy().view(np.float32).reshape(-1)
+    assert np.abs(z).min() < 1e-4
+    # in place on caller-owned buffers, with an affine in front (CloudTransformer's _transform) and a
+    # capacity smaller than the cloud: the first 1000 records move, the others stay
+    s, tr = sensors["0000"], trs[0]
+    A = oracle.affine_from_components(np.array([1.5, -2.0, 0.25], np.float32), np.array([0.1, -0.2, 0.3], np.float32))
+    pts = torch.zeros(32 * 4800, dtype=torch.uint8, device="cuda:0")
+    hts = torch.zeros(16 * 4800, dtype=torch.uint8, device="cuda:0")
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    tr.setOutputBuffers(pts.data_ptr(), hts.data_ptr(), cnt.data_ptr(), 4800)
+    tr.traceSceneAsync(1)
+    tr.cloudToWorld(s.R, pts.data_ptr(), cnt.data_ptr(), pts.data_ptr(), 1000, affine=A, d_out_total=cnt.data_ptr() + 4)
+    tr.synchronize()
+    local = oracle.trace_frame(s, ml)["points"]
+    want = oracle.cloud_to_world(local, s, A)
+    got = pts.cpu().numpy()[:32 * 1781].reshape(1781, 32)
+    assert cnt[:2].tolist() == [1781, 1000]
+    assert np.array_equal(got[:1000], want[:1000]) and np.array_equal(got[1000:], local[1000:])
+    for tr in trs:
+        tr.close()
+
+
 def test_edge_cases(oracle, capi, sensors, engine):
     """Degenerate inputs: one-triangle scene (a BVH with no internal node), coincident triangles in two
     geometries (equal t: lowest geomID wins), a geometry with zero triangles next to a real one, a

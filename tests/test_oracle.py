@@ -182,3 +182,27 @@ def test_vertex_stride(oracle, sensors, meshes):
     a = oracle.transform_vertices(v, oracle.IDENTITY_AFFINE, s)
     b = oracle.transform_vertices(rec, oracle.IDENTITY_AFFINE, s, stride=32)
     assert np.array_equal(a, b)
+
+
+def test_cloud_to_world_inverts_origin_to_sensor(oracle, sensors, meshes):
+    """f-4 (CloudTransformer.cpp:283-318, LidarDevice.cpp:393-401): the world-frame cloud of
+    lidar_0000 x ground lies on ground.stl's plane z = 0 again, only x,y,z change, and going through
+    transform_vertices (originToSensor) returns the sensor-frame points to float accuracy."""
+    s = sensors["0000"]
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    local = ref["points"]
+    world = oracle.cloud_to_world(local, s)
+    assert world.shape == local.shape == (1668, 32)
+    assert np.array_equal(world[:, 12:], local[:, 12:])
+    xyz_w = world[:, :12].copy().view(np.float32).reshape(-1, 3)
+    xyz_l = local[:, :12].copy().view(np.float32).reshape(-1, 3)
+    assert float(np.abs(xyz_w[:, 2]).max()) < 2e-4          # t ~ 17..76 m, float32
+    back = oracle.transform_vertices(xyz_w, oracle.IDENTITY_AFFINE, s)
+    assert float(np.abs(back - xyz_l).max()) < 1e-4
+    # with an affine in front: equals numpy's float32 evaluation in the reference's operation order
+    A = oracle.affine_from_components(np.array([1.0, 2.0, 3.0], np.float32), np.array([0.3, 0.2, 0.1], np.float32))
+    w2 = oracle.cloud_to_world(local, s, A)[:, :12].copy().view(np.float32).reshape(-1, 3)
+    A34, R = A.reshape(3, 4), s.R.reshape(3, 3)
+    q = ((A34[:, 0] * xyz_l[:, :1] + A34[:, 1] * xyz_l[:, 1:2]) + A34[:, 2] * xyz_l[:, 2:3]) + A34[:, 3]
+    w = ((R[:, 0] * q[:, :1] + R[:, 1] * q[:, 1:2]) + R[:, 2] * q[:, 2:3]) + s.t
+    assert np.array_equal(w.astype(np.float32), w2)
