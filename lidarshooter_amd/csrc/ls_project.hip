@@ -334,9 +334,13 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomBatch 
 }
 
 // Finish pass, one thread per ray: (1) triangles whose footprint was too large for one wave were
-// queued by k_project; here every ray walks that (normally empty) queue itself -- a gather, so no
-// atomics and no dependency between blocks -- and folds the hits into its own key; (2) hits per
-// 256-ray block, which the ordered pack needs.
+// queued by k_project; here every ray gathers from that (normally empty) queue itself -- no atomics,
+// no dependency between blocks -- and folds the hits into its own key.  A workgroup first culls the
+// queue against the rectangle of its 256 rays on the (elevation rank, column) raster, 1024 entries at
+// a time, so a ray only walks the footprints that reach its workgroup; (2) hits per 256-ray block,
+// which the ordered pack needs.
+constexpr uint32_t kCullChunk = 1024;
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_project_finish(ProjectParams pp, unsigned long long *__restrict__ best,
                                                            const BigItem *__restrict__ big, uint32_t big_capacity,
@@ -345,38 +349,77 @@ __global__ __launch_bounds__(kBlock) void k_project_finish(ProjectParams pp, uns
                                                            unsigned long long *__restrict__ stats)
 {
     __shared__ uint32_t s_cnt[kBlock / 64];
+    __shared__ uint32_t s_box[4][kBlock / 64];   // rank min / max, column min / max per wave
+    __shared__ uint16_t s_list[kCullChunk];
+    __shared__ uint32_t s_n;
     const uint32_t n = pp.tb.V * pp.tb.naz;
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t n_big = min(*big_count, big_capacity);
     bool hit = false;
-    if (q < n) {
-        unsigned long long key = best[q];
-        if (n_big) {
-            const uint32_t v = q / pp.tb.naz, h = pp.tb.az0 + (q - v * pp.tb.naz);
-            const uint32_t rank = pp.chan_rank[v];  // position of channel v in the elevation-sorted table
+    unsigned long long key = ~0ull;
+    if (q < n) key = best[q];
+    if (n_big) {   // uniform
+        uint32_t rank = 0, h = 0;
+        V3 d = {0.f, 0.f, 0.f};
+        uint32_t rmin = 0xFFFFFFFFu, rmax = 0, cmin = 0xFFFFFFFFu, cmax = 0;
+        if (q < n) {
+            const uint32_t v = q / pp.tb.naz;
+            h = pp.tb.az0 + (q - v * pp.tb.naz);
+            rank = pp.chan_rank[v];  // position of channel v in the elevation-sorted table
             const float st = pp.tb.sin_theta[v];
             const float2 cs = pp.tb.cs_phi[h];
-            const V3 d = {st * cs.x, st * cs.y, pp.tb.cos_theta[v]};
-            uint32_t ntest = 0;
-            for (uint32_t r = 0; r < n_big; ++r) {
-                const BigItem &it = big[r];
-                if (rank - it.i0 >= it.nch) continue;
-                if (h - it.h0a >= it.na && h - it.h0b >= it.nb) continue;
-                ++ntest;
-                float t;
-                if (tri_test(d, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
-                             it.NgC, t)) {
-                    const unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | it.gid;
-                    key = k2 < key ? k2 : key;
+            d = {st * cs.x, st * cs.y, pp.tb.cos_theta[v]};
+            rmin = rmax = rank;
+            cmin = cmax = h;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            rmin = min(rmin, (uint32_t)__shfl_xor(rmin, off)); rmax = max(rmax, (uint32_t)__shfl_xor(rmax, off));
+            cmin = min(cmin, (uint32_t)__shfl_xor(cmin, off)); cmax = max(cmax, (uint32_t)__shfl_xor(cmax, off));
+        }
+        if (lane == 0) { s_box[0][w] = rmin; s_box[1][w] = rmax; s_box[2][w] = cmin; s_box[3][w] = cmax; }
+        __syncthreads();
+        rmin = min(min(s_box[0][0], s_box[0][1]), min(s_box[0][2], s_box[0][3]));
+        rmax = max(max(s_box[1][0], s_box[1][1]), max(s_box[1][2], s_box[1][3]));
+        cmin = min(min(s_box[2][0], s_box[2][1]), min(s_box[2][2], s_box[2][3]));
+        cmax = max(max(s_box[3][0], s_box[3][1]), max(s_box[3][2], s_box[3][3]));
+        uint32_t ntest = 0;
+        for (uint32_t base = 0; base < n_big; base += kCullChunk) {
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+            const uint32_t m = min(kCullChunk, n_big - base);
+            for (uint32_t j = threadIdx.x; j < m; j += kBlock) {
+                const BigItem &it = big[base + j];
+                // [i0, i0+nch) x ([h0a, h0a+na) u [h0b, h0b+nb)) against [rmin, rmax] x [cmin, cmax]
+                const bool rows = it.i0 <= rmax && it.i0 + it.nch > rmin;
+                const bool cols = (it.na && it.h0a <= cmax && it.h0a + it.na > cmin) || (it.nb && it.h0b <= cmax && it.h0b + it.nb > cmin);
+                if (rows && cols) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)j;
+            }
+            __syncthreads();
+            const uint32_t cnt = s_n;
+            if (q < n) {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const BigItem &it = big[base + s_list[k]];
+                    if (rank - it.i0 >= it.nch) continue;
+                    if (h - it.h0a >= it.na && h - it.h0b >= it.nb) continue;
+                    ++ntest;
+                    float t;
+                    if (tri_test(d, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
+                                 it.NgC, t)) {
+                        const unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | it.gid;
+                        key = k2 < key ? k2 : key;
+                    }
                 }
             }
-            best[q] = key;
-            if (COUNT && ntest) atomicAdd(&stats[0], (unsigned long long)ntest);
+            __syncthreads();
         }
-        hit = key != ~0ull;
+        if (q < n) best[q] = key;
+        if (COUNT && ntest) atomicAdd(&stats[0], (unsigned long long)ntest);
     }
-    const unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    hit = q < n && key != ~0ull;
+    const unsigned long long mask = __ballot(hit);
+    if (lane == 0) s_cnt[w] = (uint32_t)__popcll(mask);
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }

@@ -225,7 +225,7 @@ int ensure_outputs(ls_tracer *tr)
         if ((rc = ensure(tr, tr->best_keys, nr))) return rc;
         if (tr->best_keys.cap != cap0) tr->keys_armed = false;
         if (!tr->big_queue.p) {
-            tr->big_capacity = 512u;  // every ray walks the whole queue: keep it short, overflow is expanded in place
+            tr->big_capacity = 2048u;  // culled per 256-ray workgroup in k_project_finish; overflow is expanded in place
             if ((rc = ensure(tr, tr->big_queue, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
         }
     } else {

@@ -556,6 +556,41 @@ def test_big_footprint_triangles(oracle, capi, sensors, engine):
     tr.close()
 
 
+def test_big_queue_chunks_and_overflow(oracle, capi, sensors, engine):
+    """2600 triangles that each cover hundreds of raster cells: more than one 1024-entry cull chunk of
+    the projection engine's big-footprint queue and more than its 2048 entries (the rest is expanded
+    by the streaming kernel itself); three frames, so the queue re-arms with a full load."""
+    s = _syn_sensor(oracle, sensors, V=64, H=512)
+    s = oracle.Sensor(uid="bigq", vertical=s.vertical, h_begin=s.h_begin, h_end=s.h_end, h_count=s.h_count,
+                      R=np.eye(3, dtype=np.float32).reshape(9), Rinv=np.eye(3, dtype=np.float32).reshape(9),
+                      t=np.zeros(3, np.float32))
+    rng = np.random.default_rng(2600)
+    n = 2600
+    c = rng.normal(0.0, 1.0, size=(n, 1, 3))
+    c[:, :, 2] *= 0.2                                       # around the horizon, where the channels are
+    dist = rng.uniform(8.0, 30.0, size=(n, 1, 1))
+    c = c / np.linalg.norm(c, axis=2, keepdims=True) * dist
+    tri = c + rng.normal(0.0, 1.0, size=(n, 3, 3)) * (0.12 * dist)   # ~14 degrees across: hundreds of cells, never near the origin
+    v = tri.reshape(-1, 3).astype(np.float32)
+    t = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    ml = [(0, v, t, oracle.IDENTITY_AFFINE)]
+    ref = oracle.trace_frame(s, ml)
+    assert int((ref["gid"] != oracle.INVALID).sum()) > 20000
+    assert len(np.unique(ref["gid"])) > 300                 # many different big triangles win somewhere
+    tr = make_tracer(capi, s, engine)
+    tr.addGeometry("m", v.shape[0], t.shape[0])
+    tr.updateGeometry("m", oracle.IDENTITY_AFFINE, v, t)
+    assert tr.commitScene() == 0
+    for frame in range(3):
+        rc, pts, hits = tr.traceScene(frame)
+        _assert_parity(oracle, s, tr, ml, pts, hits)
+    if engine == "projection":
+        tr.setOption(capi.LS_OPT_COUNT_VISITS, 1)
+        tr.traceScene(3)
+        assert tr.visitStats()[1] > 128 * 2048              # the queue was full: every entry has > 128 cells
+    tr.close()
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_projection_footprints_never_lose_a_hit(oracle, capi, sensors, seed):
     """Randomised stress of the projection engine's conservative footprints against the exhaustive
