@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one frame in flight (LS_OPT_PIPELINE off); default on a single GPU: two frames in flight")
     ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5"],
                     help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size; "
                          "cfg5 = configs[4] itself: one SYN-128 sensor per GPU on a 20 m circle over SYN-10M + ben "
@@ -178,12 +180,19 @@ def main():
         d_meshes.append((name, dv, dt))
     ident = capi.IDENTITY_AFFINE
     single = world == 1 or replicas
+    pipeline = single_gpu_pipeline = (world == 1 or replicas) and not args.no_pipeline and engine == "projection"
     if single:
-        # single GPU: [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap] in one caller-owned buffer
-        out_buf = torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=device)
-        base = out_buf.data_ptr()
-        tr.setOutputBuffers(base + 64, base + 64 + 32 * cap, base, cap)
-        count_words = [out_buf]
+        # single GPU: [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap] in caller-owned buffers, two of
+        # them: with two frames in flight (LS_OPT_PIPELINE) consecutive frames write alternate buffers
+        out_bufs = [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=device) for _ in range(2)]
+
+        def set_out(i):
+            base = out_bufs[i & 1].data_ptr()
+            tr.setOutputBuffers(base + 64, base + 64 + 32 * cap, base, cap)
+        set_out(0)
+        count_words = out_bufs
+        if pipeline:
+            tr.setOption(capi.LS_OPT_PIPELINE, 1)
     else:
         # N > 1: the travelling slot holds the count word and the 16-byte hit records only (shards.py);
         # two slots / two gather buffers alternate so that the all-gather of frame i overlaps frame i+1
@@ -207,6 +216,8 @@ def main():
             else:      # the mesh is read in place from the caller's HBM buffers (vertex transform fused into the trace)
                 tr.updateGeometryDeviceShared(name, ident, dv.data_ptr(), 12, dt.data_ptr())
         tr.commitScene()
+        if single:
+            set_out(i)
         tr.traceSceneAsync(i)
 
     def collect(b):
@@ -232,6 +243,8 @@ def main():
         if not single:
             collect(0)
             collect(1)
+        elif pipeline:
+            tr.flush()   # no-op while LS_OPT_PIPELINE is off
 
     def sync():
         flush()
@@ -275,6 +288,17 @@ def main():
     sync()
     tm = tr.timings()
     tr.setOption(capi.LS_OPT_TIMING, 0)
+
+    latency_frame_s = None
+    if pipeline:
+        # the same K frames with one frame in flight: what a consumer that needs every frame before the next sees
+        tr.setOption(capi.LS_OPT_PIPELINE, 0)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            frame(i)
+        sync()
+        latency_frame_s = (time.perf_counter() - t1) / args.steps
+        tr.setOption(capi.LS_OPT_PIPELINE, 1)
 
     breakdown = None
     if (args.breakdown or world == 1) and not replicas:
@@ -361,7 +385,9 @@ def main():
                                 "xt32": "XT-32 lidar_0000 x ground.stl+ben.stl"}[args.workload],
                    "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,
                    "frame": "updateGeometry(device, in place) + commitScene + traceScene"
-                            + (" (full BVH rebuild every frame)" if engine == "bvh" else ""),
+                            + (" (full BVH rebuild every frame)" if engine == "bvh" else "")
+                            + ("; two frames in flight (finish + pack of frame i overlap the triangle streaming of frame i+1)"
+                               if pipeline else ""),
                    "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
                                   f"hit-record slots per frame (overlapped with the next frame), cloud rebuilt on every rank"
                    if not single else ("single GPU" if world == 1 else
@@ -377,6 +403,8 @@ def main():
             "kernel_timing": "hipEvents on the tracer's stream around the kernel, in a second pass of the same K frames",
             "algorithmic_bytes_per_launch": b_launch}, **units),
     }
+    if latency_frame_s is not None:
+        out["ms_per_step_one_frame_in_flight"] = latency_frame_s * 1e3
     if breakdown is not None:
         out["stage_ms"] = {k: round(v, 5) for k, v in breakdown.items() if k != "frames"}
         out["copy_update_ms_per_step"] = copy_frame_s * 1e3

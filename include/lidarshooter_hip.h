@@ -187,6 +187,8 @@ int ls_cloud_to_world(ls_tracer *tr, const float *affine3x4, const float *R, con
  * stream).  Lets the caller order its collectives after ls_trace_scene_async. */
 int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream);
 int ls_tracer_synchronize(ls_tracer *tr);
+/* LS_OPT_PIPELINE: order the handle's stream after every frame still in flight (no host wait). */
+int ls_tracer_flush(ls_tracer *tr);
 
 /* Write packed points / hit records into caller-owned device buffers (capacity in records,
  * >= ls_total_rays of the shard) instead of the handle's own; NULL restores the default. */
@@ -197,6 +199,12 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1,2,4,8), default 1; takes effect at next commit  */
 #define LS_OPT_TIMING 2         /* 1: bracket every stage with hipEvents, 2: only the trace kernel        */
 #define LS_OPT_COUNT_VISITS 3   /* 1: trace kernel also counts node fetches / triangle tests              */
+#define LS_OPT_PIPELINE 6       /* 1: two frames in flight (projection engine, asynchronous API): finish + pack of a
+                                 * frame run on a second stream while the next frame's triangles are streamed.
+                                 * A frame's outputs are then ordered on the handle's stream only after the NEXT
+                                 * ls_trace_scene_async (or ls_tracer_flush / ls_tracer_synchronize), and the
+                                 * library's own output buffers alternate between two sets (a caller that sets
+                                 * output buffers alternates them itself).  Default 0.                          */
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LS_LIB_PATH") or os.path.join(_HERE, "liblidarshooter_hip.so")
 INVALID = 0xFFFFFFFF
 
-LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE = 1, 2, 3, 5
+LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPELINE = 1, 2, 3, 5, 6
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
 STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "trace_aux", "pack")
 
@@ -28,7 +28,7 @@ SYMBOLS = (
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
-    "ls_tracer_synchronize", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
+    "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_debug_dense_hits", "ls_debug_trace_bruteforce",
     "ls_debug_scene_size", "ls_debug_download_scene", "ls_debug_download_bvh",
 )
@@ -112,6 +112,7 @@ def load() -> C.CDLL:
     L.ls_tracer_set_output_buffers.argtypes = [vp, vp, vp, vp, u32]
     L.ls_expand_gathered_hits.argtypes = [vp, vp, u32, u32, vp, vp, vp]
     L.ls_cloud_to_world.argtypes = [vp, f32p, f32p, vp, vp, vp, vp, vp, u32]
+    L.ls_tracer_flush.argtypes = [vp]
     L.ls_tracer_set_option.argtypes = [vp, i32, i32]
     L.ls_get_timings.argtypes = [vp, f32p]
     L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -284,6 +285,9 @@ class Tracer:
         return self._check(self.L.ls_cloud_to_world(self.h, None if A is None else _f32p(A), _f32p(R), d_points_in, d_n_points,
                                                     d_points_out, d_out_base, d_out_total, out_capacity),
                            "ls_cloud_to_world")
+
+    def flush(self):
+        return self._check(self.L.ls_tracer_flush(self.h), "ls_tracer_flush")
 
     def setOption(self, option: int, value: int):
         return self._check(self.L.ls_tracer_set_option(self.h, option, value), "ls_tracer_set_option")

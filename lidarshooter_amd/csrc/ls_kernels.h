@@ -142,8 +142,26 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
 size_t project_big_item_bytes();
 void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,
                          uint32_t *block_counts2 /* two frame-parity arrays of ceil(rays/256) words */);
+// LS_OPT_PIPELINE: finish + pack of one frame as one set of workgroups (alone, or riding in the launch
+// of the next frame's k_project)
+struct FinishPackArgs {
+    unsigned long long *best;       // the frame's keys (re-armed here)
+    const void *big;                // its big-footprint queue
+    uint32_t big_capacity;
+    const uint32_t *big_count;      // its queue counter
+    uint32_t *rearm_big_count;      // the counter of the frame after the next: set to 0
+    unsigned long long *status;     // per workgroup (epoch << 32) | hits, for the chained prefix
+    uint32_t epoch;
+    GeomTable gt;
+    uint8_t *points32;
+    void *hits;
+    uint32_t *n_points;
+    uint32_t n_blocks;              // ceil(rays / 256)
+};
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
-                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats);
+                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats,
+                    const FinishPackArgs *rider = nullptr);
+void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats);
 // per ray: gather the queued big-footprint triangles, then hits per 256-ray block
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
                            uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,

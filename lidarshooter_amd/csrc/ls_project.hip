@@ -220,26 +220,33 @@ static_assert(sizeof(BigItem) == 80, "BigItem must be 80 bytes");
 // lanes (prefix sum + search), so a wave's cost is its total cell count / 64, not its largest
 // footprint.  Algorithmic bytes per triangle: 12 (indices) + 36 (vertex gather); per hit 8.
 // ------------------------------------------------------------------------------------------
+// LDS of a k_project workgroup (also the scratch of the finish + pack workgroups of k_frame)
+struct ProjectLds {
+    float tri[kBlock / 64][10][64];      // v0, e1, e2, NgC of the wave's triangles
+    uint32_t meta[kBlock / 64][6][64];   // gid, i0, h0a, na, h0b, nb
+    uint32_t pref[kBlock / 64][64];      // exclusive prefix of the cell counts
+};
+
 template <bool COUNT, bool LDS_TABLES, bool MULTI>
-__global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomBatch batch,
-                                                    unsigned long long *__restrict__ best, BigItem *__restrict__ big,
-                                                    uint32_t big_capacity, uint32_t *__restrict__ big_count,
-                                                    unsigned long long *__restrict__ stats)
+__device__ __forceinline__ void project_body(const ProjectParams &pp, const GeomBatch &batch, uint32_t block_idx, ProjectLds &lds,
+                                             float *s_chan /* LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm */,
+                                             unsigned long long *__restrict__ best, BigItem *__restrict__ big,
+                                             uint32_t big_capacity, uint32_t *__restrict__ big_count,
+                                             unsigned long long *__restrict__ stats)
 {
-    __shared__ float s_tri[kBlock / 64][10][64];      // v0, e1, e2, NgC of the wave's triangles
-    __shared__ uint32_t s_meta[kBlock / 64][6][64];   // gid, i0, h0a, na, h0b, nb
-    __shared__ uint32_t s_pref[kBlock / 64][64];      // exclusive prefix of the cell counts
-    extern __shared__ float s_chan[];                 // LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm
+    auto &s_tri = lds.tri;
+    auto &s_meta = lds.meta;
+    auto &s_pref = lds.pref;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     // one launch covers up to kGeomsPerLaunch geometries: the workgroup finds its own (uniform)
     uint32_t gi = 0;
     if (MULTI)
-        while (gi + 1u < batch.n && blockIdx.x >= batch.block_first[gi + 1u]) ++gi;
+        while (gi + 1u < batch.n && block_idx >= batch.block_first[gi + 1u]) ++gi;
     const GeomSource &src = batch.g[gi];
     // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
     // join the cell tests): its footprints are large, and the cells are what takes the time
     const uint32_t tris_per_wave = batch.tris_per_wave[gi];
-    const uint32_t block = MULTI ? blockIdx.x - batch.block_first[gi] : blockIdx.x;
+    const uint32_t block = MULTI ? block_idx - batch.block_first[gi] : block_idx;
     const uint32_t k = lane < tris_per_wave ? (block * (kBlock / 64) + w) * tris_per_wave + lane : 0xFFFFFFFFu;
     ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
     if (LDS_TABLES) {
@@ -333,6 +340,17 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomBatch 
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
 }
 
+template <bool COUNT, bool LDS_TABLES, bool MULTI>
+__global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomBatch batch,
+                                                    unsigned long long *__restrict__ best, BigItem *__restrict__ big,
+                                                    uint32_t big_capacity, uint32_t *__restrict__ big_count,
+                                                    unsigned long long *__restrict__ stats)
+{
+    __shared__ ProjectLds lds;
+    extern __shared__ float s_chan[];
+    project_body<COUNT, LDS_TABLES, MULTI>(pp, batch, blockIdx.x, lds, s_chan, best, big, big_capacity, big_count, stats);
+}
+
 // Finish pass, one thread per ray: (1) triangles whose footprint was too large for one wave were
 // queued by k_project; here every ray gathers from that (normally empty) queue itself -- no atomics,
 // no dependency between blocks -- and folds the hits into its own key.  A workgroup first culls the
@@ -424,6 +442,167 @@ __global__ __launch_bounds__(kBlock) void k_project_finish(ProjectParams pp, uns
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// ------------------------------------------------------------------------------------------
+// LS_OPT_PIPELINE: finish + pack of one frame as a single set of workgroups that can ride in the same
+// launch as the next frame's k_project (k_frame) -- one launch per frame instead of three, and the
+// tail of the triangle streaming is filled with the previous frame's per-ray work.
+// Per workgroup of 256 rays: the queue gather of k_project_finish, then the ordered pack of
+// k_pack<true>; hits before this workgroup = sum of the counts that the workgroups before it publish,
+// each tagged with the frame's epoch (no reset between frames).  A workgroup only ever waits for
+// lower-numbered ones of its own set, which the dispatcher started earlier (the chained-scan premise).
+// ------------------------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const FinishPackArgs &fa, uint32_t block_idx,
+                                                 uint32_t *scratch /* LDS, >= 560 words */,
+                                                 unsigned long long *__restrict__ stats)
+{
+    uint32_t *s_cnt = scratch;                                   // [4]
+    uint32_t *s_part = scratch + 4;                              // [4]
+    uint32_t(*s_box)[kBlock / 64] = reinterpret_cast<uint32_t(*)[kBlock / 64]>(scratch + 8);   // [4][4]
+    uint32_t *s_n = scratch + 24;
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(scratch + 32);   // [kCullChunk]
+    const SensorTables &tb = pp.tb;
+    unsigned long long *__restrict__ best = fa.best;
+    const BigItem *__restrict__ big = static_cast<const BigItem *>(fa.big);
+    const uint32_t n = tb.V * tb.naz;
+    const uint32_t q = block_idx * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t n_big = min(*fa.big_count, fa.big_capacity);
+    unsigned long long key = ~0ull;
+    uint32_t v = 0, h = 0, rank = 0;
+    V3 d = {0.f, 0.f, 0.f};
+    if (q < n) {
+        key = best[q];
+        best[q] = ~0ull;   // re-armed for the frame after the next
+        v = q / tb.naz;
+        h = tb.az0 + (q - v * tb.naz);
+        // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
+        const float st = tb.sin_theta[v];
+        const float2 cs = tb.cs_phi[h];
+        d = {st * cs.x, st * cs.y, tb.cos_theta[v]};
+    }
+    if (n_big) {   // uniform
+        uint32_t rmin = 0xFFFFFFFFu, rmax = 0, cmin = 0xFFFFFFFFu, cmax = 0;
+        if (q < n) {
+            rank = pp.chan_rank[v];  // position of channel v in the elevation-sorted table
+            rmin = rmax = rank;
+            cmin = cmax = h;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            rmin = min(rmin, (uint32_t)__shfl_xor(rmin, off)); rmax = max(rmax, (uint32_t)__shfl_xor(rmax, off));
+            cmin = min(cmin, (uint32_t)__shfl_xor(cmin, off)); cmax = max(cmax, (uint32_t)__shfl_xor(cmax, off));
+        }
+        if (lane == 0) { s_box[0][w] = rmin; s_box[1][w] = rmax; s_box[2][w] = cmin; s_box[3][w] = cmax; }
+        __syncthreads();
+        rmin = min(min(s_box[0][0], s_box[0][1]), min(s_box[0][2], s_box[0][3]));
+        rmax = max(max(s_box[1][0], s_box[1][1]), max(s_box[1][2], s_box[1][3]));
+        cmin = min(min(s_box[2][0], s_box[2][1]), min(s_box[2][2], s_box[2][3]));
+        cmax = max(max(s_box[3][0], s_box[3][1]), max(s_box[3][2], s_box[3][3]));
+        uint32_t ntest = 0;
+        for (uint32_t base = 0; base < n_big; base += kCullChunk) {
+            if (threadIdx.x == 0) *s_n = 0;
+            __syncthreads();
+            const uint32_t m = min(kCullChunk, n_big - base);
+            for (uint32_t j = threadIdx.x; j < m; j += kBlock) {
+                const BigItem &it = big[base + j];
+                const bool rows = it.i0 <= rmax && it.i0 + it.nch > rmin;
+                const bool cols = (it.na && it.h0a <= cmax && it.h0a + it.na > cmin) || (it.nb && it.h0b <= cmax && it.h0b + it.nb > cmin);
+                if (rows && cols) s_list[atomicAdd(s_n, 1u)] = (uint16_t)j;
+            }
+            __syncthreads();
+            const uint32_t cnt = *s_n;
+            if (q < n) {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const BigItem &it = big[base + s_list[k]];
+                    if (rank - it.i0 >= it.nch) continue;
+                    if (h - it.h0a >= it.na && h - it.h0b >= it.nb) continue;
+                    ++ntest;
+                    float t;
+                    if (tri_test(d, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
+                                 it.NgC, t)) {
+                        const unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | it.gid;
+                        key = k2 < key ? k2 : key;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (COUNT && ntest) atomicAdd(&stats[0], (unsigned long long)ntest);
+    }
+    const bool hit = key != ~0ull;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const uint32_t mine = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)fa.epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (block_idx == 0) *fa.rearm_big_count = 0u;   // the queue counter of the frame after the next: nobody reads it now
+    }
+    // hits of all workgroups before this one
+    uint32_t acc = 0;
+    bool stuck = false;
+    for (uint32_t i = threadIdx.x; i < block_idx; i += kBlock) {
+        unsigned long long st = __hip_atomic_load(&fa.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t spin = 0; (uint32_t)(st >> 32) != fa.epoch; ++spin) {
+            if (spin > (1u << 22)) { stuck = true; break; }   // never seen; keeps a broken premise from hanging the GPU
+            __builtin_amdgcn_s_sleep(1);
+            st = __hip_atomic_load(&fa.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        acc += (uint32_t)st;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    const bool any_stuck = __any(stuck);
+    if (lane == 0) s_part[w] = any_stuck ? 0xFFFFFFFFu : acc;
+    __syncthreads();
+    const bool bad = s_part[0] == 0xFFFFFFFFu || s_part[1] == 0xFFFFFFFFu || s_part[2] == 0xFFFFFFFFu || s_part[3] == 0xFFFFFFFFu;
+    uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (block_idx == fa.n_blocks - 1u && threadIdx.x == 0) *fa.n_points = bad ? 0u : base + mine;
+    if (bad) return;
+    for (uint32_t k = 0; k < w; ++k) base += s_cnt[k];
+    if (!hit) return;
+    const uint32_t dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t gid = (uint32_t)key;
+    const float t = __uint_as_float((uint32_t)(key >> 32));
+    float4 *__restrict__ points = reinterpret_cast<float4 *>(fa.points32);
+    uint4 *__restrict__ hits = reinterpret_cast<uint4 *>(fa.hits);
+    // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
+    points[2 * (size_t)dst] = make_float4(t * d.x, t * d.y, t * d.z, 0.0f);
+    points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+    // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
+    uint32_t lo = 0, hi = fa.gt.n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (fa.gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
+    }
+    hits[dst] = make_uint4(v * tb.H + h, fa.gt.geom_ids[lo], gid - fa.gt.tri_first[lo], __float_as_uint(t));
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_finish_pack(ProjectParams pp, FinishPackArgs fa, unsigned long long *__restrict__ stats)
+{
+    __shared__ uint32_t scratch[576];
+    finish_pack_body<COUNT>(pp, fa, blockIdx.x, scratch, stats);
+}
+
+// One launch per frame: the workgroups of this frame's k_project and of the previous frame's
+// finish + pack (FP_FIRST: those come first in the grid, otherwise last).
+template <bool LDS_TABLES, bool MULTI, bool FP_FIRST>
+__global__ __launch_bounds__(kBlock) void k_frame(ProjectParams pp, GeomBatch batch, uint32_t project_blocks,
+                                                  unsigned long long *__restrict__ best, BigItem *__restrict__ big,
+                                                  uint32_t big_capacity, uint32_t *__restrict__ big_count, FinishPackArgs fa)
+{
+    __shared__ ProjectLds lds;
+    extern __shared__ float s_chan[];
+    const bool is_fp = FP_FIRST ? blockIdx.x < fa.n_blocks : blockIdx.x >= project_blocks;
+    if (is_fp)
+        finish_pack_body<false>(pp, fa, FP_FIRST ? blockIdx.x : blockIdx.x - project_blocks, reinterpret_cast<uint32_t *>(&lds), nullptr);
+    else
+        project_body<false, LDS_TABLES, MULTI>(pp, batch, FP_FIRST ? blockIdx.x - fa.n_blocks : blockIdx.x, lds, s_chan, best, big,
+                                               big_capacity, big_count, nullptr);
+}
+
 }  // namespace
 
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
@@ -454,12 +633,13 @@ void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long l
 }
 
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
-                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats)
+                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats, const FinishPackArgs *rider)
 {
     if (!(pp.tb.V * pp.tb.naz)) return;
     // 64 triangles per wave when that still gives every SIMD a few waves; fewer for small meshes
     static const uint32_t min_tpw = getenv("LS_PROJECT_MIN_TPW") ? (uint32_t)std::max(1, atoi(getenv("LS_PROJECT_MIN_TPW"))) : 1u;
     static const uint32_t tpw_waves = getenv("LS_PROJECT_TPW_WAVES") ? (uint32_t)atoi(getenv("LS_PROJECT_TPW_WAVES")) : 8192u;
+    static const bool fp_first = getenv("LS_PROJECT_FP_FIRST") && atoi(getenv("LS_PROJECT_FP_FIRST")) != 0;
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
     uint32_t at = 0;
@@ -481,10 +661,26 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         }
         if (!batch.n) break;
         batch.block_first[batch.n] = blocks;
-        const dim3 grid(blocks);
         const bool multi = batch.n > 1;
+        const bool lt = pp.tb.V <= 2048u;   // channel tables fit in LDS (40 KB at most)
+        if (rider && !stats) {
+            // the previous frame's finish + pack workgroups ride in this launch (the first one of the frame)
+            const dim3 grid(blocks + rider->n_blocks);
+#define LS_FRAME(L, M, F) hipLaunchKernelGGL((k_frame<L, M, F>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, blocks, best, bq, big_capacity, big_count, *rider)
+            if (fp_first) {
+                if (lt) { if (multi) LS_FRAME(true, true, true); else LS_FRAME(true, false, true); }
+                else { if (multi) LS_FRAME(false, true, true); else LS_FRAME(false, false, true); }
+            } else {
+                if (lt) { if (multi) LS_FRAME(true, true, false); else LS_FRAME(true, false, false); }
+                else { if (multi) LS_FRAME(false, true, false); else LS_FRAME(false, false, false); }
+            }
+#undef LS_FRAME
+            rider = nullptr;
+            continue;
+        }
+        const dim3 grid(blocks);
 #define LS_LAUNCH(C, L, M) hipLaunchKernelGGL((k_project<C, L, M>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, best, bq, big_capacity, big_count, stats)
-        if (pp.tb.V <= 2048u) {  // channel tables fit in LDS (40 KB at most)
+        if (lt) {
             if (stats) { if (multi) LS_LAUNCH(true, true, true); else LS_LAUNCH(true, true, false); }
             else { if (multi) LS_LAUNCH(false, true, true); else LS_LAUNCH(false, true, false); }
         } else {
@@ -493,6 +689,14 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         }
 #undef LS_LAUNCH
     }
+    if (rider) launch_finish_pack(s, pp, *rider, stats);   // nothing was launched for it to ride with
+}
+
+void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats)
+{
+    if (!fa.n_blocks) return;
+    if (stats) hipLaunchKernelGGL(k_finish_pack<true>, dim3(fa.n_blocks), dim3(kBlock), 0, s, pp, fa, stats);
+    else hipLaunchKernelGGL(k_finish_pack<false>, dim3(fa.n_blocks), dim3(kBlock), 0, s, pp, fa, stats);
 }
 
 }  // namespace ls

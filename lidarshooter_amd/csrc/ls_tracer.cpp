@@ -92,6 +92,18 @@ struct ls_tracer {
     DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
     uint32_t *d_queue_heads = nullptr;
     uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 24;
+    // LS_OPT_PIPELINE: the finish + pack workgroups of frame i ride in the launch of frame i+1's k_project;
+    // everything a frame in flight touches exists twice (parity), the queue counter three times
+    int opt_pipeline = 0;
+    bool pipe_pending = false;              // a frame is projected, its finish + pack not launched yet
+    uint32_t pipe_seq = 0;                  // frames issued in pipelined mode since the last flush
+    ls::FinishPackArgs pipe_fa{};           // the pending frame's finish + pack
+    DevBuf<unsigned long long> pack_status; // chained prefix: (epoch << 32) | hits of every 256-ray workgroup
+    uint32_t pack_epoch = 0;
+    DevBuf<unsigned long long> best_keys_b; // parity 1 twins of best_keys, big_queue, points, hits, d_n_points
+    DevBuf<uint8_t> big_queue_b, points_b, hits_b;
+    uint32_t *d_n_points_b = nullptr;
+    bool keys_b_armed = false;
     bool traced_projection = false;        // the last trace ran on the projection engine (dense arrays on demand)
     const void *last_d_hits = nullptr;     // its hit records and count (device)
     const uint32_t *last_d_n = nullptr;
@@ -235,6 +247,39 @@ int ensure_outputs(ls_tracer *tr)
         if ((rc = ensure(tr, tr->points, nr * 32))) return rc;
         if ((rc = ensure(tr, tr->hits, nr * 16))) return rc;
     }
+    if (tr->opt_pipeline && use_projection(tr)) {
+        const size_t cap0 = tr->best_keys_b.cap;
+        if ((rc = ensure(tr, tr->best_keys_b, nr))) return rc;
+        if (tr->best_keys_b.cap != cap0) tr->keys_b_armed = false;
+        if (!tr->big_queue_b.p && (rc = ensure(tr, tr->big_queue_b, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
+        if (!tr->ext_points) {
+            if ((rc = ensure(tr, tr->points_b, nr * 32))) return rc;
+            if ((rc = ensure(tr, tr->hits_b, nr * 16))) return rc;
+        }
+        if (!tr->d_n_points_b) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_n_points_b), 4));
+        {
+            const size_t cap1 = tr->pack_status.cap;
+            if ((rc = ensure(tr, tr->pack_status, (nr + 255) / 256 + 1))) return rc;
+            if (tr->pack_status.cap != cap1) {   // fresh memory: no word may carry a live epoch tag
+                LS_HIP(hipMemsetAsync(tr->pack_status.p, 0, tr->pack_status.cap * 8, tr->stream));
+                tr->pack_epoch = 0;
+            }
+        }
+    }
+    return LS_OK;
+}
+
+ls::ProjectParams project_params(const ls_tracer *tr);
+
+// LS_OPT_PIPELINE: launch the finish + pack of the frame still in flight on its own
+int flush_pipeline(ls_tracer *tr)
+{
+    if (!tr->pipe_pending) return LS_OK;
+    ls::launch_finish_pack(tr->stream, project_params(tr), tr->pipe_fa, nullptr);
+    LS_HIP(hipGetLastError());
+    LS_HIP(hipMemsetAsync(tr->d_big_count, 0, 64, tr->stream));   // all queue counters: any mode may follow
+    tr->pipe_pending = false;
+    tr->pipe_seq = 0;
     return LS_OK;
 }
 
@@ -470,6 +515,9 @@ int commit_locked(ls_tracer *tr)
 
     int rc;
     if (relayout) {
+        // frames still in flight on the second stream read the old table
+        if ((rc = flush_pipeline(tr))) return rc;
+        LS_HIP(hipStreamSynchronize(tr->stream));
         std::vector<uint32_t> table(tfirst);
         for (int id : ids) table.push_back((uint32_t)id);
         if ((rc = ensure(tr, tr->geom_table, table.size()))) return rc;
@@ -559,10 +607,25 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         const ls::ProjectParams pp = project_params(tr);
         unsigned long long *stats = tr->opt_count ? tr->d_visits + 1 : nullptr;  // counts[1] = triangle tests
         const uint32_t n_blocks = (shard_rays(tr) + 255u) / 256u;
+        const bool pipelined = tr->opt_pipeline && !tr->opt_count && !tr->opt_timing;
+        if (!pipelined && (rc = flush_pipeline(tr))) return rc;
+        const uint32_t par = pipelined ? (tr->pipe_seq & 1u) : 0u;   // which twin of keys / queue / outputs this frame uses
+        unsigned long long *keys = par ? tr->best_keys_b.p : tr->best_keys.p;
+        void *bigq = par ? static_cast<void *>(tr->big_queue_b.p) : static_cast<void *>(tr->big_queue.p);
+        uint32_t *big_count = tr->d_big_count + (pipelined ? 4u * (tr->pipe_seq % 3u) : 0u);
+        if (par && !tr->ext_points) {
+            d_points = tr->points_b.p;
+            d_hits = tr->hits_b.p;
+            d_n = tr->d_n_points_b;
+        }
         if (!tr->keys_armed) {
             ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count, tr->row_counts.p);
             tr->keys_armed = true;
             tr->frame_parity = 0;
+        }
+        if (par && !tr->keys_b_armed) {
+            LS_HIP(hipMemsetAsync(tr->best_keys_b.p, 0xFF, (size_t)shard_rays(tr) * 8, s));
+            tr->keys_b_armed = true;
         }
         uint32_t *counts = tr->row_counts.p + (size_t)tr->frame_parity * n_blocks;
         uint32_t *next_counts = tr->row_counts.p + (size_t)(1u - tr->frame_parity) * n_blocks;
@@ -586,25 +649,50 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
             srcs.push_back(src);
         }
-        // one launch per 16 geometries (the descriptors travel as kernel arguments)
-        ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), tr->best_keys.p, tr->big_queue.p, tr->big_capacity,
-                           tr->d_big_count, stats);
-        mark(tr, 8);
-        ls::launch_project_finish(s, pp, tr->best_keys.p, tr->big_queue.p, tr->big_capacity, tr->d_big_count, counts, stats);
-        mark(tr, 9);
         ls::GeomTable gt;
         gt.n = (uint32_t)tr->slot_geom_ids.size();
         gt.tri_first = tr->geom_table.p;
         gt.geom_ids = tr->geom_table.p + gt.n + 1;
-        ls::launch_pack_keys(s, tb, tr->best_keys.p, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, tr->d_big_count, gt,
-                             d_points, d_hits, d_n);
-        mark(tr, 10);
-        tr->frame_parity ^= 1u;
+        if (pipelined) {
+            // one launch: this frame's k_project workgroups + the previous frame's finish + pack workgroups
+            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, nullptr,
+                               tr->pipe_pending ? &tr->pipe_fa : nullptr);
+            if (++tr->pack_epoch == 0u) {   // the epoch tag wrapped: no stale status word may match
+                LS_HIP(hipMemsetAsync(tr->pack_status.p, 0, tr->pack_status.cap * 8, s));
+                tr->pack_epoch = 1u;
+            }
+            ls::FinishPackArgs &fa = tr->pipe_fa;   // this frame's, launched with the next frame or by a flush
+            fa.best = keys;
+            fa.big = bigq;
+            fa.big_capacity = tr->big_capacity;
+            fa.big_count = big_count;
+            fa.rearm_big_count = tr->d_big_count + 4u * ((tr->pipe_seq + 2u) % 3u);
+            fa.status = tr->pack_status.p;
+            fa.epoch = tr->pack_epoch;
+            fa.gt = gt;
+            fa.points32 = d_points;
+            fa.hits = d_hits;
+            fa.n_points = d_n;
+            fa.n_blocks = n_blocks;
+            tr->pipe_pending = true;
+            ++tr->pipe_seq;
+            if (readback && (rc = flush_pipeline(tr))) return rc;
+        } else {
+            // one launch per 16 geometries (the descriptors travel as kernel arguments)
+            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats);
+            mark(tr, 8);
+            ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
+            mark(tr, 9);
+            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n);
+            mark(tr, 10);
+            tr->frame_parity ^= 1u;
+        }
         tr->traced_projection = true;
         tr->last_d_hits = d_hits;
         tr->last_d_n = d_n;
     } else {
         if (!tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "the BVH engine was selected after the last commit");
+        if ((rc = flush_pipeline(tr))) return rc;
         LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
         ls::RayQueues rq;
         rq.heads = tr->d_queue_heads;
@@ -728,6 +816,8 @@ void ls_tracer_destroy(ls_tracer *tr)
     (void)hipSetDevice(tr->device);
     if (tr->stream) (void)hipStreamSynchronize(tr->stream);
     for (auto &kv : tr->geoms) free_geometry(kv.second);
+    release(tr->best_keys_b); release(tr->big_queue_b); release(tr->points_b); release(tr->hits_b); release(tr->pack_status);
+    if (tr->d_n_points_b) (void)hipFree(tr->d_n_points_b);
     release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
     release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
     release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
@@ -901,10 +991,13 @@ int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az)
 {
     LS_ENTER(tr);
     if (n_az == 0 || first_az >= tr->H || n_az > tr->H - first_az) return fail(tr, LS_ERR_OUT_OF_RANGE, "shard outside [0, H)");
+    const int rc = flush_pipeline(tr);   // frames in flight keep their shard; the keys are re-armed behind them
+    if (rc) return rc;
     tr->az0 = first_az;
     tr->naz = n_az;
     tr->traced = false;
     tr->keys_armed = false;
+    tr->keys_b_armed = false;
     return LS_OK;
 }
 
@@ -931,6 +1024,8 @@ int ls_cloud_to_world(ls_tracer *tr, const float *affine3x4, const float *R, con
 int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream)
 {
     LS_ENTER(tr);
+    const int rc = flush_pipeline(tr);
+    if (rc) return rc;
     LS_HIP(hipStreamSynchronize(tr->stream));
     tr->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : tr->own_stream;
     return LS_OK;
@@ -939,8 +1034,16 @@ int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream)
 int ls_tracer_synchronize(ls_tracer *tr)
 {
     LS_ENTER(tr);
+    const int rc = flush_pipeline(tr);
+    if (rc) return rc;
     LS_HIP(hipStreamSynchronize(tr->stream));
     return LS_OK;
+}
+
+int ls_tracer_flush(ls_tracer *tr)
+{
+    LS_ENTER(tr);
+    return flush_pipeline(tr);
 }
 
 int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, uint32_t *d_n_points, uint32_t capacity)
@@ -974,6 +1077,12 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         tr->trec_open = false;
         return LS_OK;
     case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
+    case LS_OPT_PIPELINE: {
+        const int rc = flush_pipeline(tr);
+        if (rc) return rc;
+        tr->opt_pipeline = value != 0;
+        return LS_OK;
+    }
     case LS_OPT_ENGINE:
         if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "engine must be 0 (auto), 1 (BVH) or 2 (projection)");
         if (value == 2 && !tr->projection_ok) return fail(tr, LS_ERR_INVALID_ARGUMENT, "projection engine needs channel angles within [-90, 90] degrees");
@@ -1046,6 +1155,10 @@ int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid)
     if (!tr->traced) {
         for (uint32_t q = 0; q < n; ++q) { t[q] = -1.0f; gid[q] = ls::kInvalid; }
         return LS_OK;
+    }
+    {
+        const int rc = flush_pipeline(tr);
+        if (rc) return rc;
     }
     if (tr->traced_projection) {
         // the projection engine keeps no dense arrays: rebuild them from the frame's hit records

@@ -721,6 +721,70 @@ def test_cloud_to_world_two_sensors_merged(oracle, capi, sensors, meshes):
         tr.close()
 
 
+def test_pipelined_frames(oracle, capi, sensors, meshes):
+    """LS_OPT_PIPELINE: two frames in flight (finish + pack of frame i on the second stream while frame
+    i+1 streams its triangles).  An animated scene, caller-owned output buffers alternating A/B; every
+    frame is read after the next call (or the final flush) and equals the oracle; then the synchronous
+    API and a shard change on the same handle."""
+    import torch
+    from conftest import DATA
+    s = sensors["0001"]
+    poses = oracle.play_trajectory(os.path.join(DATA, "config", "trajectory.json"), 0.1)
+    tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_PIPELINE, 1)
+    _add(tr, "ground", meshes["ground"])
+    _add(tr, "face", meshes["ben"])
+    cap = s.V * s.H
+    bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0"), torch.zeros(16 * cap, dtype=torch.uint8, device="cuda:0"),
+             torch.zeros(4, dtype=torch.int32, device="cuda:0")) for _ in range(2)]
+    frames = list(range(0, 24))
+    expected = []
+
+    def check(i):
+        pts_t, hts_t, n_t = bufs[i & 1]
+        n = int(n_t[0].item())
+        ref = expected[i]
+        assert n == ref["points"].shape[0]
+        assert np.array_equal(pts_t.cpu().numpy()[:32 * n].reshape(n, 32), ref["points"])
+        assert np.array_equal(hts_t.cpu().numpy()[:16 * n].view(np.uint32).reshape(n, 4), ref["hits"])
+
+    stream = torch.cuda.Stream()
+    tr.setStream(stream.cuda_stream)
+    for i in frames:
+        lin, ang = poses[4 * i, :3] * np.float32(0.05), poses[4 * i, 3:]
+        A = oracle.affine_from_components(lin, ang)
+        expected.append(oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)]))
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+        tr.updateGeometryComponents("face", lin, ang, *meshes["ben"])
+        assert tr.commitScene() == 0
+        p, h, n = bufs[i & 1]
+        tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
+        tr.traceSceneAsync(i)
+        if i:                                               # frame i-1 is ordered on the handle's stream now
+            stream.synchronize()
+            check(i - 1)
+    tr.flush()
+    stream.synchronize()
+    check(frames[-1])
+    assert len({e["points"].shape[0] for e in expected}) > 3
+    # synchronous API on the pipelined handle, library-owned (twin) buffers, twice: both twins
+    tr.setOutputBuffers(None, None, None, 0)
+    ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)]
+    for k in range(3):
+        rc, pts, hits = tr.traceScene(100 + k)
+        _assert_parity(oracle, s, tr, ml, pts, hits)
+    # a shard change with frames in flight
+    tr.traceSceneAsync(200)
+    tr.setShard(10, 40)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(201)
+    ref = expected[-1]
+    cols = ref["hits"][:, 0] % s.H
+    keep = (cols >= 10) & (cols < 50)
+    assert np.array_equal(np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1), ref["hits"][keep])
+    tr.close()
+
+
 def test_edge_cases(oracle, capi, sensors, engine):
     """Degenerate inputs: one-triangle scene (a BVH with no internal node), coincident triangles in two
     geometries (equal t: lowest geomID wins), a geometry with zero triangles next to a real one, a
