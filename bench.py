@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--prime-ms", type=int, default=150,
+                    help="untimed frames for this long before the W warm-up steps (runtime one-off stalls, clocks)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one frame in flight (LS_OPT_PIPELINE off); default on a single GPU: two frames in flight")
     ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5"],
@@ -264,6 +266,17 @@ def main():
     info = tr.sceneSize()
     n_tris_total = info["n_tris"]
 
+    # The HIP runtime stalls one enqueue call for 30-40 ms once per process, some 15-25 ms after a stream
+    # starts to be fed continuously (tools/long_run.py: window 2 of 16, both frame modes); priming gets that
+    # one-off event out of the way of the W warm-up and K timed frames, whatever W the caller chose
+    prime = max(0, args.prime_ms) * 1e-3
+    t_prime = time.perf_counter()
+    i = 0
+    while time.perf_counter() - t_prime < prime:
+        for _ in range(50):
+            frame(i)
+            i += 1
+        sync()
     for i in range(args.warmup):
         frame(i)
     sync()

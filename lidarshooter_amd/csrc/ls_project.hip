@@ -539,14 +539,20 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
         __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)fa.epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (block_idx == 0) *fa.rearm_big_count = 0u;   // the queue counter of the frame after the next: nobody reads it now
     }
-    // hits of all workgroups before this one
+    // hits of all workgroups before this one.  Waiting is rare (every workgroup publishes within a few
+    // microseconds of its neighbours unless the queue gather is heavy) and must stay cheap for the ones
+    // still working: the polls back off quickly (s_sleep 1, 4, 16, 64, 127, 127, ... x 64 cycles)
     uint32_t acc = 0;
     bool stuck = false;
     for (uint32_t i = threadIdx.x; i < block_idx; i += kBlock) {
         unsigned long long st = __hip_atomic_load(&fa.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint32_t spin = 0; (uint32_t)(st >> 32) != fa.epoch; ++spin) {
-            if (spin > (1u << 22)) { stuck = true; break; }   // never seen; keeps a broken premise from hanging the GPU
-            __builtin_amdgcn_s_sleep(1);
+            if (spin > (1u << 18)) { stuck = true; break; }   // ~1 s; never seen; keeps a broken premise from hanging the GPU
+            if (spin == 0) __builtin_amdgcn_s_sleep(1);
+            else if (spin == 1) __builtin_amdgcn_s_sleep(4);
+            else if (spin == 2) __builtin_amdgcn_s_sleep(16);
+            else if (spin == 3) __builtin_amdgcn_s_sleep(64);
+            else __builtin_amdgcn_s_sleep(127);
             st = __hip_atomic_load(&fa.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         acc += (uint32_t)st;
@@ -586,21 +592,21 @@ __global__ __launch_bounds__(kBlock) void k_finish_pack(ProjectParams pp, Finish
     finish_pack_body<COUNT>(pp, fa, blockIdx.x, scratch, stats);
 }
 
-// One launch per frame: the workgroups of this frame's k_project and of the previous frame's
-// finish + pack (FP_FIRST: those come first in the grid, otherwise last).
-template <bool LDS_TABLES, bool MULTI, bool FP_FIRST>
-__global__ __launch_bounds__(kBlock) void k_frame(ProjectParams pp, GeomBatch batch, uint32_t project_blocks,
+// One launch per frame: the workgroups of this frame's k_project and, from workgroup fp_start on, those
+// of the previous frame's finish + pack (contiguous and in order, as their chained prefix needs).
+template <bool LDS_TABLES, bool MULTI>
+__global__ __launch_bounds__(kBlock) void k_frame(ProjectParams pp, GeomBatch batch, uint32_t fp_start,
                                                   unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                                   uint32_t big_capacity, uint32_t *__restrict__ big_count, FinishPackArgs fa)
 {
     __shared__ ProjectLds lds;
     extern __shared__ float s_chan[];
-    const bool is_fp = FP_FIRST ? blockIdx.x < fa.n_blocks : blockIdx.x >= project_blocks;
-    if (is_fp)
-        finish_pack_body<false>(pp, fa, FP_FIRST ? blockIdx.x : blockIdx.x - project_blocks, reinterpret_cast<uint32_t *>(&lds), nullptr);
+    const uint32_t rel = blockIdx.x - fp_start;
+    if (rel < fa.n_blocks)
+        finish_pack_body<false>(pp, fa, rel, reinterpret_cast<uint32_t *>(&lds), nullptr);
     else
-        project_body<false, LDS_TABLES, MULTI>(pp, batch, FP_FIRST ? blockIdx.x - fa.n_blocks : blockIdx.x, lds, s_chan, best, big,
-                                               big_capacity, big_count, nullptr);
+        project_body<false, LDS_TABLES, MULTI>(pp, batch, blockIdx.x < fp_start ? blockIdx.x : blockIdx.x - fa.n_blocks, lds, s_chan, best,
+                                               big, big_capacity, big_count, nullptr);
 }
 
 }  // namespace
@@ -639,7 +645,7 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
     // 64 triangles per wave when that still gives every SIMD a few waves; fewer for small meshes
     static const uint32_t min_tpw = getenv("LS_PROJECT_MIN_TPW") ? (uint32_t)std::max(1, atoi(getenv("LS_PROJECT_MIN_TPW"))) : 1u;
     static const uint32_t tpw_waves = getenv("LS_PROJECT_TPW_WAVES") ? (uint32_t)atoi(getenv("LS_PROJECT_TPW_WAVES")) : 8192u;
-    static const bool fp_first = getenv("LS_PROJECT_FP_FIRST") && atoi(getenv("LS_PROJECT_FP_FIRST")) != 0;
+    static const int fp_at = getenv("LS_PROJECT_FP_AT") ? atoi(getenv("LS_PROJECT_FP_AT")) : -1;
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
     uint32_t at = 0;
@@ -666,14 +672,11 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         if (rider && !stats) {
             // the previous frame's finish + pack workgroups ride in this launch (the first one of the frame)
             const dim3 grid(blocks + rider->n_blocks);
-#define LS_FRAME(L, M, F) hipLaunchKernelGGL((k_frame<L, M, F>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, blocks, best, bq, big_capacity, big_count, *rider)
-            if (fp_first) {
-                if (lt) { if (multi) LS_FRAME(true, true, true); else LS_FRAME(true, false, true); }
-                else { if (multi) LS_FRAME(false, true, true); else LS_FRAME(false, false, true); }
-            } else {
-                if (lt) { if (multi) LS_FRAME(true, true, false); else LS_FRAME(true, false, false); }
-                else { if (multi) LS_FRAME(false, true, false); else LS_FRAME(false, false, false); }
-            }
+            // where the riders sit in the grid: behind the triangle workgroups by default (they fill the tail)
+            const uint32_t fp_start = fp_at < 0 ? blocks : std::min((uint32_t)fp_at, blocks);
+#define LS_FRAME(L, M) hipLaunchKernelGGL((k_frame<L, M>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, fp_start, best, bq, big_capacity, big_count, *rider)
+            if (lt) { if (multi) LS_FRAME(true, true); else LS_FRAME(true, false); }
+            else { if (multi) LS_FRAME(false, true); else LS_FRAME(false, false); }
 #undef LS_FRAME
             rider = nullptr;
             continue;

@@ -247,7 +247,7 @@ int ensure_outputs(ls_tracer *tr)
         if ((rc = ensure(tr, tr->points, nr * 32))) return rc;
         if ((rc = ensure(tr, tr->hits, nr * 16))) return rc;
     }
-    if (tr->opt_pipeline && use_projection(tr)) {
+    if ((tr->opt_pipeline || tr->pipe_seq) && use_projection(tr)) {   // twins: needed as long as the rotation may stand on parity 1
         const size_t cap0 = tr->best_keys_b.cap;
         if ((rc = ensure(tr, tr->best_keys_b, nr))) return rc;
         if (tr->best_keys_b.cap != cap0) tr->keys_b_armed = false;
@@ -277,9 +277,7 @@ int flush_pipeline(ls_tracer *tr)
     if (!tr->pipe_pending) return LS_OK;
     ls::launch_finish_pack(tr->stream, project_params(tr), tr->pipe_fa, nullptr);
     LS_HIP(hipGetLastError());
-    LS_HIP(hipMemsetAsync(tr->d_big_count, 0, 64, tr->stream));   // all queue counters: any mode may follow
-    tr->pipe_pending = false;
-    tr->pipe_seq = 0;
+    tr->pipe_pending = false;   // pipe_seq goes on: the next frame, in any mode, takes the next twin and queue counter
     return LS_OK;
 }
 
@@ -609,10 +607,13 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         const uint32_t n_blocks = (shard_rays(tr) + 255u) / 256u;
         const bool pipelined = tr->opt_pipeline && !tr->opt_count && !tr->opt_timing;
         if (!pipelined && (rc = flush_pipeline(tr))) return rc;
-        const uint32_t par = pipelined ? (tr->pipe_seq & 1u) : 0u;   // which twin of keys / queue / outputs this frame uses
+        // which twin of keys / queue / outputs and which of the three queue counters this frame uses: pipe_seq
+        // counts the pipelined frames; a frame that is not pipelined re-arms what it used itself and leaves
+        // pipe_seq alone, so the rotation stays consistent across mode changes
+        const uint32_t par = tr->pipe_seq & 1u;
         unsigned long long *keys = par ? tr->best_keys_b.p : tr->best_keys.p;
         void *bigq = par ? static_cast<void *>(tr->big_queue_b.p) : static_cast<void *>(tr->big_queue.p);
-        uint32_t *big_count = tr->d_big_count + (pipelined ? 4u * (tr->pipe_seq % 3u) : 0u);
+        uint32_t *big_count = tr->d_big_count + 4u * (tr->pipe_seq % 3u);
         if (par && !tr->ext_points) {
             d_points = tr->points_b.p;
             d_hits = tr->hits_b.p;
