@@ -220,12 +220,41 @@ static_assert(sizeof(BigItem) == 80, "BigItem must be 80 bytes");
 // lanes (prefix sum + search), so a wave's cost is its total cell count / 64, not its largest
 // footprint.  Algorithmic bytes per triangle: 12 (indices) + 36 (vertex gather); per hit 8.
 // ------------------------------------------------------------------------------------------
+// Inclusive prefix sum over the 64 lanes of a wave with DPP (row shifts inside each row of 16, then the
+// two row broadcasts): twelve dependent vector instructions, no LDS round trips (a __shfl_up ladder is
+// six ds_bpermute round trips; measured -0.8 us on the headline k_project).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)v;
+}
+
 // LDS of a k_project workgroup (also the scratch of the finish + pack workgroups of k_frame)
 struct ProjectLds {
     float tri[kBlock / 64][10][64];      // v0, e1, e2, NgC of the wave's triangles
     uint32_t meta[kBlock / 64][6][64];   // gid, i0, h0a, na, h0b, nb
-    uint32_t pref[kBlock / 64][64];      // exclusive prefix of the cell counts
+    uint32_t pref[kBlock / 64][64];      // first cell of every staged footprint (exclusive prefix of the cell counts)
+    uint8_t flag[kBlock / 64][64];       // expansion: 1 at the first cell of a footprint inside the current 64-cell chunk
 };
+
+// orders this wave's LDS writes before its later LDS reads (LDS executes a wave's operations in order;
+// the fence only stops the compiler from moving them)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
 template <bool COUNT, bool LDS_TABLES, bool MULTI>
 __device__ __forceinline__ void project_body(const ProjectParams &pp, const GeomBatch &batch, uint32_t block_idx, ProjectLds &lds,
@@ -261,7 +290,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V)};
         __syncthreads();
     }
-    uint32_t cells = 0;
+    uint32_t cells = 0, slot = 0;
     if (k < src.ntris) {
         const uint32_t a = src.idx[3 * (size_t)k + 0], b = src.idx[3 * (size_t)k + 1], c = src.idx[3 * (size_t)k + 2];
         V3 v0, v1, v2;
@@ -305,37 +334,46 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             if (queued) {
                 cells = 0;
             } else {
-                s_tri[w][0][lane] = v0.x; s_tri[w][1][lane] = v0.y; s_tri[w][2][lane] = v0.z;
-                s_tri[w][3][lane] = e1.x; s_tri[w][4][lane] = e1.y; s_tri[w][5][lane] = e1.z;
-                s_tri[w][6][lane] = e2.x; s_tri[w][7][lane] = e2.y; s_tri[w][8][lane] = e2.z;
-                s_tri[w][9][lane] = NgC;
-                s_meta[w][0][lane] = gid; s_meta[w][1][lane] = f.i0; s_meta[w][2][lane] = f.h0a;
-                s_meta[w][3][lane] = f.na; s_meta[w][4][lane] = f.h0b; s_meta[w][5][lane] = f.nb;
+                // the lanes in this branch are exactly the footprints the wave expands itself: they are
+                // staged packed to the front (slot = rank among them), which makes "the footprint that
+                // owns cell j" a rank, computable with a ballot (below)
+                slot = lanes_below(__ballot(true));
+                s_tri[w][0][slot] = v0.x; s_tri[w][1][slot] = v0.y; s_tri[w][2][slot] = v0.z;
+                s_tri[w][3][slot] = e1.x; s_tri[w][4][slot] = e1.y; s_tri[w][5][slot] = e1.z;
+                s_tri[w][6][slot] = e2.x; s_tri[w][7][slot] = e2.y; s_tri[w][8][slot] = e2.z;
+                s_tri[w][9][slot] = NgC;
+                s_meta[w][0][slot] = gid; s_meta[w][1][slot] = f.i0; s_meta[w][2][slot] = f.h0a;
+                s_meta[w][3][slot] = f.na; s_meta[w][4][slot] = f.h0b; s_meta[w][5][slot] = f.nb;
             }
         }
     }
     // wave-level inclusive scan of the cell counts
-    uint32_t incl = cells;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off);
-        if (lane >= (uint32_t)off) incl += up;
-    }
-    const uint32_t total = __shfl(incl, 63);
-    s_pref[w][lane] = incl - cells;
-    __syncthreads();
-    for (uint32_t j = lane; j < total; j += 64u) {
-        // the triangle that owns cell j: last lane whose exclusive prefix is <= j
-        uint32_t lo = 0, hi = 64;
-        while (hi - lo > 1) {
-            const uint32_t m = (lo + hi) >> 1;
-            if (s_pref[w][m] <= j) lo = m; else hi = m;
+    const uint32_t incl = wave_inclusive_scan(cells);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t n_slots = (uint32_t)__popcll(__ballot(cells != 0));
+    if (cells) s_pref[w][slot] = incl - cells;
+    wave_lds_fence();
+    // lane s < n_slots holds the first cell of staged footprint s
+    const uint32_t first = lane < n_slots ? s_pref[w][lane] : 0xFFFFFFFFu;
+    for (uint32_t jb = 0; jb < total; jb += 64u) {
+        // the footprint that owns cell jb + lane, by rank: footprints that started before this chunk +
+        // starts inside the chunk up to this lane (a flag per first cell, then one ballot) - 1
+        lds.flag[w][lane] = 0;
+        wave_lds_fence();
+        if (first - jb < 64u) lds.flag[w][first - jb] = 1;
+        wave_lds_fence();
+        const uint32_t before = (uint32_t)__popcll(__ballot(first < jb));
+        const unsigned long long starts = __ballot(lds.flag[w][lane] != 0);
+        const uint32_t j = jb + lane;
+        if (j < total) {
+            const uint32_t lo = before + lanes_below(starts) + (uint32_t)((starts >> lane) & 1ull) - 1u;
+            const uint32_t m = j - s_pref[w][lo];
+            uint32_t v, h;
+            foot_cell(ct, s_meta[w][1][lo], s_meta[w][2][lo], s_meta[w][3][lo], s_meta[w][4][lo], s_meta[w][5][lo], m, v, h);
+            test_cell(pp, ct, {s_tri[w][0][lo], s_tri[w][1][lo], s_tri[w][2][lo]}, {s_tri[w][3][lo], s_tri[w][4][lo], s_tri[w][5][lo]},
+                      {s_tri[w][6][lo], s_tri[w][7][lo], s_tri[w][8][lo]}, s_tri[w][9][lo], s_meta[w][0][lo], v, h, best);
         }
-        const uint32_t m = j - s_pref[w][lo];
-        uint32_t v, h;
-        foot_cell(ct, s_meta[w][1][lo], s_meta[w][2][lo], s_meta[w][3][lo], s_meta[w][4][lo], s_meta[w][5][lo], m, v, h);
-        test_cell(pp, ct, {s_tri[w][0][lo], s_tri[w][1][lo], s_tri[w][2][lo]}, {s_tri[w][3][lo], s_tri[w][4][lo], s_tri[w][5][lo]},
-                  {s_tri[w][6][lo], s_tri[w][7][lo], s_tri[w][8][lo]}, s_tri[w][9][lo], s_meta[w][0][lo], v, h, best);
+        wave_lds_fence();
     }
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
 }
