@@ -85,6 +85,8 @@ struct ProjectParams {
     float begin_deg, step_deg;     // azimuth of column h = begin + step*h (LidarDevice.cpp:306)
     float inv_step_deg, inv_period; // 1/step and |step|/360 (0 when step is 0)
     float margin_deg;              // angular slack of the footprint bounds
+    int sector_on;                 // the shard covers less than 180 degrees of azimuth: sec_a / sec_b are valid
+    float sec_a[2], sec_b[2];      // unit vectors (cos, sin) of the padded sector's first / second boundary, counter-clockwise
     uint32_t big_cells;            // footprints above this many cells go to the gather queue
     int debug;                     // diagnostic: 1 = stop after the vertex loads, 2 = after the footprints
 };

@@ -309,7 +309,19 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             v0 = {pa[0], pa[1], pa[2]}; v1 = {pb[0], pb[1], pb[2]}; v2 = {pc[0], pc[1], pc[2]};
         }
         if (pp.debug == 1) { if (v0.x + v1.y + v2.z == 12345.678f) best[0] = 0; return; }
-        const Foot f = footprint(pp, ct, v0, v1, v2);
+        // multi-GPU shards: a triangle wholly on the outer side of one of the two vertical planes that bound
+        // the shard's azimuth sector (padded; only when the sector is narrower than 180 degrees) cannot be hit
+        // by its rays.  Meshes are spatially coherent, so whole waves skip the footprint and the cell tests.
+        bool outside = false;
+        if (pp.sector_on) {
+            const float a0 = pp.sec_a[0] * v0.y - pp.sec_a[1] * v0.x, a1 = pp.sec_a[0] * v1.y - pp.sec_a[1] * v1.x,
+                        a2 = pp.sec_a[0] * v2.y - pp.sec_a[1] * v2.x;   // cross(d_a, p): < 0 right of the first boundary
+            const float b0 = v0.x * pp.sec_b[1] - v0.y * pp.sec_b[0], b1 = v1.x * pp.sec_b[1] - v1.y * pp.sec_b[0],
+                        b2 = v2.x * pp.sec_b[1] - v2.y * pp.sec_b[0];   // cross(p, d_b): < 0 left of the second boundary
+            outside = (a0 < 0.0f && a1 < 0.0f && a2 < 0.0f) || (b0 < 0.0f && b1 < 0.0f && b2 < 0.0f);
+        }
+        Foot f = {0, 0, 0, 0, 0, 0};
+        if (!outside) f = footprint(pp, ct, v0, v1, v2);
         cells = f.nch * (f.na + f.nb);
         if (pp.debug == 2) { if (cells == 0xFFFFFFFFu) best[0] = 0; return; }
         if (cells) {

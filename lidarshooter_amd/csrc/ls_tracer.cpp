@@ -214,6 +214,22 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     pp.inv_step_deg = pp.step_deg != 0.0f ? 1.0f / pp.step_deg : 0.0f;
     pp.inv_period = std::fabs(pp.step_deg) / 360.0f;
     pp.margin_deg = kProjectMarginDeg;
+    // azimuth sector of the shard, padded by the angular margin and 1.5 columns per side, as two boundary
+    // directions in counter-clockwise order; used to reject triangles early when it spans less than 180 degrees
+    pp.sector_on = 0;
+    pp.sec_a[0] = pp.sec_a[1] = pp.sec_b[0] = pp.sec_b[1] = 0.0f;
+    if (tr->naz < tr->H && pp.step_deg != 0.0f) {
+        const double step = pp.step_deg, pad = kProjectMarginDeg + 1.5 * std::fabs(step);
+        double lo = (double)tr->h_begin + step * (double)tr->az0, hi = (double)tr->h_begin + step * (double)(tr->az0 + tr->naz - 1u);
+        if (lo > hi) std::swap(lo, hi);
+        lo -= pad;
+        hi += pad;
+        if (hi - lo < 179.0) {
+            pp.sector_on = 1;
+            pp.sec_a[0] = (float)std::cos(lo * M_PI / 180.0); pp.sec_a[1] = (float)std::sin(lo * M_PI / 180.0);
+            pp.sec_b[0] = (float)std::cos(hi * M_PI / 180.0); pp.sec_b[1] = (float)std::sin(hi * M_PI / 180.0);
+        }
+    }
     pp.big_cells = getenv("LS_PROJECT_BIG_CELLS") ? (uint32_t)atoi(getenv("LS_PROJECT_BIG_CELLS")) : 128u;
     pp.debug = getenv("LS_PROJECT_DEBUG") ? atoi(getenv("LS_PROJECT_DEBUG")) : 0;
     return pp;
