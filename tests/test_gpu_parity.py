@@ -396,6 +396,24 @@ def test_many_geometries_one_frame(oracle, capi, sensors, engine):
     rc, pts, hits = tr.traceScene(0)
     ref = _assert_parity(oracle, s, tr, ml, pts, hits)
     assert len(set(ref["hits"][:, 1].tolist())) >= 3       # the cloud mixes several geometries
+    if engine == "projection":
+        # the same scene with two frames in flight: three launches per frame here (16 + 16 + 5 geometries),
+        # the previous frame's finish + pack ride in the first of them
+        import torch
+        tr.setOption(capi.LS_OPT_PIPELINE, 1)
+        cap = s.V * s.H
+        bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0"), torch.zeros(16 * cap, dtype=torch.uint8, device="cuda:0"),
+                 torch.zeros(4, dtype=torch.int32, device="cuda:0")) for _ in range(2)]
+        for i in range(5):
+            p, h, n = bufs[i & 1]
+            tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
+            tr.traceSceneAsync(10 + i)
+        tr.synchronize()
+        for p, h, n in bufs:
+            k = int(n[0].item())
+            assert k == ref["points"].shape[0]
+            assert np.array_equal(p.cpu().numpy()[:32 * k].reshape(k, 32), ref["points"])
+            assert np.array_equal(h.cpu().numpy()[:16 * k].view(np.uint32).reshape(k, 4), ref["hits"])
     tr.close()
 
 
