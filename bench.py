@@ -272,11 +272,15 @@ def main():
     prime = max(0, args.prime_ms) * 1e-3
     t_prime = time.perf_counter()
     i = 0
-    while time.perf_counter() - t_prime < prime:
+    # N > 1: every rank must issue the same collectives, so the count is fixed there (about 150 ms worth)
+    batches = None if world == 1 else (60 if prime > 0 else 0)
+    while (time.perf_counter() - t_prime < prime) if batches is None else (batches > 0):
         for _ in range(50):
             frame(i)
             i += 1
         sync()
+        if batches is not None:
+            batches -= 1
     for i in range(args.warmup):
         frame(i)
     sync()
