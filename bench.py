@@ -422,6 +422,13 @@ def main():
     }
     if latency_frame_s is not None:
         out["ms_per_step_one_frame_in_flight"] = latency_frame_s * 1e3
+        # two frames in flight: the timed region is one k_frame launch per frame = this frame's k_project
+        # workgroups + the previous frame's finish + pack; its bytes = k_project's + per ray 8 (key read) + 8
+        # (key re-armed) + per hit 48 (point + record); duration taken as the frame time (launch gap included)
+        fk_bytes = b_launch + 16 * shard_rays + 48 * n_hits
+        out["frame_kernel"] = {"name": "k_frame", "algorithmic_bytes_per_launch": fk_bytes, "launch_ms_upper_bound": ms_per_step,
+                               "achieved": fk_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                               "frac": fk_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if breakdown is not None:
         out["stage_ms"] = {k: round(v, 5) for k, v in breakdown.items() if k != "frames"}
         out["copy_update_ms_per_step"] = copy_frame_s * 1e3
