@@ -230,8 +230,11 @@ ls::ProjectParams project_params(const ls_tracer *tr)
             pp.sec_b[0] = (float)std::cos(hi * M_PI / 180.0); pp.sec_b[1] = (float)std::sin(hi * M_PI / 180.0);
         }
     }
-    pp.big_cells = getenv("LS_PROJECT_BIG_CELLS") ? (uint32_t)atoi(getenv("LS_PROJECT_BIG_CELLS")) : 128u;
-    pp.debug = getenv("LS_PROJECT_DEBUG") ? atoi(getenv("LS_PROJECT_DEBUG")) : 0;
+    // tuning / ablation knobs of tools/sweep_*.sh, read once
+    static const uint32_t big_cells = getenv("LS_PROJECT_BIG_CELLS") ? (uint32_t)atoi(getenv("LS_PROJECT_BIG_CELLS")) : 128u;
+    static const int debug = getenv("LS_PROJECT_DEBUG") ? atoi(getenv("LS_PROJECT_DEBUG")) : 0;
+    pp.big_cells = big_cells;
+    pp.debug = debug;
     return pp;
 }
 
