@@ -64,9 +64,12 @@ struct ChanTables {
     const uint32_t *perm;
 };
 
-__device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 v1, V3 v2)
+// The footprint is computed in two steps: band() (elevation -> channel range; run for every triangle --
+// most triangles of a large scene fall between two channels and end there) and columns() (azimuth ->
+// column intervals; only for the survivors).
+__device__ __forceinline__ void band(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 v1, V3 v2, uint32_t &i0_out,
+                                     uint32_t &nch_out)
 {
-    Foot f = {0, 0, 0, 0, 0, 0};
     // ---- elevation band in tangent space: tan(e) = z / rho over the triangle lies inside
     //      [zmin / (zmin >= 0 ? rho_max : rho_min), zmax / (zmax > 0 ? rho_min : rho_max)]
     // rho_max = largest vertex rho.  rho_min: for the unit vector u towards the centroid (2-D), every
@@ -99,7 +102,14 @@ __device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTab
     const uint32_t i0 = lo;
     uint32_t i1 = i0;  // bands are narrow: walk forward instead of a second search
     while (i1 < pp.tb.V && ct.tan_dn[i1] <= tan_hi) ++i1;
-    if (i0 >= i1) return f;
+    i0_out = i0;
+    nch_out = i1 > i0 ? i1 - i0 : 0u;
+}
+
+__device__ __forceinline__ void columns(const ProjectParams &pp, V3 v0, V3 v1, V3 v2, uint32_t &h0a, uint32_t &na, uint32_t &h0b,
+                                        uint32_t &nb)
+{
+    h0a = na = h0b = nb = 0;
 
     // ---- azimuth arc.  Small triangles (both other vertices within 14 deg of vertex 0 as seen from
     //      the vertical axis -- the bulk of a large scene) need one arctangent: the offsets come from
@@ -121,7 +131,8 @@ __device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTab
             phi_lo = fast_atan2_deg(v0.y, v0.x) + lo * (kRadToDeg * 1.0001f);
             span = (hi - lo) * (kRadToDeg * 1.0001f);
         } else {
-            const float ctol = 1e-6f * rho_max * rho_max;
+            const float r0 = v0.x * v0.x + v0.y * v0.y, r1 = v1.x * v1.x + v1.y * v1.y, r2 = v2.x * v2.x + v2.y * v2.y;
+            const float ctol = 1.0002e-6f * fmaxf(r0, fmaxf(r1, r2));
             const float c3 = cross2(v1.x, v1.y, v2.x, v2.y);   // v0 x v1 = c1, v1 x v2 = c3, v2 x v0 = -c2
             const bool inside = (c1 >= -ctol && c3 >= -ctol && -c2 >= -ctol) || (c1 <= ctol && c3 <= ctol && -c2 <= ctol);
             if (inside) {
@@ -142,8 +153,6 @@ __device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTab
             }
         }
     }
-    f.i0 = i0;
-    f.nch = i1 - i0;
     if (!full) {
         // column index (real) of an azimuth: u = (phi - begin) / step; the raster repeats every P columns
         const float inv_step = pp.inv_step_deg;
@@ -163,12 +172,19 @@ __device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTab
                 if (h < (float)az_first || l > (float)az_last) continue;
                 const uint32_t h0 = (uint32_t)fmaxf(l, (float)az_first), h1 = (uint32_t)fminf(h, (float)az_last);
                 if (h0 > h1) continue;
-                if (n == n_min) { f.h0a = h0; f.na = h1 - h0 + 1u; }
-                else { f.h0b = h0; f.nb = h1 - h0 + 1u; }
+                if (n == n_min) { h0a = h0; na = h1 - h0 + 1u; }
+                else { h0b = h0; nb = h1 - h0 + 1u; }
             }
         }
     }
-    if (full) { f.h0a = az_first; f.na = az_last - az_first + 1u; f.h0b = 0; f.nb = 0; }
+    if (full) { h0a = az_first; na = az_last - az_first + 1u; h0b = 0; nb = 0; }
+}
+
+__device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 v1, V3 v2)
+{
+    Foot f = {0, 0, 0, 0, 0, 0};
+    band(pp, ct, v0, v1, v2, f.i0, f.nch);
+    if (f.nch) columns(pp, v0, v1, v2, f.h0a, f.na, f.h0b, f.nb);
     return f;
 }
 
