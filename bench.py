@@ -412,6 +412,8 @@ def main():
         "frames_per_s": args.steps / elapsed,
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         "hits_per_frame_rank0": n_hits,
+        # N > 1: points of the whole frame as rebuilt from the gathered slots on rank 0 (= the 1-GPU hit count)
+        "gathered_points_rank0": None if single else int(cloud_n[0].item()),
         "rehearsal_gloo_shared_gpu": True if rehearsal else None,
         "roofline": dict({
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
