@@ -428,7 +428,16 @@ def main():
         # workgroups + the previous frame's finish + pack; its bytes = k_project's + per ray 8 (key read) + 8
         # (key re-armed) + per hit 48 (point + record); duration taken as the frame time (launch gap included)
         fk_bytes = b_launch + 16 * shard_rays + 48 * n_hits
+        fk_traffic = None
+        if traffic_src:
+            try:
+                kk = json.load(open(prof))["kernels"]
+                fk_key = next((n for n in kk if n.split("<")[0] == "k_frame"), None)
+                fk_traffic = kk[fk_key]["hbm_bytes_per_launch"] if fk_key else None
+            except Exception:
+                pass
         out["frame_kernel"] = {"name": "k_frame", "algorithmic_bytes_per_launch": fk_bytes, "launch_ms_upper_bound": ms_per_step,
+                               "traffic": fk_traffic,
                                "achieved": fk_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                "frac": fk_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if breakdown is not None:
