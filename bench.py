@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line (see README/DESIGN.md for the extra keys).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -42,8 +43,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--prime-ms", type=int, default=150,
-                    help="untimed frames for this long before the W warm-up steps (runtime one-off stalls, clocks)")
+    ap.add_argument("--prime-ms", type=int, default=50,
+                    help="untimed frames for this long before the W warm-up steps (clocks, caches)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one frame in flight (LS_OPT_PIPELINE off); default on a single GPU: two frames in flight")
     ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5"],
@@ -266,14 +267,18 @@ def main():
     info = tr.sceneSize()
     n_tris_total = info["n_tris"]
 
-    # The HIP runtime stalls one enqueue call for 30-40 ms once per process, some 15-25 ms after a stream
-    # starts to be fed continuously (tools/long_run.py: window 2 of 16, both frame modes); priming gets that
-    # one-off event out of the way of the W warm-up and K timed frames, whatever W the caller chose
+    # CPython's cyclic garbage collector runs a full (generation 2) collection some 700 frames into the run --
+    # every frame allocates a few ctypes objects -- and with torch imported that pause is 30-40 ms, a thousand
+    # frames' worth (tools/long_run.py).  The measurement loop allocates nothing that needs it: freeze what
+    # exists and switch the collector off.  The priming frames that follow are for clocks and caches.
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     prime = max(0, args.prime_ms) * 1e-3
     t_prime = time.perf_counter()
     i = 0
-    # N > 1: every rank must issue the same collectives, so the count is fixed there (about 150 ms worth)
-    batches = None if world == 1 else (60 if prime > 0 else 0)
+    # N > 1: every rank must issue the same collectives, so the count is fixed there (1000 frames)
+    batches = None if world == 1 else (20 if prime > 0 else 0)
     while (time.perf_counter() - t_prime < prime) if batches is None else (batches > 0):
         for _ in range(50):
             frame(i)

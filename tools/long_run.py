@@ -1,4 +1,5 @@
-"""Long streaming run: frames per second over windows, to expose periodic host-side stalls."""
+"""Long streaming run: frames per second over windows, to expose host-side stalls (argv[3] == "nogc": with
+CPython's cyclic collector frozen and off -- the one 30-40 ms pause of a run is its first full collection)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +17,9 @@ for n, dv, dt, nv, nt in dm: tr.addGeometry(n, nv, nt)
 def frame(i):
     for n, dv, dt, nv, nt in dm: tr.updateGeometryDeviceShared(n, capi.IDENTITY_AFFINE, dv.data_ptr(), 12, dt.data_ptr())
     tr.commitScene(); tr.traceSceneAsync(i)
+import gc
+if len(sys.argv) > 3 and sys.argv[3] == "nogc":
+    gc.collect(); gc.freeze(); gc.disable()
 for i in range(50): frame(i)
 tr.synchronize()
 W = 500
