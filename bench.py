@@ -46,7 +46,10 @@ def parse_args():
     ap.add_argument("--prime-ms", type=int, default=50,
                     help="untimed frames for this long before the W warm-up steps (clocks, caches)")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="one frame in flight (LS_OPT_PIPELINE off); default on a single GPU: two frames in flight")
+                    help="one frame in flight (LS_OPT_PIPELINE off)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="single GPU: LS_OPT_PIPELINE mode, 1 = two frames in flight on one stream (finish + pack ride in "
+                         "the next frame's launch), 2 = three frames in flight on three streams (default)")
     ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5"],
                     help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size; "
                          "cfg5 = configs[4] itself: one SYN-128 sensor per GPU on a 20 m circle over SYN-10M + ben "
@@ -171,7 +174,8 @@ def main():
     # a dedicated (non-default) stream shared by the tracer's kernels and, through torch, by RCCL's
     # stream dependencies: the all-gather of frame i is ordered after frame i's pack kernel
     stream = torch.cuda.Stream(device)
-    tr.setStream(stream.cuda_stream)
+    if world > 1:            # a single GPU has no collective to order: the tracer keeps its own stream
+        tr.setStream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
 
     # inputs resident in HBM before the timed region
@@ -187,15 +191,15 @@ def main():
     if single:
         # single GPU: [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap] in caller-owned buffers, two of
         # them: with two frames in flight (LS_OPT_PIPELINE) consecutive frames write alternate buffers
-        out_bufs = [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=device) for _ in range(2)]
+        out_bufs = [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=device) for _ in range(3)]
 
         def set_out(i):
-            base = out_bufs[i & 1].data_ptr()
+            base = out_bufs[i % 3].data_ptr()
             tr.setOutputBuffers(base + 64, base + 64 + 32 * cap, base, cap)
         set_out(0)
         count_words = out_bufs
         if pipeline:
-            tr.setOption(capi.LS_OPT_PIPELINE, 1)
+            tr.setOption(capi.LS_OPT_PIPELINE, args.pipeline)
     else:
         # N > 1: the travelling slot holds the count word and the 16-byte hit records only (shards.py);
         # two slots / two gather buffers alternate so that the all-gather of frame i overlaps frame i+1
@@ -320,7 +324,7 @@ def main():
             frame(i)
         sync()
         latency_frame_s = (time.perf_counter() - t1) / args.steps
-        tr.setOption(capi.LS_OPT_PIPELINE, 1)
+        tr.setOption(capi.LS_OPT_PIPELINE, args.pipeline)
 
     breakdown = None
     if (args.breakdown or world == 1) and not replicas:
@@ -408,7 +412,8 @@ def main():
                    "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,
                    "frame": "updateGeometry(device, in place) + commitScene + traceScene"
                             + (" (full BVH rebuild every frame)" if engine == "bvh" else "")
-                            + ("; two frames in flight (finish + pack of frame i overlap the triangle streaming of frame i+1)"
+                            + (("; two frames in flight (finish + pack of frame i ride in the launch of frame i+1)"
+                                if args.pipeline == 1 else "; three frames in flight (whole frames rotate over three streams)")
                                if pipeline else ""),
                    "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
                                   f"hit-record slots per frame (overlapped with the next frame), cloud rebuilt on every rank"
@@ -429,6 +434,7 @@ def main():
     }
     if latency_frame_s is not None:
         out["ms_per_step_one_frame_in_flight"] = latency_frame_s * 1e3
+    if latency_frame_s is not None and args.pipeline == 1:
         # two frames in flight: the timed region is one k_frame launch per frame = this frame's k_project
         # workgroups + the previous frame's finish + pack; its bytes = k_project's + per ray 8 (key read) + 8
         # (key re-armed) + per hit 48 (point + record); duration taken as the frame time (launch gap included)

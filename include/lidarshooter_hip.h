@@ -199,12 +199,16 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1,2,4,8), default 1; takes effect at next commit  */
 #define LS_OPT_TIMING 2         /* 1: bracket every stage with hipEvents, 2: only the trace kernel        */
 #define LS_OPT_COUNT_VISITS 3   /* 1: trace kernel also counts node fetches / triangle tests              */
-#define LS_OPT_PIPELINE 6       /* 1: two frames in flight (projection engine, asynchronous API): finish + pack of a
-                                 * frame run on a second stream while the next frame's triangles are streamed.
-                                 * A frame's outputs are then ordered on the handle's stream only after the NEXT
-                                 * ls_trace_scene_async (or ls_tracer_flush / ls_tracer_synchronize), and the
-                                 * library's own output buffers alternate between two sets (a caller that sets
-                                 * output buffers alternates them itself).  Default 0.                          */
+#define LS_OPT_PIPELINE 6       /* frames in flight (projection engine, asynchronous API).  0 (default): one.
+                                 * 1: two, on the handle's stream -- the finish + pack workgroups of a frame ride in the
+                                 *    launch of the next frame's k_project; a frame's outputs are ordered on the
+                                 *    handle's stream after the NEXT ls_trace_scene_async.
+                                 * 2: three -- whole frames rotate over three streams of the library; outputs are ordered
+                                 *    on the handle's stream by ls_tracer_flush (no event or wait per frame).
+                                 * In both modes ls_tracer_flush / ls_tracer_synchronize complete everything, the
+                                 * library's own output buffers rotate with the frames (a caller that sets output
+                                 * buffers rotates them itself), and meshes handed over with
+                                 * ls_update_geometry_device_shared must stay unchanged while frames are in flight.  */
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */

@@ -168,6 +168,8 @@ void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPack
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
                            uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,
                            unsigned long long *stats);
+// one idle wave for `ticks` x 10 ns (stream / hardware-queue calibration)
+void launch_spin(hipStream_t s, unsigned long long ticks);
 // sensor -> world transform of a packed cloud (m.a = A, m.rinv = R, m.t = t); max_points bounds the grid
 void launch_cloud_to_world(hipStream_t s, const Affine &m, const void *in, const uint32_t *n_points, void *out,
                            const uint32_t *out_base, uint32_t *out_total, uint32_t capacity, uint32_t max_points);

@@ -799,6 +799,17 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
                        reinterpret_cast<uint4 *>(hits), n_points);
 }
 
+// One wave that does nothing for `ticks` of the 100 MHz wall clock: ls_tracer.cpp uses it to find out which
+// streams share a hardware queue (two of these take twice as long on one queue as on two).
+__global__ void k_spin(unsigned long long ticks, unsigned long long *out)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+    if (out && threadIdx.x == 0) *out = t0;
+}
+
+void launch_spin(hipStream_t s, unsigned long long ticks) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, ticks, static_cast<unsigned long long *>(nullptr)); }
+
 void launch_cloud_to_world(hipStream_t s, const Affine &m, const void *in, const uint32_t *n_points, void *out,
                            const uint32_t *out_base, uint32_t *out_total, uint32_t capacity, uint32_t max_points)
 {

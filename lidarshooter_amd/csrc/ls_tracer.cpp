@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -104,6 +105,17 @@ struct ls_tracer {
     DevBuf<uint8_t> big_queue_b, points_b, hits_b;
     uint32_t *d_n_points_b = nullptr;
     bool keys_b_armed = false;
+    // LS_OPT_PIPELINE = 2: whole frames rotate over three streams (three frames in flight); slot 0 / 1 use
+    // the buffers above, slot 2 the ones below; every slot has its own block-count array
+    hipStream_t slot_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_main = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
+    bool slot_pending[3] = {false, false, false};   // frames issued on slot_stream[s] since the last flush
+    bool main_dirty = false;                        // the library enqueued mesh copies on the handle's stream since the last frame
+    uint32_t ms_seq = 0;
+    DevBuf<unsigned long long> best_keys_c;
+    DevBuf<uint8_t> big_queue_c, points_c, hits_c;
+    uint32_t *d_n_points_c = nullptr;
+    bool keys_c_armed = false;
     bool traced_projection = false;        // the last trace ran on the projection engine (dense arrays on demand)
     const void *last_d_hits = nullptr;     // its hit records and count (device)
     const uint32_t *last_d_n = nullptr;
@@ -240,6 +252,50 @@ ls::ProjectParams project_params(const ls_tracer *tr)
 
 uint32_t shard_rays(const ls_tracer *tr) { return tr->V * tr->naz; }
 
+// LS_OPT_PIPELINE = 2 needs three streams whose kernels really run side by side.  The runtime multiplexes
+// streams onto a few hardware queues (which ones depends on every stream created before, by anybody in the
+// process), and two streams on one queue serialise: 24 us per frame instead of 16.  So: candidates are created
+// and tried pairwise with an idle 200 us wave each -- two on one queue take twice as long as two on two --
+// until three mutually concurrent ones are found; the rest is destroyed.  A few milliseconds, once per handle.
+int pick_slot_streams(ls_tracer *tr)
+{
+    constexpr int kCandidates = 8;
+    constexpr unsigned long long kTicks = 20000;   // 200 us
+    hipStream_t cand[kCandidates] = {};
+    for (auto &c : cand) LS_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    auto pair_us = [&](hipStream_t a, hipStream_t b, double &us) -> int {
+        LS_HIP(hipStreamSynchronize(a));
+        LS_HIP(hipStreamSynchronize(b));
+        const auto t0 = std::chrono::steady_clock::now();
+        ls::launch_spin(a, kTicks);
+        ls::launch_spin(b, kTicks);
+        LS_HIP(hipStreamSynchronize(a));
+        LS_HIP(hipStreamSynchronize(b));
+        us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        return LS_OK;
+    };
+    int rc;
+    double warm;
+    if ((rc = pair_us(cand[0], cand[1], warm))) return rc;   // first launches: code object upload etc.
+    int chosen[3] = {0, -1, -1}, n = 1;
+    for (int c = 1; c < kCandidates && n < 3; ++c) {
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {
+            double us;
+            if ((rc = pair_us(cand[chosen[k]], cand[c], us))) return rc;
+            ok = us < 1.5 * (double)kTicks / 100.0;   // concurrent: ~200 us; serialised: ~400 us
+        }
+        if (ok) chosen[n++] = c;
+    }
+    for (int i = 0; i < 3; ++i) tr->slot_stream[i] = cand[chosen[i] >= 0 ? chosen[i] : chosen[0]];
+    for (int c = 0; c < kCandidates; ++c) {
+        bool used = false;
+        for (int i = 0; i < 3; ++i) used = used || tr->slot_stream[i] == cand[c];
+        if (!used) (void)hipStreamDestroy(cand[c]);
+    }
+    return LS_OK;
+}
+
 int ensure_outputs(ls_tracer *tr)
 {
     const size_t nr = shard_rays(tr);
@@ -248,7 +304,7 @@ int ensure_outputs(ls_tracer *tr)
     if ((rc = ensure(tr, tr->hit_gid, nr))) return rc;
     {
         const size_t c0 = tr->row_counts.cap;
-        if ((rc = ensure(tr, tr->row_counts, 2 * ((nr + 255) / 256) + 8))) return rc;  // two frame-parity arrays
+        if ((rc = ensure(tr, tr->row_counts, 4 * ((nr + 255) / 256) + 8))) return rc;  // two frame-parity arrays (+ two: three-stream mode)
         if (tr->row_counts.cap != c0) tr->keys_armed = false;
     }
     if (use_projection(tr)) {
@@ -265,6 +321,23 @@ int ensure_outputs(ls_tracer *tr)
     if (!tr->ext_points) {
         if ((rc = ensure(tr, tr->points, nr * 32))) return rc;
         if ((rc = ensure(tr, tr->hits, nr * 16))) return rc;
+    }
+    if (tr->opt_pipeline == 2 && use_projection(tr)) {
+        const size_t cap0 = tr->best_keys_c.cap;
+        if ((rc = ensure(tr, tr->best_keys_c, nr))) return rc;
+        if (tr->best_keys_c.cap != cap0) tr->keys_c_armed = false;
+        if (!tr->big_queue_c.p && (rc = ensure(tr, tr->big_queue_c, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
+        if (!tr->ext_points) {
+            if ((rc = ensure(tr, tr->points_c, nr * 32))) return rc;
+            if ((rc = ensure(tr, tr->hits_c, nr * 16))) return rc;
+        }
+        if (!tr->d_n_points_c) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_n_points_c), 4));
+        if (!tr->slot_stream[0]) {
+            LS_HIP(hipEventCreateWithFlags(&tr->ev_main, hipEventDisableTiming | hipEventDisableSystemFence));
+            if ((rc = pick_slot_streams(tr))) return rc;
+            for (int i = 0; i < 3; ++i)
+                LS_HIP(hipEventCreateWithFlags(&tr->ev_done[i], hipEventDisableTiming | hipEventDisableSystemFence));
+        }
     }
     if ((tr->opt_pipeline || tr->pipe_seq) && use_projection(tr)) {   // twins: needed as long as the rotation may stand on parity 1
         const size_t cap0 = tr->best_keys_b.cap;
@@ -291,8 +364,19 @@ int ensure_outputs(ls_tracer *tr)
 ls::ProjectParams project_params(const ls_tracer *tr);
 
 // LS_OPT_PIPELINE: launch the finish + pack of the frame still in flight on its own
+// frames on one of the three streams (LS_OPT_PIPELINE = 2) may still read the meshes: the handle's stream, on
+// which the next mesh copy is about to be enqueued, waits for them (same as a flush)
+int flush_pipeline(ls_tracer *tr);
+int order_after_projects(ls_tracer *tr) { return flush_pipeline(tr); }
+
 int flush_pipeline(ls_tracer *tr)
 {
+    for (int i = 0; i < 3; ++i)
+        if (tr->slot_pending[i]) {   // three-stream mode: no per-frame event; the one recorded now covers the stream's frames
+            LS_HIP(hipEventRecord(tr->ev_done[i], tr->slot_stream[i]));
+            LS_HIP(hipStreamWaitEvent(tr->stream, tr->ev_done[i], 0));
+            tr->slot_pending[i] = false;
+        }
     if (!tr->pipe_pending) return LS_OK;
     ls::launch_finish_pack(tr->stream, project_params(tr), tr->pipe_fa, nullptr);
     LS_HIP(hipGetLastError());
@@ -431,6 +515,11 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         g.has_verts = true;
         if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; }
         return LS_OK;
+    }
+    {   // three-stream mode: frames in flight may still read the mesh buffers this call overwrites
+        const int rc = order_after_projects(tr);
+        if (rc) return rc;
+        tr->main_dirty = true;
     }
     if (verts) {
         g.shared_raw = nullptr;
@@ -613,7 +702,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     if (tr->ext_points && tr->ext_capacity < shard_rays(tr))
         return fail(tr, LS_ERR_OUT_OF_RANGE, "external output buffers smaller than the shard's ray count");
 
-    hipStream_t s = tr->stream;
+    hipStream_t s = tr->stream;   // three-stream mode switches to the frame's own stream below
     const ls::SensorTables tb = tables(tr);
     uint8_t *d_points = tr->ext_points ? static_cast<uint8_t *>(tr->ext_points) : tr->points.p;
     void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
@@ -624,31 +713,47 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         const ls::ProjectParams pp = project_params(tr);
         unsigned long long *stats = tr->opt_count ? tr->d_visits + 1 : nullptr;  // counts[1] = triangle tests
         const uint32_t n_blocks = (shard_rays(tr) + 255u) / 256u;
-        const bool pipelined = tr->opt_pipeline && !tr->opt_count && !tr->opt_timing;
-        if (!pipelined && (rc = flush_pipeline(tr))) return rc;
-        // which twin of keys / queue / outputs and which of the three queue counters this frame uses: pipe_seq
-        // counts the pipelined frames; a frame that is not pipelined re-arms what it used itself and leaves
-        // pipe_seq alone, so the rotation stays consistent across mode changes
-        const uint32_t par = tr->pipe_seq & 1u;
-        unsigned long long *keys = par ? tr->best_keys_b.p : tr->best_keys.p;
-        void *bigq = par ? static_cast<void *>(tr->big_queue_b.p) : static_cast<void *>(tr->big_queue.p);
-        uint32_t *big_count = tr->d_big_count + 4u * (tr->pipe_seq % 3u);
-        if (par && !tr->ext_points) {
-            d_points = tr->points_b.p;
-            d_hits = tr->hits_b.p;
-            d_n = tr->d_n_points_b;
+        const bool pipelined = tr->opt_pipeline == 1 && !tr->opt_count && !tr->opt_timing;
+        const bool multi = tr->opt_pipeline == 2 && !tr->opt_count && !tr->opt_timing;
+        if (!pipelined && !multi && (rc = flush_pipeline(tr))) return rc;
+        // which set of keys / queue / outputs and which of the three queue counters this frame uses.
+        // Rider mode and frames that are not pipelined: pipe_seq counts the pipelined frames; a frame that is
+        // not pipelined re-arms what it used itself and leaves pipe_seq alone, so the rotation stays
+        // consistent across mode changes.  Three-stream mode: slot = frame number mod 3.
+        const uint32_t slot = multi ? tr->ms_seq % 3u : (tr->pipe_seq & 1u);
+        unsigned long long *keys = slot == 0 ? tr->best_keys.p : (slot == 1 ? tr->best_keys_b.p : tr->best_keys_c.p);
+        void *bigq = slot == 0 ? static_cast<void *>(tr->big_queue.p)
+                               : (slot == 1 ? static_cast<void *>(tr->big_queue_b.p) : static_cast<void *>(tr->big_queue_c.p));
+        uint32_t *big_count = tr->d_big_count + 4u * (multi ? slot : tr->pipe_seq % 3u);
+        if (slot && !tr->ext_points) {
+            d_points = slot == 1 ? tr->points_b.p : tr->points_c.p;
+            d_hits = slot == 1 ? tr->hits_b.p : tr->hits_c.p;
+            d_n = slot == 1 ? tr->d_n_points_b : tr->d_n_points_c;
+        }
+        if (multi) {
+            // the frame's stream first sees what is enqueued on the handle's stream: the library's own mesh copies,
+            // or anything at all when the stream is the caller's (host API calls are not cheap: only when needed)
+            const bool dep = tr->main_dirty || tr->stream != tr->own_stream;
+            if (dep) LS_HIP(hipEventRecord(tr->ev_main, s));
+            s = tr->slot_stream[slot];
+            if (dep) LS_HIP(hipStreamWaitEvent(s, tr->ev_main, 0));
+            tr->main_dirty = false;
         }
         if (!tr->keys_armed) {
             ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count, tr->row_counts.p);
             tr->keys_armed = true;
             tr->frame_parity = 0;
         }
-        if (par && !tr->keys_b_armed) {
+        if (slot == 1 && !tr->keys_b_armed) {
             LS_HIP(hipMemsetAsync(tr->best_keys_b.p, 0xFF, (size_t)shard_rays(tr) * 8, s));
             tr->keys_b_armed = true;
         }
-        uint32_t *counts = tr->row_counts.p + (size_t)tr->frame_parity * n_blocks;
-        uint32_t *next_counts = tr->row_counts.p + (size_t)(1u - tr->frame_parity) * n_blocks;
+        if (slot == 2 && !tr->keys_c_armed) {
+            LS_HIP(hipMemsetAsync(tr->best_keys_c.p, 0xFF, (size_t)shard_rays(tr) * 8, s));
+            tr->keys_c_armed = true;
+        }
+        uint32_t *counts = tr->row_counts.p + (size_t)(multi ? slot : tr->frame_parity) * n_blocks;
+        uint32_t *next_counts = tr->row_counts.p + (size_t)(multi ? 3u : 1u - tr->frame_parity) * n_blocks;
         mark(tr, 7);
         std::vector<ls::GeomSource> &srcs = tr->project_srcs;
         srcs.clear();
@@ -705,7 +810,15 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             mark(tr, 9);
             ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n);
             mark(tr, 10);
-            tr->frame_parity ^= 1u;
+            if (multi) {
+                // no event per frame: a flush (or a mesh copy) records one per stream and orders the handle's stream after it
+                tr->slot_pending[slot] = true;
+                ++tr->ms_seq;
+                s = tr->stream;
+                if (readback && (rc = flush_pipeline(tr))) return rc;
+            } else {
+                tr->frame_parity ^= 1u;
+            }
         }
         tr->traced_projection = true;
         tr->last_d_hits = d_hits;
@@ -836,8 +949,19 @@ void ls_tracer_destroy(ls_tracer *tr)
     (void)hipSetDevice(tr->device);
     if (tr->stream) (void)hipStreamSynchronize(tr->stream);
     for (auto &kv : tr->geoms) free_geometry(kv.second);
+    for (int i = 0; i < 3; ++i)
+        if (tr->slot_stream[i]) (void)hipStreamSynchronize(tr->slot_stream[i]);
     release(tr->best_keys_b); release(tr->big_queue_b); release(tr->points_b); release(tr->hits_b); release(tr->pack_status);
+    release(tr->best_keys_c); release(tr->big_queue_c); release(tr->points_c); release(tr->hits_c);
     if (tr->d_n_points_b) (void)hipFree(tr->d_n_points_b);
+    if (tr->d_n_points_c) (void)hipFree(tr->d_n_points_c);
+    if (tr->ev_main) (void)hipEventDestroy(tr->ev_main);
+    for (int i = 0; i < 3; ++i) {
+        if (tr->ev_done[i]) (void)hipEventDestroy(tr->ev_done[i]);
+        bool dup = false;
+        for (int k = 0; k < i; ++k) dup = dup || tr->slot_stream[k] == tr->slot_stream[i];
+        if (tr->slot_stream[i] && !dup) (void)hipStreamDestroy(tr->slot_stream[i]);
+    }
     release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
     release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
     release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
@@ -1098,9 +1222,15 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         return LS_OK;
     case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
     case LS_OPT_PIPELINE: {
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_PIPELINE: 0 off, 1 two frames on one stream, 2 three streams");
+        if (value == tr->opt_pipeline) return LS_OK;
         const int rc = flush_pipeline(tr);
         if (rc) return rc;
-        tr->opt_pipeline = value != 0;
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        LS_HIP(hipMemset(tr->d_big_count, 0, 64));   // the modes rotate the queue counters differently
+        tr->pipe_seq = 0;
+        tr->ms_seq = 0;
+        tr->opt_pipeline = value;
         return LS_OK;
     }
     case LS_OPT_ENGINE:

@@ -739,27 +739,29 @@ def test_cloud_to_world_two_sensors_merged(oracle, capi, sensors, meshes):
         tr.close()
 
 
-def test_pipelined_frames(oracle, capi, sensors, meshes):
-    """LS_OPT_PIPELINE: two frames in flight (finish + pack of frame i on the second stream while frame
-    i+1 streams its triangles).  An animated scene, caller-owned output buffers alternating A/B; every
-    frame is read after the next call (or the final flush) and equals the oracle; then the synchronous
-    API and a shard change on the same handle."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pipelined_frames(oracle, capi, sensors, meshes, mode):
+    """LS_OPT_PIPELINE = 1 (two frames in flight: the finish + pack workgroups of frame i ride in the launch
+    of frame i+1) and = 2 (three frames in flight on three streams).  An animated scene (the moving mesh is
+    copied into library-owned buffers every frame), caller-owned output buffers rotating over three sets;
+    every frame is read once it is ordered on the handle's stream (after `mode` further calls, or the
+    final flush) and equals the oracle; then the synchronous API and a shard change on the same handle."""
     import torch
     from conftest import DATA
     s = sensors["0001"]
     poses = oracle.play_trajectory(os.path.join(DATA, "config", "trajectory.json"), 0.1)
     tr = make_tracer(capi, s, "projection")
-    tr.setOption(capi.LS_OPT_PIPELINE, 1)
+    tr.setOption(capi.LS_OPT_PIPELINE, mode)
     _add(tr, "ground", meshes["ground"])
     _add(tr, "face", meshes["ben"])
     cap = s.V * s.H
     bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0"), torch.zeros(16 * cap, dtype=torch.uint8, device="cuda:0"),
-             torch.zeros(4, dtype=torch.int32, device="cuda:0")) for _ in range(2)]
+             torch.zeros(4, dtype=torch.int32, device="cuda:0")) for _ in range(3)]
     frames = list(range(0, 24))
     expected = []
 
     def check(i):
-        pts_t, hts_t, n_t = bufs[i & 1]
+        pts_t, hts_t, n_t = bufs[i % 3]
         n = int(n_t[0].item())
         ref = expected[i]
         assert n == ref["points"].shape[0]
@@ -775,15 +777,21 @@ def test_pipelined_frames(oracle, capi, sensors, meshes):
         tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
         tr.updateGeometryComponents("face", lin, ang, *meshes["ben"])
         assert tr.commitScene() == 0
-        p, h, n = bufs[i & 1]
+        p, h, n = bufs[i % 3]
         tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
         tr.traceSceneAsync(i)
-        if i:                                               # frame i-1 is ordered on the handle's stream now
+        if mode == 1 and i:                                 # frame i-1 is ordered on the handle's stream now
             stream.synchronize()
             check(i - 1)
+        if mode == 2 and i >= 2 and i % 3 == 2:             # three streams: a flush orders everything issued so far
+            tr.flush()
+            stream.synchronize()
+            for k in (i - 2, i - 1, i):
+                check(k)
     tr.flush()
     stream.synchronize()
-    check(frames[-1])
+    for i in frames[-mode:]:
+        check(i)
     assert len({e["points"].shape[0] for e in expected}) > 3
     # synchronous API on the pipelined handle, library-owned (twin) buffers, twice: both twins
     tr.setOutputBuffers(None, None, None, 0)

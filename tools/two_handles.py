@@ -3,11 +3,13 @@ frames issued round-robin; frames/s against one handle.  Experiment tooling."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import gc
 import numpy as np, torch
 from lidarshooter_amd import capi
 import bench
 
 sensor, meshes = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "syn128x1m")
+gc.collect(); gc.freeze(); gc.disable()   # a full collection inside one of the runs would look like a slow configuration
 dev = torch.device("cuda", 0)
 d_meshes = [(n, torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev),
              torch.from_numpy(np.ascontiguousarray(t, np.uint32).view(np.int32)).to(dev), v.shape[0], t.shape[0]) for n, v, t in meshes]
@@ -16,6 +18,7 @@ for nh in (2, 3, 4, 6, 2, 1):
     for k in range(nh):
         tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], int(sensor["h_count"]), sensor["Rinv"], sensor["t"])
         tr.setOption(capi.LS_OPT_ENGINE, 2)
+        tr.setOption(capi.LS_OPT_PIPELINE, int(os.environ.get("PIPE", "0")))
         for n, dv, dt, nv, nt in d_meshes:
             tr.addGeometry(n, nv, nt)
         trs.append(tr)
