@@ -261,6 +261,7 @@ int pick_slot_streams(ls_tracer *tr)
 {
     constexpr int kCandidates = 8;
     constexpr unsigned long long kTicks = 20000;   // 200 us
+    LS_HIP(hipDeviceSynchronize());                // nothing else may be running while pairs are timed
     hipStream_t cand[kCandidates] = {};
     for (auto &c : cand) LS_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
     auto pair_us = [&](hipStream_t a, hipStream_t b, double &us) -> int {
@@ -1142,6 +1143,7 @@ int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az)
     tr->traced = false;
     tr->keys_armed = false;
     tr->keys_b_armed = false;
+    tr->keys_c_armed = false;
     return LS_OK;
 }
 
