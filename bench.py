@@ -47,9 +47,10 @@ def parse_args():
                     help="untimed frames for this long before the W warm-up steps (clocks, caches)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one frame in flight (LS_OPT_PIPELINE off)")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
                     help="single GPU: LS_OPT_PIPELINE mode, 1 = two frames in flight on one stream (finish + pack ride in "
-                         "the next frame's launch), 2 = three frames in flight on three streams (default)")
+                         "the next frame's launch: one launch per frame), 2 = three frames in flight on three streams; "
+                         "0 (default) = 2 for scenes of 200 000 triangles or more, 1 for small scenes (host-bound)")
     ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5"],
                     help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size; "
                          "cfg5 = configs[4] itself: one SYN-128 sensor per GPU on a 20 m circle over SYN-10M + ben "
@@ -156,6 +157,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     sensor, meshes = build_workload(args.workload, rank)
+    if args.pipeline == 0:
+        args.pipeline = 2 if sum(t.shape[0] for _, _, t in meshes) >= 200000 else 1
     replicas = args.workload == "cfg5"               # every rank traces its own full sensor: no shards, no collective
     if replicas:  # the AffineMesh pose rule played over config/trajectory.json, scaled to keep ben inside the scene
         poses = hostapi.trajectory_play(os.path.join(DATA, "config", "trajectory.json"), 0.1)
@@ -213,7 +216,32 @@ def main():
         works = [None, None]
         count_words = slots
 
+    # The same four C-ABI calls per frame as below, bound once with their constant arguments: the loop is the
+    # host side of the product path, and a per-call numpy conversion / string encode is Python's cost, not its
+    import ctypes as C
+    L, h = tr.L, tr.h
+    f32p = C.POINTER(C.c_float)
+    ident_c = (C.c_float * 12)(*[float(x) for x in ident])
+    fast_meshes = [(name.encode(), C.c_void_p(dv.data_ptr()), C.c_void_p(dt.data_ptr()), name == "face") for name, dv, dt in d_meshes]
+    fast_aff = [(C.c_float * 12)(*[float(x) for x in a]) for a in affines] if replicas else None
+    fast_frame_struct = capi.Frame()
+    fast_out = [(C.c_void_p(b.data_ptr() + 64), C.c_void_p(b.data_ptr() + 64 + 32 * cap), C.c_void_p(b.data_ptr())) for b in out_bufs] if single else None
+
+    def fast_update_and_trace(i):
+        for nm, pv, pt, moving in fast_meshes:
+            a = fast_aff[i % len(fast_aff)] if (moving and replicas) else ident_c
+            if L.ls_update_geometry_device_shared(h, nm, C.cast(a, f32p), pv, 12, pt) < 0:
+                raise RuntimeError(tr.last_error())
+        if L.ls_commit_scene(h) < -1:
+            raise RuntimeError(tr.last_error())
+        o = fast_out[i % 3]
+        L.ls_tracer_set_output_buffers(h, o[0], o[1], o[2], cap)
+        if L.ls_trace_scene_async(h, i, C.byref(fast_frame_struct)) < -1:
+            raise RuntimeError(tr.last_error())
+
     def update_and_trace(i, copy):
+        if single and not copy:
+            return fast_update_and_trace(i)
         for name, dv, dt in d_meshes:                      # MeshProjector.cpp:448-461: every mesh, every frame
             if replicas and name == "face":                # the animated instance: a new pose every frame
                 tr.updateGeometryDeviceShared(name, affines[i % len(affines)], dv.data_ptr(), 12, dt.data_ptr())
