@@ -811,6 +811,49 @@ def test_pipelined_frames(oracle, capi, sensors, meshes, mode):
     tr.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pipeline_stress(oracle, capi, sensors, meshes, mode):
+    """900 frames streamed without a host wait in either pipelined mode, the moving mesh cycling through
+    four poses (in-place device meshes, transform only), outputs rotating over three caller-owned sets;
+    every 150 frames everything is flushed and the three frames last issued are compared with the oracle."""
+    import torch
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_PIPELINE, mode)
+    dev = torch.device("cuda", 0)
+    d = {}
+    for name, key in (("ground", "ground"), ("face", "ben")):
+        v, t = meshes[key]
+        d[name] = (torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev),
+                   torch.from_numpy(np.ascontiguousarray(t, np.uint32).view(np.int32)).to(dev))
+        tr.addGeometry(name, v.shape[0], t.shape[0])
+    poses = [oracle.affine_from_components(np.array(l, np.float32), np.array(a, np.float32))
+             for l, a in (((0, 0, 0), (0, 0, 0)), ((1.5, -1.0, 0.2), (0.1, 0.0, 0.7)), ((-2.0, 0.5, 0.0), (0.0, 0.3, -1.1)),
+                          ((0.3, 2.5, 0.4), (-0.2, 0.1, 2.0)))]
+    refs = [oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)]) for A in poses]
+    assert len({r["points"].shape[0] for r in refs}) >= 3
+    cap = s.V * s.H
+    bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device=dev), torch.zeros(16 * cap, dtype=torch.uint8, device=dev),
+             torch.zeros(4, dtype=torch.int32, device=dev)) for _ in range(3)]
+    for i in range(900):
+        tr.updateGeometryDeviceShared("ground", oracle.IDENTITY_AFFINE, d["ground"][0].data_ptr(), 12, d["ground"][1].data_ptr())
+        tr.updateGeometryDeviceShared("face", poses[(i * 7) % 4], d["face"][0].data_ptr(), 12, d["face"][1].data_ptr())
+        assert tr.commitScene() == 0
+        p, h, n = bufs[i % 3]
+        tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
+        tr.traceSceneAsync(i)
+        if i % 150 == 149:
+            tr.synchronize()
+            for k in (i - 2, i - 1, i):
+                p, h, n = bufs[k % 3]
+                ref = refs[(k * 7) % 4]
+                cnt = int(n[0].item())
+                assert cnt == ref["points"].shape[0], (k, cnt)
+                assert np.array_equal(p.cpu().numpy()[:32 * cnt].reshape(cnt, 32), ref["points"])
+                assert np.array_equal(h.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4), ref["hits"])
+    tr.close()
+
+
 def test_edge_cases(oracle, capi, sensors, engine):
     """Degenerate inputs: one-triangle scene (a BVH with no internal node), coincident triangles in two
     geometries (equal t: lowest geomID wins), a geometry with zero triangles next to a real one, a
