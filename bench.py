@@ -263,19 +263,46 @@ def main():
             tr.expandGatheredHits(gathered[b].data_ptr(), world, cap, cloud_points.data_ptr(), cloud_hits.data_ptr(),
                                   cloud_n.data_ptr())
 
+    # N > 1: with two frames in flight (LS_OPT_PIPELINE = 1, one stream: the finish + pack of frame i ride in the
+    # launch of frame i+1) the slot of frame i is complete on the stream after call i+1, so its all-gather starts
+    # one call later and has two frames of work to hide behind.  G(f) reads slot[f & 1], which the riders in the
+    # launch of frame f+3 write again: G(f) is waited for (and its cloud rebuilt) at the start of frame f+3.
+    lagged = (not single) and engine == "projection" and not args.no_pipeline
+    if lagged:
+        tr.setOption(capi.LS_OPT_PIPELINE, 1)
+    state = {"prev": None}
+
+    def start_gather(f):
+        b = f & 1
+        works[b] = shards.all_gather_slots(slots[b], gathered[b], async_op=True)
+
     def frame(i, copy=False):
         if single:
             update_and_trace(i, copy)
             return
         b = i & 1
+        if lagged:
+            collect(b ^ 1)                                 # G(i-3): its slot is written again by the riders in this launch
+            tr.setOutputBuffers(local_points.data_ptr(), slots[b].data_ptr() + shards.HEADER, slots[b].data_ptr(), cap)
+            update_and_trace(i, copy)
+            if state["prev"] is not None:
+                start_gather(state["prev"])                # frame i-1 is complete on the stream now
+            state["prev"] = i
+            return
         collect(b)                                         # slot b is free again (its gather is two frames old)
         tr.setOutputBuffers(local_points.data_ptr(), slots[b].data_ptr() + shards.HEADER, slots[b].data_ptr(), cap)
         update_and_trace(i, copy)                          # runs while the previous frame's gather is in flight
         collect(b ^ 1)                                     # previous frame: gather done -> its cloud
-        works[b] = shards.all_gather_slots(slots[b], gathered[b], async_op=True)
+        start_gather(i)
 
     def flush():
         if not single:
+            if lagged:
+                tr.flush()                                 # the last frame's riders
+                if state["prev"] is not None:
+                    collect(state["prev"] & 1)             # an older gather from the same slot pair first
+                    start_gather(state["prev"])
+                    state["prev"] = None
             collect(0)
             collect(1)
         elif pipeline:
@@ -444,7 +471,8 @@ def main():
                                 if args.pipeline == 1 else "; three frames in flight (whole frames rotate over three streams)")
                                if pipeline else ""),
                    "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
-                                  f"hit-record slots per frame (overlapped with the next frame), cloud rebuilt on every rank"
+                                  f"hit-record slots per frame (overlapped with the next "
+                                  f"{'two frames; two frames in flight per rank' if lagged else 'frame'}), cloud rebuilt on every rank"
                    if not single else ("single GPU" if world == 1 else
                                        f"{world} independent replicas (one sensor pose per GPU), no collective")},
         "frames_per_s": args.steps / elapsed,
