@@ -731,6 +731,14 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             d_hits = slot == 1 ? tr->hits_b.p : tr->hits_c.p;
             d_n = slot == 1 ? tr->d_n_points_b : tr->d_n_points_c;
         }
+        if (!tr->keys_armed) {
+            // first frame (or a new shard / raster): key set 0, all queue counters, the block counts.  In three-
+            // stream mode the other streams' frames use those counters too: the initialisation completes first
+            ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count, tr->row_counts.p);
+            if (multi) LS_HIP(hipStreamSynchronize(s));
+            tr->keys_armed = true;
+            tr->frame_parity = 0;
+        }
         if (multi) {
             // the frame's stream first sees what is enqueued on the handle's stream: the library's own mesh copies,
             // or anything at all when the stream is the caller's (host API calls are not cheap: only when needed)
@@ -739,11 +747,6 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             s = tr->slot_stream[slot];
             if (dep) LS_HIP(hipStreamWaitEvent(s, tr->ev_main, 0));
             tr->main_dirty = false;
-        }
-        if (!tr->keys_armed) {
-            ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count, tr->row_counts.p);
-            tr->keys_armed = true;
-            tr->frame_parity = 0;
         }
         if (slot == 1 && !tr->keys_b_armed) {
             LS_HIP(hipMemsetAsync(tr->best_keys_b.p, 0xFF, (size_t)shard_rays(tr) * 8, s));
