@@ -128,8 +128,10 @@ int ls_update_geometry_device_shared(ls_tracer *tr, const char *name, const floa
 int ls_update_geometry_transform(ls_tracer *tr, const char *name, const float affine3x4[12]);
 
 /* ---- ITracer::commitScene (ITracer.hpp:87; EmbreeTracer.cpp:290-295 rtcCommitScene;
- * OptixTracer.cpp:263-275, :517-571).  Transforms every geometry into the sensor frame and builds
- * the BVH on the device.  Returns 0, or -1 on an empty scene (OptixTracer.cpp:266-267). */
+ * OptixTracer.cpp:263-275, :517-571).  Fixes the geometry layout (global triangle ids in (geomID,
+ * primID) order); with the BVH engine it also transforms every geometry into the sensor frame and
+ * builds the BVH on the device (the projection engine has nothing to build).  Returns 0, or -1 on an
+ * empty scene (OptixTracer.cpp:266-267). */
 int ls_commit_scene(ls_tracer *tr);
 
 /* ---- ITracer::traceScene (ITracer.hpp:94; EmbreeTracer.cpp:297-367; OptixTracer.cpp:277-358).
@@ -138,7 +140,8 @@ int ls_commit_scene(ls_tracer *tr);
 int ls_trace_scene(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
 
 /* As ls_trace_scene but leaves the results on the device (out->points32 / hits are NULL,
- * n_points is not read back): nothing in it blocks the host. */
+ * n_points is not read back): nothing in it blocks the host.  The results are ordered on the handle's
+ * stream when the call returns -- unless LS_OPT_PIPELINE keeps several frames in flight (see there). */
 int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
 
 /* ---- ITracer::getGeometryCount (ITracer.hpp:101) */
