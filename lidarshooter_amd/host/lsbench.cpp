@@ -1,0 +1,181 @@
+// lsbench.cpp -- a C++ caller of the C ABI (include/lidarshooter_hip.h) with no Python and no PyTorch in
+// the process: sensor JSON and STL meshes through the host mirror (LidarDevice, loadPolygonFileSTL), the
+// meshes uploaded to HBM once, then frames streamed the way MeshProjector.cpp:446-464 drives a tracer --
+// updateGeometry for every mesh, commitScene, traceScene -- with the device-resident update variant.
+// Prints one JSON line.  It is the harness SURVEY.md 8b calls "lsbench"; tests/test_gpu_parity.py runs it
+// on the XT-32 scene and checks the reference's known answer (1781 points).
+//
+//   lsbench --config sensor.json [--mesh name=file.stl]... [--syn V H]  [--grid NX NY]
+//           [--frames K] [--warmup W] [--pipeline 0|1|2] [--engine 0|1|2]
+//   --syn V H    : replace the sensor's raster by V channels (+15 .. -25 deg) x H azimuths (0 .. 360 deg)
+//   --grid NX NY : add a synthetic ground of NX x NY cells (2 triangles each) over [-50, 50]^2 m
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lidarshooter_hip.h"
+#include "HostTypes.hpp"
+#include "LidarDevice.hpp"
+
+namespace {
+
+struct DeviceMesh {
+    std::string name;
+    void* d_verts = nullptr;
+    void* d_tris = nullptr;
+    uint32_t stride = 12, n_verts = 0, n_tris = 0;
+};
+
+#define HIP_OK(x)                                                                                  \
+    do {                                                                                           \
+        const hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } \
+    } while (0)
+
+int upload(DeviceMesh& m, const void* verts, size_t vbytes, const uint32_t* tris, size_t tbytes)
+{
+    HIP_OK(hipMalloc(&m.d_verts, vbytes));
+    HIP_OK(hipMalloc(&m.d_tris, tbytes));
+    HIP_OK(hipMemcpy(m.d_verts, verts, vbytes, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m.d_tris, tris, tbytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::string config;
+    std::vector<std::pair<std::string, std::string>> mesh_files;
+    int synV = 0, synH = 0, gridX = 0, gridY = 0, frames = 200, warmup = 50, pipeline = 0, engine = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) { std::fprintf(stderr, "%s: missing value\n", a.c_str()); std::exit(2); } };
+        if (a == "--config") { need(1); config = argv[++i]; }
+        else if (a == "--mesh") { need(1); const std::string v = argv[++i]; const auto eq = v.find('='); mesh_files.push_back({v.substr(0, eq), v.substr(eq + 1)}); }
+        else if (a == "--syn") { need(2); synV = std::atoi(argv[++i]); synH = std::atoi(argv[++i]); }
+        else if (a == "--grid") { need(2); gridX = std::atoi(argv[++i]); gridY = std::atoi(argv[++i]); }
+        else if (a == "--frames") { need(1); frames = std::atoi(argv[++i]); }
+        else if (a == "--warmup") { need(1); warmup = std::atoi(argv[++i]); }
+        else if (a == "--pipeline") { need(1); pipeline = std::atoi(argv[++i]); }
+        else if (a == "--engine") { need(1); engine = std::atoi(argv[++i]); }
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (config.empty()) { std::fprintf(stderr, "--config is required\n"); return 2; }
+
+    // ---- sensor: LidarDevice.cpp:482-633 through the host mirror; --syn swaps the raster, keeps the pose
+    lidarshooter::LidarDevice::Ptr dev;
+    try { dev = lidarshooter::LidarDevice::create(config); }
+    catch (const std::exception& e) { std::fprintf(stderr, "sensor config: %s\n", e.what()); return 2; }
+    ls_sensor_desc sd = dev->sensorDesc();
+    std::vector<float> syn_vertical;
+    if (synV > 0 && synH > 1) {
+        syn_vertical.resize(synV);
+        for (int v = 0; v < synV; ++v) syn_vertical[v] = 15.0f - static_cast<float>(v) * (40.0f / static_cast<float>(synV > 1 ? synV - 1 : 1));
+        sd.vertical_deg = syn_vertical.data();
+        sd.n_vertical = static_cast<uint32_t>(synV);
+        sd.h_begin = 0.0f;
+        sd.h_end = 360.0f;
+        sd.h_count = static_cast<uint32_t>(synH);
+    }
+    ls_tracer* tr = nullptr;
+    if (ls_tracer_create(&sd, 0, &tr) != LS_OK) { std::fprintf(stderr, "ls_tracer_create failed (no MI355X?)\n"); return 2; }
+    ls_tracer_set_option(tr, LS_OPT_ENGINE, engine);
+
+    // ---- meshes: STL files (pcl::io::loadPolygonFileSTL semantics) and / or a synthetic ground, resident in HBM
+    std::vector<DeviceMesh> meshes;
+    for (const auto& mf : mesh_files) {
+        lidarshooter::PolygonMesh pm;
+        if (lidarshooter::loadPolygonFileSTL(mf.second, pm) <= 0) { std::fprintf(stderr, "cannot load %s\n", mf.second.c_str()); return 2; }
+        std::vector<uint32_t> idx;
+        idx.reserve(pm.polygons.size() * 3);
+        for (const auto& p : pm.polygons) { idx.push_back(p.vertices[0]); idx.push_back(p.vertices[1]); idx.push_back(p.vertices[2]); }
+        DeviceMesh m;
+        m.name = mf.first;
+        m.stride = pm.cloud.point_step;
+        m.n_verts = pm.cloud.width * pm.cloud.height;
+        m.n_tris = static_cast<uint32_t>(pm.polygons.size());
+        if (upload(m, pm.cloud.data.data(), pm.cloud.data.size(), idx.data(), idx.size() * 4)) return 2;
+        meshes.push_back(m);
+    }
+    if (gridX > 0 && gridY > 0) {
+        const int nx = gridX + 1, ny = gridY + 1;
+        std::vector<float> v(static_cast<size_t>(nx) * ny * 3);
+        uint32_t lcg = 20240u;
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const float x = -50.0f + 100.0f * static_cast<float>(i) / static_cast<float>(gridX);
+                const float y = -50.0f + 100.0f * static_cast<float>(j) / static_cast<float>(gridY);
+                lcg = lcg * 1664525u + 1013904223u;
+                const float noise = (static_cast<float>(lcg >> 8) / 16777216.0f - 0.5f) * 0.02f;
+                float* p = &v[(static_cast<size_t>(j) * nx + i) * 3];
+                p[0] = x; p[1] = y; p[2] = 0.25f * std::sin(0.35f * x) * std::cos(0.27f * y) + noise;
+            }
+        std::vector<uint32_t> t;
+        t.reserve(static_cast<size_t>(gridX) * gridY * 6);
+        for (int j = 0; j < gridY; ++j)
+            for (int i = 0; i < gridX; ++i) {
+                const uint32_t a = static_cast<uint32_t>(j * nx + i), b = a + 1, c = a + nx, d = c + 1;
+                t.insert(t.end(), {a, b, d, a, d, c});
+            }
+        DeviceMesh m;
+        m.name = "grid";
+        m.n_verts = static_cast<uint32_t>(v.size() / 3);
+        m.n_tris = static_cast<uint32_t>(t.size() / 3);
+        if (upload(m, v.data(), v.size() * 4, t.data(), t.size() * 4)) return 2;
+        meshes.push_back(m);
+    }
+    if (meshes.empty()) { std::fprintf(stderr, "no meshes\n"); return 2; }
+    uint64_t total_tris = 0;
+    for (const auto& m : meshes) {
+        if (ls_add_geometry(tr, m.name.c_str(), LS_GEOMETRY_TYPE_TRIANGLE, static_cast<int>(m.n_verts), static_cast<int>(m.n_tris)) < 0) {
+            std::fprintf(stderr, "ls_add_geometry: %s\n", ls_last_error(tr));
+            return 2;
+        }
+        total_tris += m.n_tris;
+    }
+
+    // ---- outputs: three caller-owned sets (frames in flight rotate over them)
+    const uint32_t rays = ls_total_rays(tr);
+    struct Out { void *points = nullptr, *hits = nullptr; uint32_t* n = nullptr; } out[3];
+    for (auto& o : out) {
+        HIP_OK(hipMalloc(&o.points, static_cast<size_t>(rays) * 32));
+        HIP_OK(hipMalloc(&o.hits, static_cast<size_t>(rays) * 16));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&o.n), 4));
+    }
+    ls_tracer_set_option(tr, LS_OPT_PIPELINE, pipeline);
+    static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    auto frame = [&](uint32_t i) -> int {
+        for (const auto& m : meshes)   // MeshProjector.cpp:448-461: every mesh, every frame
+            if (ls_update_geometry_device_shared(tr, m.name.c_str(), kIdentity, m.d_verts, m.stride, static_cast<const uint32_t*>(m.d_tris)) < 0) return -2;
+        if (ls_commit_scene(tr) < -1) return -2;
+        const Out& o = out[i % 3];
+        if (ls_tracer_set_output_buffers(tr, o.points, o.hits, o.n, rays) < 0) return -2;
+        ls_frame f;
+        return ls_trace_scene_async(tr, i, &f) < -1 ? -2 : 0;
+    };
+    for (int i = 0; i < warmup; ++i)
+        if (frame(static_cast<uint32_t>(i))) { std::fprintf(stderr, "frame: %s\n", ls_last_error(tr)); return 2; }
+    ls_tracer_synchronize(tr);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < frames; ++i)
+        if (frame(static_cast<uint32_t>(i))) { std::fprintf(stderr, "frame: %s\n", ls_last_error(tr)); return 2; }
+    const double enqueue_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ls_tracer_synchronize(tr);
+    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    uint32_t n_points = 0;
+    HIP_OK(hipMemcpy(&n_points, out[(frames - 1) % 3].n, 4, hipMemcpyDeviceToHost));
+    std::printf("{\"harness\": \"lsbench\", \"rays_per_frame\": %u, \"triangles\": %llu, \"frames\": %d, \"pipeline\": %d, "
+                "\"us_per_frame\": %.3f, \"frames_per_s\": %.1f, \"mrays_per_s\": %.1f, \"host_enqueue_us_per_frame\": %.3f, "
+                "\"points_last_frame\": %u}\n",
+                rays, static_cast<unsigned long long>(total_tris), frames, pipeline, elapsed / frames * 1e6, frames / elapsed,
+                static_cast<double>(rays) * frames / elapsed / 1e6, enqueue_s / frames * 1e6, n_points);
+    ls_tracer_destroy(tr);
+    return 0;
+}

@@ -854,6 +854,28 @@ def test_pipeline_stress(oracle, capi, sensors, meshes, mode):
     tr.close()
 
 
+@pytest.mark.parametrize("uid,expected,mode", [("0000", 1781, 0), ("0000", 1781, 1), ("0001", 1769, 2)])
+def test_lsbench_cpp_harness(uid, expected, mode):
+    """The C++ streaming harness (lidarshooter_amd/host/lsbench.cpp: host mirror + C ABI + /opt/rocm's HIP
+    runtime, no Python or PyTorch in the process) on the reference's XT-32 scene, in every frame mode: the
+    last of 300 streamed frames has the reference's known point count (OptixTracer_test.cpp:122-169)."""
+    import json
+    import subprocess
+    from conftest import DATA
+    exe = os.path.join(os.path.dirname(DATA), "..", "..", "lidarshooter_amd", "lsbench")
+    exe = os.path.normpath(exe)
+    assert os.path.exists(exe), "lsbench not built (python -c 'import __graft_entry__ as g; g.build()')"
+    out = subprocess.run([exe, "--config", os.path.join(DATA, "config", f"hesai-pandar-XT-32-lidar_{uid}.json"),
+                          "--mesh", "ground=" + os.path.join(DATA, "mesh", "ground.stl"),
+                          "--mesh", "face=" + os.path.join(DATA, "mesh", "ben.stl"),
+                          "--frames", "300", "--warmup", "20", "--pipeline", str(mode)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["rays_per_frame"] == 4800 and rec["triangles"] == 162 + 5489
+    assert rec["points_last_frame"] == expected
+
+
 def test_edge_cases(oracle, capi, sensors, engine):
     """Degenerate inputs: one-triangle scene (a BVH with no internal node), coincident triangles in two
     geometries (equal t: lowest geomID wins), a geometry with zero triangles next to a real one, a
