@@ -609,7 +609,7 @@ def test_big_queue_chunks_and_overflow(oracle, capi, sensors, engine):
     tr.close()
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("LS_STRESS_SEEDS", "12")))))   # more seeds: LS_STRESS_SEEDS=300
 def test_projection_footprints_never_lose_a_hit(oracle, capi, sensors, seed):
     """Randomised stress of the projection engine's conservative footprints against the exhaustive
     GPU kernel: random sensor rasters (channel sets, azimuth ranges, sweep direction, shard), random
