@@ -407,7 +407,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
 }
 
 template <bool COUNT, bool LDS_TABLES, bool MULTI>
-__global__ __launch_bounds__(kBlock) void k_project(ProjectParams pp, GeomBatch batch,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_project(ProjectParams pp, GeomBatch batch,
                                                     unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                                     uint32_t big_capacity, uint32_t *__restrict__ big_count,
                                                     unsigned long long *__restrict__ stats)
@@ -660,8 +660,9 @@ __global__ __launch_bounds__(kBlock) void k_finish_pack(ProjectParams pp, Finish
 
 // One launch per frame: the workgroups of this frame's k_project and, from workgroup fp_start on, those
 // of the previous frame's finish + pack (contiguous and in order, as their chained prefix needs).
+// (at most 80 SGPRs: one more and a CU admits 7 of these workgroups instead of 8, MI355X_MICROARCH.md "Residency")
 template <bool LDS_TABLES, bool MULTI>
-__global__ __launch_bounds__(kBlock) void k_frame(ProjectParams pp, GeomBatch batch, uint32_t fp_start,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_frame(ProjectParams pp, GeomBatch batch, uint32_t fp_start,
                                                   unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                                   uint32_t big_capacity, uint32_t *__restrict__ big_count, FinishPackArgs fa)
 {
