@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LS_ABI_VERSION 1
+#define LS_ABI_VERSION 2
 
 typedef struct ls_tracer ls_tracer;
 
@@ -60,6 +60,27 @@ typedef struct ls_sensor_desc {
     float t[3];                /* (baseToOrigin.tx, baseToOrigin.ty, sensorToBase.tz) (:383-388)   */
 } ls_sensor_desc;
 
+/* The same sensor as ray-direction factor tables, for a caller that holds a live LidarDevice but not its
+ * private fields (the ROS-typed adapter integration/HipTracer.hpp recovers these through the public
+ * API only: LidarDevice::nextRay1 and originToSensor, LidarDevice.hpp:180,252).  Ray (v, h) has the
+ * direction (sin_theta[v]*cos_phi[h], sin_theta[v]*sin_phi[h], cos_theta[v]) -- the products the
+ * reference forms (LidarDevice.cpp:310-316); the kernels multiply exactly these entries.
+ * elevation_deg / h_begin_deg / h_step_deg only feed conservative footprint bounds (0.005 degrees of
+ * slack), so values good to 1e-4 degrees are enough. */
+typedef struct ls_sensor_tables {
+    const float *sin_theta;     /* [n_vertical]                                              */
+    const float *cos_theta;     /* [n_vertical]                                              */
+    const float *elevation_deg; /* [n_vertical] degrees above the horizon (90 - theta)       */
+    uint32_t n_vertical;
+    const float *sin_phi;       /* [h_count]                                                 */
+    const float *cos_phi;       /* [h_count]                                                 */
+    uint32_t h_count;
+    float h_begin_deg;          /* azimuth of column 0                                       */
+    float h_step_deg;           /* azimuth of column h = h_begin_deg + h_step_deg * h        */
+    float Rinv[9];              /* as in ls_sensor_desc                                      */
+    float t[3];
+} ls_sensor_tables;
+
 /* One hit, 16 bytes.  Points and hit records are emitted in ray-index order (r = v*H + h,
  * LidarDevice.cpp:824-845), one record per point. */
 typedef struct ls_hit {
@@ -86,6 +107,7 @@ typedef struct ls_frame {
 /* ---- lifetime: EmbreeTracer::create / ~EmbreeTracer (EmbreeTracer.cpp:10-70),
  *      OptixTracer::create (OptixTracer.hpp:91) --------------------------------------------- */
 int ls_tracer_create(const ls_sensor_desc *sensor, int hip_device, ls_tracer **out);
+int ls_tracer_create_tables(const ls_sensor_tables *sensor, int hip_device, ls_tracer **out);
 void ls_tracer_destroy(ls_tracer *tr);
 
 /* ---- ITracer::addGeometry (ITracer.hpp:50; EmbreeTracer.cpp:115-218; OptixTracer.cpp:63-133).
@@ -100,7 +122,10 @@ int ls_remove_geometry(ls_tracer *tr, const char *name);
  * MeshTransformer.cpp:142-205).  affine3x4: row-major [linear | translation].  verts: n_vertices
  * records of vert_stride bytes whose first 12 bytes are x,y,z float32 (pcl cloud.data with
  * point_step, MeshTransformer.cpp:176-181).  tri_idx: 3*n_elements vertex indices (polygons[i].vertices,
- * MeshTransformer.cpp:512-518); NULL keeps the indices of the previous update.  Host pointers. */
+ * MeshTransformer.cpp:512-518); NULL keeps the indices of the previous update.  Host pointers; the
+ * caller may reuse them as soon as the call returns (MeshProjector.cpp:448-461 does): the data is copied
+ * by the library's worker threads into a pinned staging buffer, chunk by chunk, and each chunk's DMA is
+ * enqueued on the handle's stream behind it -- the call never waits for the device. */
 int ls_update_geometry(ls_tracer *tr, const char *name, const float affine3x4[12], const void *verts,
                        uint32_t vert_stride, const uint32_t *tri_idx);
 
@@ -126,6 +151,11 @@ int ls_update_geometry_device_shared(ls_tracer *tr, const char *name, const floa
 /* Only the rigid transform of an already uploaded mesh changes (AffineMesh pose integration,
  * AffineMesh.cpp:108-128): no vertex traffic at all. */
 int ls_update_geometry_transform(ls_tracer *tr, const char *name, const float affine3x4[12]);
+
+/* T = Translation(lin) * Rz(ang.z) * Ry(ang.y) * Rx(ang.x) as the row-major 3x4 matrix the calls above take
+ * (MeshTransformer.cpp:467-477, Eigen's AngleAxis arithmetic) -- lets the adapter turn the (translation,
+ * rotation) overload of ITracer::updateGeometry into ls_update_geometry_transform when the mesh is unchanged. */
+void ls_affine_from_components(const float lin[3], const float ang[3], float affine3x4[12]);
 
 /* ---- ITracer::commitScene (ITracer.hpp:87; EmbreeTracer.cpp:290-295 rtcCommitScene;
  * OptixTracer.cpp:263-275, :517-571).  Fixes the geometry layout (global triangle ids in (geomID,
@@ -212,10 +242,32 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
                                  * library's own output buffers rotate with the frames (a caller that sets output
                                  * buffers rotates them itself), and meshes handed over with
                                  * ls_update_geometry_device_shared must stay unchanged while frames are in flight.  */
+#define LS_OPT_HOST_OUTPUT 7    /* synchronous ls_trace_scene: 1 (default) the pack kernel writes points (and hit
+                                 *    records) straight into the pinned host buffers that ls_frame returns -- one
+                                 *    host wait per frame, no copy engine; 0: device buffers, then count + sized D2H
+                                 *    copies (two waits).                                                      */
+#define LS_OPT_READBACK_HITS 8  /* synchronous ls_trace_scene: 1 (default) ls_frame.hits is filled; 0: the 16-byte
+                                 *    hit records stay on the device (ls_frame.hits = NULL, d_hits valid) -- the ITracer
+                                 *    adapter only needs the 32-byte points.                                   */
+#define LS_OPT_DEBUG_FAULT 9    /* test hook: 1 makes the next pipelined frame publish a wrong epoch, so that the
+                                 *    chained prefix gives up and the device status word is raised (one frame).  */
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */
 int ls_tracer_set_option(ls_tracer *tr, int option, int value);
+
+/* Copy `bytes` from src to dst with the library's worker threads (both host pointers).  The adapter
+ * uses it to move a frame's points from the pinned buffer of ls_frame into PointCloud2::data; a single
+ * thread moves 8 MB in ~0.7 ms, the PCIe transfer of the same bytes takes 0.15 ms. */
+int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
+
+/* Facts about the handle: returns the value or a negative ls_status. */
+#define LS_INFO_CONCURRENT_STREAMS 1 /* LS_OPT_PIPELINE = 2: mutually concurrent streams found by the calibration
+                                      *    (3 = full three-stream mode; fewer: the handle runs mode 1 instead)    */
+#define LS_INFO_PIPELINE_MODE 2      /* the frames-in-flight mode actually in use (0, 1 or 2)                    */
+#define LS_INFO_DEVICE_STATUS 3      /* sticky device status word (0 = ok); read-and-clear, synchronises          */
+#define LS_INFO_HOST_THREADS 4       /* worker threads of the host copy pool                                     */
+long ls_get_info(ls_tracer *tr, int what);
 
 /* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded
  * since the previous call; recording never synchronises, this call does.  Returns the number of

@@ -1,0 +1,570 @@
+// HipTracer.hpp -- lidarshooter::ITracer backend for AMD MI355X, over the C ABI of liblidarshooter_hip.so.
+//
+// Drop this file into ros_ws/src/lidarshooter/src/ next to EmbreeTracer.hpp / OptixTracer.hpp; nothing else
+// of lidarshooter changes except the backend-selection line (mainwindow.cpp:256-258) and three CMake lines
+// (INTEGRATION.md).  It compiles against the UNMODIFIED reference headers: everything it needs from the
+// sensor it gets through LidarDevice's public interface (LidarDevice.hpp:116-300) --
+//   * ray directions: one walk of nextRay1() over the V*H rays at construction (LidarDevice.cpp:160-198),
+//     from which the exact libm factor tables sin/cos(theta_v), sin/cos(phi_h) are recovered and verified
+//     bit for bit against every walked direction;
+//   * sensor pose: originToSensorInverse(0) = t exactly, and originToSensor(t + 2^k e_i) = 2^k * Rinv[:,i]
+//     exactly (LidarDevice.cpp:383-401);
+//   * header: initMessage() every frame (LidarDevice.cpp:94-115), as EmbreeTracer::traceScene does.
+//
+// Per frame (MeshProjector.cpp:446-464: updateGeometry for every mesh, commitScene, traceScene):
+//   * polygons are flattened and uploaded once per mesh and again only when their fingerprint changes (the
+//     reference never edits them after pcl::io::loadPolygonFileSTL, mainwindow.cpp:146);
+//   * vertices are uploaded every frame by default (MeshProjector::affineMeshCallback rewrites the cloud in
+//     place, MeshProjector.cpp:306-307, so the bytes have to be read anyway); setMeshPolicy(SkipUnchanged)
+//     or LIDARSHOOTER_HIP_SKIP_UNCHANGED=1 makes an update whose cloud still carries the same
+//     (buffer, size, header.seq, header.stamp, 256-vertex probe) a transform-only update: no copy at all
+//     -- what a joystick-driven pose change is (AffineMesh.cpp:108-128);
+//   * the vertex transform (MeshTransformer.cpp:142-205), ray generation, closest hit and 32-byte point
+//     packing (XYZIRBytes.cpp:24-40) run on the GPU; the points land in pinned host memory with one host
+//     wait and are moved into PointCloud2::data by the library's copy threads.
+#pragma once
+
+#include <lidarshooter_hip.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "Exceptions.hpp"
+#include "ITracer.hpp"
+#include "LidarDevice.hpp"
+
+namespace lidarshooter
+{
+
+class HipTracer : public ITracer, public std::enable_shared_from_this<HipTracer>
+{
+public:
+    using Ptr = std::shared_ptr<HipTracer>;
+    using ConstPtr = std::shared_ptr<HipTracer const>;
+
+    /// What an updateGeometry() call does with the vertex data it is handed
+    enum class MeshPolicy {
+        UploadAlways,   ///< default: always correct, ~0.15 ms per 8 MB of vertices
+        SkipUnchanged   ///< same buffer + size + header + probe as last time -> transform-only update
+    };
+
+    /// Same signature as EmbreeTracer::create (EmbreeTracer.hpp:51) / OptixTracer::create (OptixTracer.hpp:91)
+    static HipTracer::Ptr create(LidarDevice::Ptr _sensorConfig, sensor_msgs::PointCloud2::Ptr _traceStorage = nullptr,
+                                 std::shared_ptr<spdlog::logger> _logger = nullptr, int _hipDevice = 0)
+    {
+        return HipTracer::Ptr(new HipTracer(_sensorConfig, _traceStorage, _logger, _hipDevice));
+    }
+
+    ITracer::Ptr getPtr() override { return shared_from_this(); }
+
+    ~HipTracer() override
+    {
+        if (_handle != nullptr) ls_tracer_destroy(_handle);
+    }
+
+    /// ITracer.hpp:50; returns the geometry id like EmbreeTracer (lowest free id), 0 for an unsupported type
+    int addGeometry(const std::string& _meshName, enum RTCGeometryType _geometryType, int _numVertices, int _numElements) override
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        const int rc = ls_add_geometry(_handle, _meshName.c_str(), static_cast<int>(_geometryType), _numVertices, _numElements);
+        if (rc == LS_ERR_UNSUPPORTED_TYPE) return 0;   // EmbreeTracer.cpp:200-201 `return false`
+        if (rc < 0) return rc;
+        MeshState state;
+        state.numVertices = static_cast<std::size_t>(_numVertices);
+        state.numElements = static_cast<std::size_t>(_numElements);
+        _meshes[_meshName] = std::move(state);
+        setGeometryCount(getGeometryCount() + 1);
+        return rc;
+    }
+
+    /// ITracer.hpp:59; -1 when the name is unknown (EmbreeTracer.cpp:224-225); the scene is re-committed (:252)
+    int removeGeometry(const std::string& _meshName) override
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        const int rc = ls_remove_geometry(_handle, _meshName.c_str());
+        if (rc >= 0) {
+            _meshes.erase(_meshName);
+            setGeometryCount(getGeometryCount() - 1);
+        }
+        return rc < -1 ? -1 : rc;
+    }
+
+    /// ITracer.hpp:69
+    int updateGeometry(const std::string& _meshName, Eigen::Affine3f _transform, pcl::PolygonMesh::Ptr& _mesh) override
+    {
+        float affine[12];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) affine[4 * i + j] = _transform(i, j);
+        return updateFromMesh(_meshName, affine, _mesh);
+    }
+
+    /// ITracer.hpp:80; T = Translation * Rz * Ry * Rx (MeshTransformer.cpp:467-477), built by the library
+    int updateGeometry(const std::string& _meshName, Eigen::Vector3f _translation, Eigen::Vector3f _rotation,
+                       pcl::PolygonMesh::Ptr& _mesh) override
+    {
+        const float lin[3] = {_translation.x(), _translation.y(), _translation.z()};
+        const float ang[3] = {_rotation.x(), _rotation.y(), _rotation.z()};
+        float affine[12];
+        ls_affine_from_components(lin, ang, affine);
+        return updateFromMesh(_meshName, affine, _mesh);
+    }
+
+    /// ITracer.hpp:87; -1 on an empty scene (OptixTracer.cpp:266-267)
+    int commitScene() override
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        const int rc = ls_commit_scene(_handle);
+        if (rc < -1) throw TraceException(__FILE__, ls_last_error(_handle), rc);
+        return rc;
+    }
+
+    /// ITracer.hpp:94; fills the shared PointCloud2 in place (EmbreeTracer.cpp:297-367)
+    int traceScene(std::uint32_t _frameIndex) override
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        auto cloud = getTraceCloud();
+        getSensorConfig()->initMessage(cloud, static_cast<int>(_frameIndex));
+        getSensorConfig()->reset();
+        ls_frame frame;
+        const int rc = ls_trace_scene(_handle, _frameIndex, &frame);
+        if (rc < -1) {
+            cloud->data.clear();
+            throw TraceException(__FILE__, ls_last_error(_handle), rc);
+        }
+        // no clear() first: shrinking costs nothing and growing value-initialises only the difference
+        const std::size_t bytes = static_cast<std::size_t>(frame.n_points) * 32u;
+        cloud->data.resize(bytes);
+        if (bytes != 0) ls_parallel_copy(cloud->data.data(), frame.points32, bytes);
+        cloud->width = frame.n_points;   // EmbreeTracer.cpp:364; height 1, row_step 0 from initMessage
+        return rc;
+    }
+
+    // ---- the per-name getters of EmbreeTracer (EmbreeTracer.cpp:369-439): unknown names throw
+    int getGeometryId(const std::string& _meshName) const
+    {
+        const int rc = ls_geometry_id(_handle, _meshName.c_str());
+        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in geometry ID map", 7);
+        return rc;
+    }
+    long getVertexCount(const std::string& _meshName) const
+    {
+        const long rc = ls_vertex_count(_handle, _meshName.c_str());
+        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in vertex count map", 3);
+        return rc;
+    }
+    long getElementCount(const std::string& _meshName) const
+    {
+        const long rc = ls_element_count(_handle, _meshName.c_str());
+        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in element count map", 5);
+        return rc;
+    }
+
+    void setMeshPolicy(MeshPolicy _policy) { _policy_ = _policy; }
+    MeshPolicy getMeshPolicy() const { return _policy_; }
+    /// Forget what is known about a mesh: its next update re-sends vertices and polygons
+    void invalidateMesh(const std::string& _meshName)
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        auto it = _meshes.find(_meshName);
+        if (it != _meshes.end()) it->second.haveVertices = it->second.haveElements = false;
+    }
+    /// Number of updateGeometry calls that copied vertex data / that were transform-only (diagnostics)
+    std::uint64_t getUploadCount() const { return _uploads; }
+    std::uint64_t getSkippedUploadCount() const { return _skipped; }
+    /// The C-ABI handle (asynchronous / multi-GPU extensions, include/lidarshooter_hip.h)
+    ls_tracer* getHandle() { return _handle; }
+
+private:
+    struct MeshState {
+        std::size_t numVertices = 0, numElements = 0;
+        bool haveVertices = false, haveElements = false;
+        // identity of the data handed over last time
+        const void* polygonStorage = nullptr;
+        std::size_t polygonCount = 0;
+        std::uint64_t polygonProbe = 0;
+        const void* vertexStorage = nullptr;
+        std::size_t vertexBytes = 0;
+        std::uint64_t vertexProbe = 0, stamp = 0;
+        std::uint32_t seq = 0, pointStep = 0;
+        std::vector<std::uint32_t> flat;   // scratch of the one-off polygon flatten
+    };
+
+    HipTracer(LidarDevice::Ptr _sensorConfig, sensor_msgs::PointCloud2::Ptr _traceStorage, std::shared_ptr<spdlog::logger> __logger,
+              int _hipDevice)
+        : ITracer(_sensorConfig, _traceStorage, __logger)
+    {
+        if (const char* e = std::getenv("LIDARSHOOTER_HIP_SKIP_UNCHANGED"))
+            if (e[0] == '1') _policy_ = MeshPolicy::SkipUnchanged;
+        SensorProbe probe(*_sensorConfig);
+        const ls_sensor_tables tables = probe.tables();
+        const int rc = ls_tracer_create_tables(&tables, _hipDevice, &_handle);
+        if (rc != LS_OK)
+            throw TraceException(__FILE__, rc == LS_ERR_NO_DEVICE ? "no usable HIP device for the MI355X tracer (there is no CPU fallback)"
+                                                                  : "ls_tracer_create_tables rejected the probed sensor", rc);
+        ls_tracer_set_option(_handle, LS_OPT_READBACK_HITS, 0);   // the cloud only carries the 32-byte points
+        if (_logger) _logger->debug("HipTracer: {} channels x {} azimuths, {} host copy threads", tables.n_vertical, tables.h_count,
+                                    ls_get_info(_handle, LS_INFO_HOST_THREADS));
+    }
+
+    // FNV-1a over a few words: identity probes, not integrity checks
+    static std::uint64_t mix(std::uint64_t h, std::uint64_t x)
+    {
+        for (int i = 0; i < 8; ++i) { h ^= (x >> (8 * i)) & 0xFFu; h *= 1099511628211ull; }
+        return h;
+    }
+
+    static std::uint64_t probePolygons(const pcl::PolygonMesh& mesh)
+    {
+        std::uint64_t h = 1469598103934665603ull;
+        const std::size_t n = mesh.polygons.size(), step = n > 64 ? n / 64 : 1;
+        for (std::size_t i = 0; i < n; i += step) {
+            const auto& p = mesh.polygons[i].vertices;
+            h = mix(h, p.size());
+            for (std::size_t k = 0; k < p.size() && k < 4; ++k) h = mix(h, static_cast<std::uint64_t>(p[k]));
+        }
+        if (n) {
+            const auto& p = mesh.polygons[n - 1].vertices;
+            for (std::size_t k = 0; k < p.size() && k < 4; ++k) h = mix(h, static_cast<std::uint64_t>(p[k]));
+        }
+        return h;
+    }
+
+    static std::uint64_t probeVertices(const std::uint8_t* data, std::size_t count, std::size_t pointStep)
+    {
+        std::uint64_t h = 1469598103934665603ull;
+        const std::size_t step = count > 256 ? count / 256 : 1;
+        for (std::size_t i = 0; i < count; i += step) {
+            std::uint64_t w[2] = {0, 0};
+            std::memcpy(w, data + i * pointStep, 12);
+            h = mix(mix(h, w[0]), w[1]);
+        }
+        return h;
+    }
+
+    int updateFromMesh(const std::string& _meshName, const float affine[12], pcl::PolygonMesh::Ptr& _mesh)
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        auto it = _meshes.find(_meshName);
+        if (it == _meshes.end())
+            throw TraceException(__FILE__, "Geometry key does not exist in geometry types map", 8);   // EmbreeTracer.cpp:102-113
+        if (!_mesh) throw TraceException(__FILE__, "updateGeometry was handed a null mesh", 1);
+        MeshState& st = it->second;
+        const auto& cloud = _mesh->cloud;
+        const std::size_t pointStep = cloud.point_step;
+        if (pointStep < 12 || (pointStep & 3u) != 0)
+            throw TraceException(__FILE__, "mesh cloud point_step must be a multiple of 4 and hold x, y, z float32 first", 1);
+        if (cloud.data.size() < st.numVertices * pointStep)
+            throw TraceException(__FILE__, "mesh cloud holds fewer vertices than addGeometry registered", 1);
+        if (_mesh->polygons.size() != st.numElements)
+            throw TraceException(__FILE__, "mesh holds a different number of polygons than addGeometry registered", 1);
+
+        // ---- polygons: flatten + upload only when they are new (MeshTransformer.cpp:486-520 does it every frame)
+        const std::uint32_t* indices = nullptr;
+        const std::uint64_t polygonProbe = probePolygons(*_mesh);
+        if (!st.haveElements || st.polygonStorage != static_cast<const void*>(_mesh->polygons.data()) ||
+            st.polygonCount != _mesh->polygons.size() || st.polygonProbe != polygonProbe) {
+            st.flat.resize(st.numElements * 3);
+            std::size_t k = 0;
+            for (const auto& polygon : _mesh->polygons) {
+                if (polygon.vertices.size() != 3)
+                    throw TraceException(__FILE__, "Geometry does not match element vertex count", 1);
+                st.flat[k++] = static_cast<std::uint32_t>(polygon.vertices[0]);
+                st.flat[k++] = static_cast<std::uint32_t>(polygon.vertices[1]);
+                st.flat[k++] = static_cast<std::uint32_t>(polygon.vertices[2]);
+            }
+            indices = st.flat.data();
+        }
+
+        // ---- vertices
+        const std::uint8_t* vertexData = cloud.data.data();
+        const std::size_t vertexBytes = st.numVertices * pointStep;
+        const std::uint64_t stamp = static_cast<std::uint64_t>(cloud.header.stamp);
+        const std::uint32_t seq = static_cast<std::uint32_t>(cloud.header.seq);
+        bool unchanged = false;
+        std::uint64_t vertexProbe = 0;
+        if (_policy_ == MeshPolicy::SkipUnchanged) {
+            vertexProbe = probeVertices(vertexData, st.numVertices, pointStep);
+            unchanged = st.haveVertices && indices == nullptr && st.vertexStorage == static_cast<const void*>(vertexData) &&
+                        st.vertexBytes == vertexBytes && st.pointStep == pointStep && st.seq == seq && st.stamp == stamp &&
+                        st.vertexProbe == vertexProbe;
+        }
+        int rc;
+        if (unchanged) {
+            rc = ls_update_geometry_transform(_handle, _meshName.c_str(), affine);
+            ++_skipped;
+        } else {
+            rc = ls_update_geometry(_handle, _meshName.c_str(), affine, vertexData, static_cast<std::uint32_t>(pointStep), indices);
+            ++_uploads;
+        }
+        if (rc < 0) throw TraceException(__FILE__, ls_last_error(_handle), rc);
+        st.haveVertices = true;
+        st.vertexStorage = vertexData;
+        st.vertexBytes = vertexBytes;
+        st.pointStep = static_cast<std::uint32_t>(pointStep);
+        st.seq = seq;
+        st.stamp = stamp;
+        st.vertexProbe = vertexProbe;
+        if (indices != nullptr) {
+            st.haveElements = true;
+            st.polygonStorage = _mesh->polygons.data();
+            st.polygonCount = _mesh->polygons.size();
+            st.polygonProbe = polygonProbe;
+            std::vector<std::uint32_t>().swap(st.flat);   // 12 MB per million triangles: not kept
+        }
+        return 0;
+    }
+
+public:
+    // ------------------------------------------------------------------------------------------------
+    // Everything the tracer needs to know about the sensor, recovered through LidarDevice's public
+    // interface and checked bit for bit against it.  The reference forms ray (v, h) as
+    //   theta = float((90.0 - chi_v) * pi / 180), phi = float((begin + step * float(h)) * pi / 180),
+    //   d = (sinf(theta) cosf(phi), sinf(theta) sinf(phi), cosf(theta))          (LidarDevice.cpp:176-186)
+    // so two floats (begin, step) and one float per channel (theta_v) determine all V*H directions; they
+    // are found by trying the few floats around an arctangent estimate and keeping the ones that reproduce
+    // every walked direction exactly.
+    // ------------------------------------------------------------------------------------------------
+    class SensorProbe
+    {
+    public:
+        explicit SensorProbe(LidarDevice& device)
+        {
+            V = device.getTotalChannels();
+            H = device.getScanRayCount();
+            if (V == 0 || H < 2 || static_cast<unsigned long long>(V) * H != device.getTotalRays())
+                fail("the device reports an empty or inconsistent ray raster");
+            walk(device);
+            recoverChannels();
+            recoverColumns();
+            verify();
+            recoverPose(device);
+        }
+
+        ls_sensor_tables tables() const
+        {
+            ls_sensor_tables t;
+            std::memset(&t, 0, sizeof(t));
+            t.sin_theta = sinTheta.data();
+            t.cos_theta = cosTheta.data();
+            t.elevation_deg = elevationDeg.data();
+            t.n_vertical = V;
+            t.sin_phi = sinPhi.data();
+            t.cos_phi = cosPhi.data();
+            t.h_count = H;
+            t.h_begin_deg = beginDeg;
+            t.h_step_deg = stepDeg;
+            std::memcpy(t.Rinv, Rinv, sizeof(Rinv));
+            std::memcpy(t.t, translation, sizeof(translation));
+            return t;
+        }
+
+    private:
+        static constexpr int kNeighbours = 6;   // floats tried on each side of an estimate
+        static constexpr double kPi = 3.14159265358979323846;
+
+        [[noreturn]] static void fail(const std::string& what)
+        {
+            throw TraceException(__FILE__, "HipTracer cannot derive the sensor from LidarDevice's public interface: " + what, 1);
+        }
+        static float stepFloat(float x, int n)
+        {
+            for (; n > 0; --n) x = std::nextafter(x, std::numeric_limits<float>::infinity());
+            for (; n < 0; ++n) x = std::nextafter(x, -std::numeric_limits<float>::infinity());
+            return x;
+        }
+        static bool sameBits(float a, float b) { return std::memcmp(&a, &b, 4) == 0 || (a == 0.0f && b == 0.0f); }
+
+        void walk(LidarDevice& device)
+        {
+            const std::size_t n = static_cast<std::size_t>(V) * H;
+            dx.resize(n);
+            dy.resize(n);
+            dz.resize(n);
+            device.reset();
+            for (std::size_t r = 0; r < n; ++r) {   // channel-major: r = v * H + h (LidarDevice.cpp:824-845)
+                RTCRayHit ray;
+                int valid = -1;
+                device.nextRay1(ray, &valid);
+                dx[r] = ray.ray.dir_x;
+                dy[r] = ray.ray.dir_y;
+                dz[r] = ray.ray.dir_z;
+            }
+            device.reset();
+        }
+
+        // per channel: every float theta near the estimate with cosf(theta) == dz; the sine is settled later
+        void recoverChannels()
+        {
+            cosTheta.resize(V);
+            thetaCandidates.resize(V);
+            double best = -1.0;
+            for (unsigned v = 0; v < V; ++v) {
+                const std::size_t r0 = static_cast<std::size_t>(v) * H;
+                for (unsigned h = 1; h < H; ++h)
+                    if (!sameBits(dz[r0 + h], dz[r0])) fail("a channel's z direction varies with azimuth");
+                cosTheta[v] = dz[r0];
+                const double rho = std::hypot(static_cast<double>(dx[r0]), static_cast<double>(dy[r0]));
+                const float estimate = static_cast<float>(std::atan2(rho, static_cast<double>(dz[r0])));
+                for (int k = -kNeighbours; k <= kNeighbours; ++k) {
+                    const float theta = stepFloat(estimate, k);
+                    if (sameBits(std::cos(theta), cosTheta[v])) thetaCandidates[v].push_back(theta);
+                }
+                if (thetaCandidates[v].empty()) fail("no float polar angle reproduces a channel's z direction");
+                if (rho > best) { best = rho; reference = v; }
+            }
+            if (!(best > 1e-3)) fail("every channel points along the vertical axis");
+        }
+
+        bool columnsMatch(unsigned v, float sine, const std::vector<float>& c, const std::vector<float>& s) const
+        {
+            const std::size_t r0 = static_cast<std::size_t>(v) * H;
+            for (unsigned h = 0; h < H; ++h)
+                if (!sameBits(sine * c[h], dx[r0 + h]) || !sameBits(sine * s[h], dy[r0 + h])) return false;
+            return true;
+        }
+
+        void buildColumns(float begin, float step, std::vector<float>& c, std::vector<float>& s) const
+        {
+            for (unsigned h = 0; h < H; ++h) {
+                const float prePhi = begin + step * static_cast<float>(h);
+                const float phi = static_cast<float>(static_cast<double>(prePhi) * kPi / 180.0);
+                c[h] = std::cos(phi);
+                s[h] = std::sin(phi);
+            }
+        }
+
+        // (begin, step): estimated from the arctangents of the reference channel, then the floats around the
+        // estimates are tried until one pair reproduces that channel's H directions exactly
+        void recoverColumns()
+        {
+            const std::size_t r0 = static_cast<std::size_t>(reference) * H;
+            std::vector<double> az(H);
+            for (unsigned h = 0; h < H; ++h) az[h] = std::atan2(static_cast<double>(dy[r0 + h]), static_cast<double>(dx[r0 + h]));
+            double span = 0.0;
+            for (unsigned h = 0; h + 1 < H; ++h) {
+                double d = az[h + 1] - az[h];
+                while (d > kPi) d -= 2.0 * kPi;
+                while (d <= -kPi) d += 2.0 * kPi;
+                span += d;
+            }
+            const double stepEstimate = span / static_cast<double>(H - 1) * 180.0 / kPi;
+            const double beginEstimate = az[0] * 180.0 / kPi;
+            std::vector<float> c(H), s(H);
+            // a two-column raster cannot tell a step from its 360-degree aliases; nor can any raster tell begin
+            // from begin +- 360: the aliases are tried too (they differ in the rounding of phi)
+            for (int beginTurn = 0; beginTurn < 3; ++beginTurn) {
+                static const double turns[3] = {0.0, 360.0, -360.0};
+                for (int stepTurn = 0; stepTurn < (H == 2 ? 3 : 1); ++stepTurn) {
+                    const float b0 = static_cast<float>(beginEstimate + turns[beginTurn]);
+                    const float s0 = static_cast<float>(stepEstimate + turns[stepTurn]);
+                    for (int kb = 0; kb <= 2 * kNeighbours; ++kb) {
+                        const float begin = stepFloat(b0, (kb & 1) ? (kb + 1) / 2 : -(kb / 2));
+                        for (int ks = 0; ks <= 2 * kNeighbours; ++ks) {
+                            const float step = stepFloat(s0, (ks & 1) ? (ks + 1) / 2 : -(ks / 2));
+                            buildColumns(begin, step, c, s);
+                            for (float theta : thetaCandidates[reference]) {
+                                if (!columnsMatch(reference, std::sin(theta), c, s)) continue;
+                                if (!allChannelsMatch(c, s)) continue;
+                                beginDeg = begin;
+                                stepDeg = step;
+                                cosPhi = c;
+                                sinPhi = s;
+                                return;
+                            }
+                        }
+                    }
+                }
+            }
+            fail("no (begin, step) pair reproduces the walked azimuth directions");
+        }
+
+        // settles sin(theta_v) for every channel against the given columns
+        bool allChannelsMatch(const std::vector<float>& c, const std::vector<float>& s)
+        {
+            std::vector<float> sines(V), elevations(V);
+            for (unsigned v = 0; v < V; ++v) {
+                bool found = false;
+                for (float theta : thetaCandidates[v]) {
+                    const float sine = std::sin(theta);
+                    if (!columnsMatch(v, sine, c, s)) continue;
+                    sines[v] = sine;
+                    elevations[v] = static_cast<float>(90.0 - static_cast<double>(theta) * 180.0 / kPi);
+                    found = true;
+                    break;
+                }
+                if (!found) return false;
+            }
+            sinTheta = sines;
+            elevationDeg = elevations;
+            return true;
+        }
+
+        void verify() const
+        {
+            for (unsigned v = 0; v < V; ++v)
+                for (unsigned h = 0; h < H; ++h) {
+                    const std::size_t r = static_cast<std::size_t>(v) * H + h;
+                    if (!sameBits(sinTheta[v] * cosPhi[h], dx[r]) || !sameBits(sinTheta[v] * sinPhi[h], dy[r]) || !sameBits(cosTheta[v], dz[r]))
+                        fail("the recovered tables do not reproduce every ray direction");
+                }
+        }
+
+        // LidarDevice.cpp:383-401: originToSensorInverse(q) = R q + t, originToSensor(p) = Rinv (p - t)
+        void recoverPose(LidarDevice& device)
+        {
+            Eigen::Vector3f origin(0.0f, 0.0f, 0.0f);
+            device.originToSensorInverse(origin);   // R * 0 + t = t, exactly
+            translation[0] = origin.x();
+            translation[1] = origin.y();
+            translation[2] = origin.z();
+            for (int i = 0; i < 3; ++i) {
+                // a power of two that adds to and subtracts from t_i without rounding: (t_i + s) - t_i == s
+                float scale = 0.0f, shifted = 0.0f;
+                for (int k = 0; k <= 40 && scale == 0.0f; ++k) {
+                    for (int sign = 0; sign < 2 && scale == 0.0f; ++sign) {
+                        const float s = std::ldexp(1.0f, sign ? -k : k);
+                        volatile float x = translation[i] + s;
+                        volatile float back = x - translation[i];
+                        if (back == s && std::isfinite(x)) { scale = s; shifted = x; }
+                    }
+                }
+                if (scale == 0.0f) fail("the sensor translation has no exactly invertible offset");
+                Eigen::Vector3f probe(translation[0], translation[1], translation[2]);
+                if (i == 0) probe = Eigen::Vector3f(shifted, translation[1], translation[2]);
+                if (i == 1) probe = Eigen::Vector3f(translation[0], shifted, translation[2]);
+                if (i == 2) probe = Eigen::Vector3f(translation[0], translation[1], shifted);
+                device.originToSensor(probe);        // Rinv * (0, .., s, .., 0) = s * column i, exactly
+                Rinv[0 + i] = probe.x() / scale;
+                Rinv[3 + i] = probe.y() / scale;
+                Rinv[6 + i] = probe.z() / scale;
+            }
+            for (float r : Rinv)
+                if (!std::isfinite(r)) fail("the sensor rotation is not finite");
+        }
+
+        unsigned V = 0, H = 0, reference = 0;
+        std::vector<float> dx, dy, dz;
+        std::vector<std::vector<float>> thetaCandidates;
+        std::vector<float> sinTheta, cosTheta, elevationDeg, sinPhi, cosPhi;
+        float beginDeg = 0.0f, stepDeg = 0.0f;
+        float Rinv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, translation[3] = {0, 0, 0};
+    };
+
+private:
+
+    std::mutex _mutex;   // add/remove come from the GUI thread, update/commit/trace from the ROS spinner (mainwindow.cpp:153,320)
+    std::map<std::string, MeshState> _meshes;
+    MeshPolicy _policy_ = MeshPolicy::UploadAlways;
+    std::uint64_t _uploads = 0, _skipped = 0;
+    ls_tracer* _handle = nullptr;
+};
+
+}  // namespace lidarshooter

@@ -1,0 +1,12 @@
+// stub of std_msgs/Header.h
+#pragma once
+#include <cstdint>
+#include <string>
+#include "ros/time.h"
+namespace std_msgs {
+struct Header {
+    std::uint32_t seq = 0;
+    ros::Time stamp;
+    std::string frame_id;
+};
+}  // namespace std_msgs

@@ -18,12 +18,14 @@ LIB_PATH = os.environ.get("LS_LIB_PATH") or os.path.join(_HERE, "liblidarshooter
 INVALID = 0xFFFFFFFF
 
 LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPELINE = 1, 2, 3, 5, 6
+LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT = 7, 8, 9
+LS_INFO_CONCURRENT_STREAMS, LS_INFO_PIPELINE_MODE, LS_INFO_DEVICE_STATUS, LS_INFO_HOST_THREADS = 1, 2, 3, 4
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
 STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "trace_aux", "pack")
 
 # every symbol include/lidarshooter_hip.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = (
-    "ls_abi_version", "ls_tracer_create", "ls_tracer_destroy", "ls_add_geometry", "ls_remove_geometry",
+    "ls_abi_version", "ls_tracer_create", "ls_tracer_create_tables", "ls_tracer_destroy", "ls_parallel_copy", "ls_get_info", "ls_affine_from_components", "ls_add_geometry", "ls_remove_geometry",
     "ls_update_geometry", "ls_update_geometry_components", "ls_update_geometry_device",
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
@@ -37,6 +39,13 @@ SYMBOLS = (
 class SensorDesc(C.Structure):
     _fields_ = [("vertical_deg", C.POINTER(C.c_float)), ("n_vertical", C.c_uint32), ("h_begin", C.c_float),
                 ("h_end", C.c_float), ("h_count", C.c_uint32), ("Rinv", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+class SensorTables(C.Structure):
+    _fields_ = [("sin_theta", C.POINTER(C.c_float)), ("cos_theta", C.POINTER(C.c_float)),
+                ("elevation_deg", C.POINTER(C.c_float)), ("n_vertical", C.c_uint32),
+                ("sin_phi", C.POINTER(C.c_float)), ("cos_phi", C.POINTER(C.c_float)), ("h_count", C.c_uint32),
+                ("h_begin_deg", C.c_float), ("h_step_deg", C.c_float), ("Rinv", C.c_float * 9), ("t", C.c_float * 3)]
 
 
 class Frame(C.Structure):
@@ -81,6 +90,12 @@ def load() -> C.CDLL:
     vp, u32, i32, f32p, u32p = C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.ls_abi_version.restype = i32
     L.ls_tracer_create.argtypes = [C.POINTER(SensorDesc), i32, C.POINTER(vp)]
+    L.ls_tracer_create_tables.argtypes = [C.POINTER(SensorTables), i32, C.POINTER(vp)]
+    L.ls_affine_from_components.argtypes = [f32p, f32p, f32p]
+    L.ls_affine_from_components.restype = None
+    L.ls_parallel_copy.argtypes = [vp, vp, C.c_uint64]
+    L.ls_get_info.argtypes = [vp, i32]
+    L.ls_get_info.restype = C.c_long
     L.ls_tracer_destroy.argtypes = [vp]
     L.ls_tracer_destroy.restype = None
     L.ls_add_geometry.argtypes = [vp, C.c_char_p, i32, i32, i32]
@@ -230,7 +245,8 @@ class Tracer:
         n = int(fr.n_points)
         if n:
             pts = np.ctypeslib.as_array(fr.points32, shape=(n * 32,)).reshape(n, 32).copy()
-            hits = np.frombuffer(C.string_at(fr.hits, n * 16), dtype=HIT_DTYPE).copy()
+            hits = (np.frombuffer(C.string_at(fr.hits, n * 16), dtype=HIT_DTYPE).copy() if fr.hits
+                    else np.zeros(0, HIT_DTYPE))   # LS_OPT_READBACK_HITS = 0: the records stay on the device
         else:
             pts = np.zeros((0, 32), np.uint8)
             hits = np.zeros(0, HIT_DTYPE)
@@ -285,6 +301,9 @@ class Tracer:
         return self._check(self.L.ls_cloud_to_world(self.h, None if A is None else _f32p(A), _f32p(R), d_points_in, d_n_points,
                                                     d_points_out, d_out_base, d_out_total, out_capacity),
                            "ls_cloud_to_world")
+
+    def info(self, what: int) -> int:
+        return int(self._check(self.L.ls_get_info(self.h, what), "ls_get_info"))
 
     def flush(self):
         return self._check(self.L.ls_tracer_flush(self.h), "ls_tracer_flush")

@@ -153,7 +153,10 @@ struct FinishPackArgs {
     const uint32_t *big_count;      // its queue counter
     uint32_t *rearm_big_count;      // the counter of the frame after the next: set to 0
     unsigned long long *status;     // per workgroup (epoch << 32) | hits, for the chained prefix
-    uint32_t epoch;
+    uint32_t epoch;                 // tag this frame's workgroups wait for
+    uint32_t publish_epoch;         // tag they publish (== epoch; LS_OPT_DEBUG_FAULT publishes another one)
+    uint32_t spin_limit;            // polls before a waiting workgroup gives up and raises device_status
+    uint32_t *device_status;        // sticky status word in pinned host memory (bit 0: a chained prefix gave up)
     GeomTable gt;
     uint8_t *points32;
     void *hits;

@@ -602,7 +602,7 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     __syncthreads();
     const uint32_t mine = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)fa.epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)fa.publish_epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (block_idx == 0) *fa.rearm_big_count = 0u;   // the queue counter of the frame after the next: nobody reads it now
     }
     // hits of all workgroups before this one.  Waiting is rare (every workgroup publishes within a few
@@ -613,7 +613,7 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     for (uint32_t i = threadIdx.x; i < block_idx; i += kBlock) {
         unsigned long long st = __hip_atomic_load(&fa.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint32_t spin = 0; (uint32_t)(st >> 32) != fa.epoch; ++spin) {
-            if (spin > (1u << 18)) { stuck = true; break; }   // ~1 s; never seen; keeps a broken premise from hanging the GPU
+            if (spin > fa.spin_limit) { stuck = true; break; }   // ~1 s; never seen; keeps a broken premise from hanging the GPU
             if (spin == 0) __builtin_amdgcn_s_sleep(1);
             else if (spin == 1) __builtin_amdgcn_s_sleep(4);
             else if (spin == 2) __builtin_amdgcn_s_sleep(16);
@@ -631,7 +631,11 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     const bool bad = s_part[0] == 0xFFFFFFFFu || s_part[1] == 0xFFFFFFFFu || s_part[2] == 0xFFFFFFFFu || s_part[3] == 0xFFFFFFFFu;
     uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     if (block_idx == fa.n_blocks - 1u && threadIdx.x == 0) *fa.n_points = bad ? 0u : base + mine;
-    if (bad) return;
+    if (bad) {
+        // the frame is lost: tell the host (checked at its next wait: ls_trace_scene, ls_tracer_synchronize)
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(fa.device_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     for (uint32_t k = 0; k < w; ++k) base += s_cnt[k];
     if (!hit) return;
     const uint32_t dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));

@@ -8,7 +8,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -35,6 +39,10 @@ struct Geometry {
     const void *shared_raw = nullptr;       // ls_update_geometry_device_shared: caller-owned device buffers
     const uint32_t *shared_idx = nullptr;   // read in place by the kernels, never copied or freed
     bool has_verts = false, has_idx = false, idx_dirty = true;
+    // host uploads (ls_update_geometry): pinned staging, written by the copy pool, read by the DMA
+    void *h_stage_v = nullptr, *h_stage_i = nullptr;
+    size_t stage_v_cap = 0, stage_i_cap = 0;
+    hipEvent_t ev_stage_v = nullptr, ev_stage_i = nullptr;   // recorded behind the last DMA that reads the staging buffer
     const void *raw() const { return shared_raw ? shared_raw : d_raw; }
     const uint32_t *idx() const { return shared_idx ? shared_idx : d_idx; }
     float affine[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -46,6 +54,121 @@ struct DevBuf {
     size_t cap = 0;  // elements
 };
 
+// Worker threads for host-side copies (pageable caller memory <-> pinned staging).  One pool per process,
+// created on first use; LS_HOST_THREADS overrides its size (default: half the cores, at most 8).
+class HostPool {
+public:
+    static HostPool &get()
+    {
+        static HostPool pool;
+        return pool;
+    }
+    int threads() const { return (int)workers_.size() + 1; }
+    // run fn(0) .. fn(n-1); the calling thread works too.  `on_done(i)` (optional) is called on the CALLING thread,
+    // in index order, as soon as item i is complete -- the caller enqueues item i's DMA there while later items copy.
+    void run(size_t n, const std::function<void(size_t)> &fn, const std::function<void(size_t)> *on_done = nullptr)
+    {
+        if (!n) return;
+        if (workers_.empty() || n == 1) {
+            for (size_t i = 0; i < n; ++i) { fn(i); if (on_done) (*on_done)(i); }
+            return;
+        }
+        std::unique_lock<std::mutex> run_lock(run_mu_);   // one job at a time
+        std::vector<std::atomic<uint8_t>> done(n);
+        for (auto &d : done) d.store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            done_ = done.data();
+            n_ = n;
+            next_.store(0);
+            active_ = workers_.size();
+            ++generation_;
+        }
+        cv_.notify_all();
+        size_t reported = 0;
+        auto report = [&]() {
+            while (on_done && reported < n && done[reported].load(std::memory_order_acquire)) (*on_done)(reported++);
+        };
+        if (!on_done) {
+            for (size_t i; (i = next_.fetch_add(1)) < n;) { fn(i); done[i].store(1, std::memory_order_release); }
+        } else {
+            // the caller only copies when nothing is waiting to be reported (its DMA calls are what the device waits for)
+            while (reported < n) {
+                report();
+                if (reported == n) break;
+                if (!done[reported].load(std::memory_order_acquire)) {
+                    const size_t i = next_.fetch_add(1);
+                    if (i < n) { fn(i); done[i].store(1, std::memory_order_release); }
+                    else std::this_thread::yield();
+                }
+            }
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        idle_cv_.wait(lk, [&] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    HostPool()
+    {
+        int n = 0;
+        if (const char *e = getenv("LS_HOST_THREADS")) n = atoi(e);
+        if (n <= 0) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            n = (int)std::min(8u, std::max(1u, hw / 2u));
+        }
+        for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            const std::function<void(size_t)> *fn = fn_;
+            std::atomic<uint8_t> *done = done_;
+            const size_t n = n_;
+            lk.unlock();
+            for (size_t i; (i = next_.fetch_add(1)) < n;) { (*fn)(i); done[i].store(1, std::memory_order_release); }
+            lk.lock();
+            if (--active_ == 0) idle_cv_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, idle_cv_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    std::atomic<uint8_t> *done_ = nullptr;
+    size_t n_ = 0, active_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
+constexpr size_t kCopyChunk = 512u << 10;   // host copy / DMA granularity of an upload
+
+void parallel_copy(void *dst, const void *src, size_t bytes)
+{
+    if (bytes <= kCopyChunk) { std::memcpy(dst, src, bytes); return; }
+    const size_t n = (bytes + kCopyChunk - 1) / kCopyChunk;
+    HostPool::get().run(n, [&](size_t i) {
+        const size_t off = i * kCopyChunk;
+        std::memcpy(static_cast<uint8_t *>(dst) + off, static_cast<const uint8_t *>(src) + off, std::min(kCopyChunk, bytes - off));
+    });
+}
+
 }  // namespace
 
 struct ls_tracer {
@@ -56,7 +179,8 @@ struct ls_tracer {
 
     // sensor (LidarDevice state needed by the path)
     std::vector<float> vertical;
-    float h_begin = 0, h_end = 0;
+    float h_begin = 0, h_end = 0, h_step = 0;
+    std::vector<float> given_tables;   // ls_tracer_create_tables: sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H] as handed over
     uint32_t V = 0, H = 0;
     float rinv[9], t[3];
     float *d_tables = nullptr;  // sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H]
@@ -110,7 +234,9 @@ struct ls_tracer {
     hipStream_t slot_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_main = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
     bool slot_pending[3] = {false, false, false};   // frames issued on slot_stream[s] since the last flush
-    bool main_dirty = false;                        // the library enqueued mesh copies on the handle's stream since the last frame
+    // the library enqueues mesh copies on the handle's stream; a slot stream whose epoch is behind orders itself
+    // after that stream before its next frame (every slot, not only the first frame after the copy)
+    uint64_t main_epoch = 0, slot_epoch[3] = {0, 0, 0};
     uint32_t ms_seq = 0;
     DevBuf<unsigned long long> best_keys_c;
     DevBuf<uint8_t> big_queue_c, points_c, hits_c;
@@ -139,6 +265,11 @@ struct ls_tracer {
     size_t h_cap = 0;  // records
     uint32_t *h_n_points = nullptr;
     bool traced = false;
+    int opt_host_output = 1;     // LS_OPT_HOST_OUTPUT: the pack kernel writes the pinned host buffers itself
+    int opt_readback_hits = 1;   // LS_OPT_READBACK_HITS
+    int opt_debug_fault = 0;     // LS_OPT_DEBUG_FAULT (one frame)
+    uint32_t *h_status = nullptr;   // sticky device status word in pinned host memory (bit 0: chained prefix gave up)
+    int concurrent_streams = 0;     // LS_OPT_PIPELINE = 2 calibration result (0 = not run yet)
 
     // options / measurement
     int opt_timing = 0;  // 0 off, 1 every stage, 2 only the trace kernel
@@ -222,7 +353,7 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     pp.chan_perm = reinterpret_cast<const uint32_t *>(pp.chan_tan_dn + tr->V);
     pp.chan_rank = reinterpret_cast<const uint32_t *>(tr->d_tables + 5 * (size_t)tr->V + 4 * (size_t)tr->H);
     pp.begin_deg = tr->h_begin;
-    pp.step_deg = (tr->h_end - tr->h_begin) / static_cast<float>(tr->H - 1u);  // LidarDevice.cpp:611
+    pp.step_deg = tr->h_step;  // LidarDevice.cpp:611
     pp.inv_step_deg = pp.step_deg != 0.0f ? 1.0f / pp.step_deg : 0.0f;
     pp.inv_period = std::fabs(pp.step_deg) / 360.0f;
     pp.margin_deg = kProjectMarginDeg;
@@ -257,22 +388,33 @@ uint32_t shard_rays(const ls_tracer *tr) { return tr->V * tr->naz; }
 // process), and two streams on one queue serialise: 24 us per frame instead of 16.  So: candidates are created
 // and tried pairwise with an idle 200 us wave each -- two on one queue take twice as long as two on two --
 // until three mutually concurrent ones are found; the rest is destroyed.  A few milliseconds, once per handle.
+// The number found is kept (LS_INFO_CONCURRENT_STREAMS); with fewer than three the handle runs mode 1 instead.
 int pick_slot_streams(ls_tracer *tr)
 {
     constexpr int kCandidates = 8;
     constexpr unsigned long long kTicks = 20000;   // 200 us
-    LS_HIP(hipDeviceSynchronize());                // nothing else may be running while pairs are timed
     hipStream_t cand[kCandidates] = {};
     for (auto &c : cand) LS_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    LS_HIP(hipEventCreate(&e0));
+    LS_HIP(hipEventCreate(&ea));
+    LS_HIP(hipEventCreate(&eb));
+    // device-side timing: both waves are launched behind e0; on one hardware queue the second one ends ~400 us
+    // after e0, on two queues ~200 us -- host scheduling noise does not enter
     auto pair_us = [&](hipStream_t a, hipStream_t b, double &us) -> int {
         LS_HIP(hipStreamSynchronize(a));
         LS_HIP(hipStreamSynchronize(b));
-        const auto t0 = std::chrono::steady_clock::now();
+        LS_HIP(hipEventRecord(e0, a));
         ls::launch_spin(a, kTicks);
         ls::launch_spin(b, kTicks);
+        LS_HIP(hipEventRecord(ea, a));
+        LS_HIP(hipEventRecord(eb, b));
         LS_HIP(hipStreamSynchronize(a));
         LS_HIP(hipStreamSynchronize(b));
-        us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        float ma = 0.f, mb = 0.f;
+        LS_HIP(hipEventElapsedTime(&ma, e0, ea));
+        LS_HIP(hipEventElapsedTime(&mb, e0, eb));
+        us = 1e3 * (double)std::max(ma, mb);
         return LS_OK;
     };
     int rc;
@@ -288,13 +430,53 @@ int pick_slot_streams(ls_tracer *tr)
         }
         if (ok) chosen[n++] = c;
     }
+    tr->concurrent_streams = n;
     for (int i = 0; i < 3; ++i) tr->slot_stream[i] = cand[chosen[i] >= 0 ? chosen[i] : chosen[0]];
     for (int c = 0; c < kCandidates; ++c) {
         bool used = false;
         for (int i = 0; i < 3; ++i) used = used || tr->slot_stream[i] == cand[c];
         if (!used) (void)hipStreamDestroy(cand[c]);
     }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
     return LS_OK;
+}
+
+int ensure_slot_streams(ls_tracer *tr)
+{
+    if (tr->slot_stream[0]) return LS_OK;
+    int rc;
+    LS_HIP(hipEventCreateWithFlags(&tr->ev_main, hipEventDisableTiming | hipEventDisableSystemFence));
+    if ((rc = pick_slot_streams(tr))) return rc;
+    for (int i = 0; i < 3; ++i)
+        LS_HIP(hipEventCreateWithFlags(&tr->ev_done[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    return LS_OK;
+}
+
+// pinned host buffers of the synchronous ls_trace_scene (written by the pack kernel itself or by D2H copies)
+int ensure_host_buffers(ls_tracer *tr, size_t records)
+{
+    if (records <= tr->h_cap) return LS_OK;
+    if (tr->h_points) LS_HIP(hipHostFree(tr->h_points));
+    if (tr->h_hits) LS_HIP(hipHostFree(tr->h_hits));
+    tr->h_points = nullptr;
+    tr->h_hits = nullptr;
+    tr->h_cap = 0;
+    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_points), records * 32));
+    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_hits), records * 16));
+    tr->h_cap = records;
+    return LS_OK;
+}
+
+// the sticky device status word, read after a host wait: a frame whose chained prefix gave up is lost
+int check_device_status(ls_tracer *tr)
+{
+    const uint32_t st = __atomic_exchange_n(tr->h_status, 0u, __ATOMIC_ACQ_REL);
+    if (!st) return LS_OK;
+    tr->err = "device status " + std::to_string(st) + ": the chained prefix of a pipelined finish + pack pass gave up waiting; "
+              "that frame's cloud is incomplete";
+    return LS_ERR_HIP;
 }
 
 int ensure_outputs(ls_tracer *tr)
@@ -333,12 +515,7 @@ int ensure_outputs(ls_tracer *tr)
             if ((rc = ensure(tr, tr->hits_c, nr * 16))) return rc;
         }
         if (!tr->d_n_points_c) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_n_points_c), 4));
-        if (!tr->slot_stream[0]) {
-            LS_HIP(hipEventCreateWithFlags(&tr->ev_main, hipEventDisableTiming | hipEventDisableSystemFence));
-            if ((rc = pick_slot_streams(tr))) return rc;
-            for (int i = 0; i < 3; ++i)
-                LS_HIP(hipEventCreateWithFlags(&tr->ev_done[i], hipEventDisableTiming | hipEventDisableSystemFence));
-        }
+        if ((rc = ensure_slot_streams(tr))) return rc;
     }
     if ((tr->opt_pipeline || tr->pipe_seq) && use_projection(tr)) {   // twins: needed as long as the rotation may stand on parity 1
         const size_t cap0 = tr->best_keys_b.cap;
@@ -419,18 +596,23 @@ void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
 {
     const uint32_t V = tr->V, H = tr->H;
     tab.resize(2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V + 2 * (size_t)H + (size_t)V);
-    const float step = (tr->h_end - tr->h_begin) / static_cast<float>(H - 1u);  // LidarDevice.cpp:611
-    for (uint32_t v = 0; v < V; ++v) {
-        const float preChi = tr->vertical[v];
-        const float theta = static_cast<float>((90.0 - static_cast<double>(preChi)) * M_PI / 180.0);
-        tab[v] = std::sin(theta);
-        tab[V + v] = std::cos(theta);
-    }
-    for (uint32_t h = 0; h < H; ++h) {
-        const float prePhi = tr->h_begin + step * static_cast<float>(h);
-        const float phi = static_cast<float>(static_cast<double>(prePhi) * M_PI / 180.0);
-        tab[2 * (size_t)V + h] = std::sin(phi);
-        tab[2 * (size_t)V + H + h] = std::cos(phi);
+    const float step = tr->h_step;  // LidarDevice.cpp:611
+    if (!tr->given_tables.empty()) {
+        // ls_tracer_create_tables: the caller's factor tables, bit for bit
+        std::memcpy(tab.data(), tr->given_tables.data(), (2 * (size_t)V + 2 * (size_t)H) * sizeof(float));
+    } else {
+        for (uint32_t v = 0; v < V; ++v) {
+            const float preChi = tr->vertical[v];
+            const float theta = static_cast<float>((90.0 - static_cast<double>(preChi)) * M_PI / 180.0);
+            tab[v] = std::sin(theta);
+            tab[V + v] = std::cos(theta);
+        }
+        for (uint32_t h = 0; h < H; ++h) {
+            const float prePhi = tr->h_begin + step * static_cast<float>(h);
+            const float phi = static_cast<float>(static_cast<double>(prePhi) * M_PI / 180.0);
+            tab[2 * (size_t)V + h] = std::sin(phi);
+            tab[2 * (size_t)V + H + h] = std::cos(phi);
+        }
     }
     // projection engine: channels by ascending elevation; tan(elevation +- margin), nudged outwards
     std::vector<uint32_t> perm(V);
@@ -500,6 +682,49 @@ void affine_from_components(const float *lin, const float *ang, float *A)
     }
 }
 
+// Host memory -> device, without waiting for the device: the copy pool moves the caller's (pageable) bytes into
+// a pinned staging buffer chunk by chunk, and the calling thread enqueues each chunk's DMA on the handle's
+// stream as soon as the chunk is staged, so copying and DMA overlap.  When the call returns the caller's
+// memory is free again (MeshProjector.cpp:448-461 reuses it); the staging buffer is protected by `ev`.
+int stage_upload(ls_tracer *tr, void *&stage, size_t &stage_cap, hipEvent_t &ev, void *d_dst, const void *src, size_t bytes)
+{
+    if (!bytes) return LS_OK;
+    if (bytes > stage_cap) {
+        if (stage) { LS_HIP(hipStreamSynchronize(tr->stream)); LS_HIP(hipHostFree(stage)); }
+        stage = nullptr;
+        stage_cap = 0;
+        LS_HIP(hipHostMalloc(&stage, bytes, hipHostMallocDefault));
+        stage_cap = bytes;
+    }
+    if (!ev) LS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else LS_HIP(hipEventSynchronize(ev));   // a DMA of the previous upload may still read the buffer (asynchronous callers)
+    const size_t n = (bytes + kCopyChunk - 1) / kCopyChunk;
+    hipError_t err = hipSuccess;
+    const std::function<void(size_t)> copy = [&](size_t i) {
+        const size_t off = i * kCopyChunk;
+        std::memcpy(static_cast<uint8_t *>(stage) + off, static_cast<const uint8_t *>(src) + off, std::min(kCopyChunk, bytes - off));
+    };
+    // DMAs are enqueued in runs of up to four staged chunks (2 MB): fewer API calls, still a fine-grained pipeline
+    size_t run_first = 0, run_len = 0;
+    auto flush_run = [&]() {
+        if (!run_len) return;
+        const size_t off = run_first * kCopyChunk, len = std::min(run_len * kCopyChunk, bytes - off);
+        const hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + off, static_cast<uint8_t *>(stage) + off, len,
+                                            hipMemcpyHostToDevice, tr->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        run_len = 0;
+    };
+    const std::function<void(size_t)> dma = [&](size_t i) {
+        if (!run_len) run_first = i;
+        if (++run_len == 4 || i + 1 == n) flush_run();
+    };
+    HostPool::get().run(n, copy, &dma);
+    flush_run();
+    if (err != hipSuccess) { tr->err = std::string("hipMemcpyAsync (upload): ") + hipGetErrorString(err); return LS_ERR_HIP; }
+    LS_HIP(hipEventRecord(ev, tr->stream));
+    return LS_OK;
+}
+
 int update_common(ls_tracer *tr, const char *name, const float *affine, const void *verts, uint32_t stride,
                   const uint32_t *idx, hipMemcpyKind kind, bool shared = false)
 {
@@ -517,11 +742,13 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; }
         return LS_OK;
     }
+    if (!verts && !idx) return LS_OK;   // transform only: nothing is copied, nothing to order
     {   // three-stream mode: frames in flight may still read the mesh buffers this call overwrites
         const int rc = order_after_projects(tr);
         if (rc) return rc;
-        tr->main_dirty = true;
+        ++tr->main_epoch;   // every slot stream must see the copies below before its next frame
     }
+    const bool from_host = kind == hipMemcpyHostToDevice;
     if (verts) {
         g.shared_raw = nullptr;
         if (stride < 12 || (stride & 3u)) return fail(tr, LS_ERR_INVALID_ARGUMENT, "vertex stride must be >= 12 and a multiple of 4");
@@ -533,7 +760,14 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
             LS_HIP(hipMalloc(&g.d_raw, bytes ? bytes : 4));
             g.raw_cap = bytes;
         }
-        if (bytes) LS_HIP(hipMemcpyAsync(g.d_raw, verts, bytes, kind, tr->stream));
+        if (bytes) {
+            if (from_host) {
+                const int rc = stage_upload(tr, g.h_stage_v, g.stage_v_cap, g.ev_stage_v, g.d_raw, verts, bytes);
+                if (rc) return rc;
+            } else {
+                LS_HIP(hipMemcpyAsync(g.d_raw, verts, bytes, kind, tr->stream));
+            }
+        }
         g.stride = stride;
         if (!g.has_verts) tr->layout_dirty = true;
         g.has_verts = true;
@@ -542,13 +776,18 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         g.shared_idx = nullptr;
         const size_t bytes = (size_t)g.n_tris * 12;
         if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), bytes ? bytes : 4));
-        if (bytes) LS_HIP(hipMemcpyAsync(g.d_idx, idx, bytes, kind, tr->stream));
+        if (bytes) {
+            if (from_host) {
+                const int rc = stage_upload(tr, g.h_stage_i, g.stage_i_cap, g.ev_stage_i, g.d_idx, idx, bytes);
+                if (rc) return rc;
+            } else {
+                LS_HIP(hipMemcpyAsync(g.d_idx, idx, bytes, kind, tr->stream));
+            }
+        }
         if (!g.has_idx) tr->layout_dirty = true;
         g.has_idx = true;
         g.idx_dirty = true;
     }
-    // host memory may be reused by the caller as soon as we return (MeshProjector.cpp:448-461)
-    if (kind == hipMemcpyHostToDevice && (verts || idx)) LS_HIP(hipStreamSynchronize(tr->stream));
     return LS_OK;
 }
 
@@ -556,8 +795,15 @@ void free_geometry(Geometry &g)
 {
     if (g.d_raw) (void)hipFree(g.d_raw);
     if (g.d_idx) (void)hipFree(g.d_idx);
+    if (g.h_stage_v) (void)hipHostFree(g.h_stage_v);
+    if (g.h_stage_i) (void)hipHostFree(g.h_stage_i);
+    if (g.ev_stage_v) (void)hipEventDestroy(g.ev_stage_v);
+    if (g.ev_stage_i) (void)hipEventDestroy(g.ev_stage_i);
     g.d_raw = nullptr;
     g.d_idx = nullptr;
+    g.h_stage_v = g.h_stage_i = nullptr;
+    g.stage_v_cap = g.stage_i_cap = 0;
+    g.ev_stage_v = g.ev_stage_i = nullptr;
 }
 
 // (re)build the committed scene arrays (transformed vertices, rebased indices) on the device
@@ -708,6 +954,16 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     uint8_t *d_points = tr->ext_points ? static_cast<uint8_t *>(tr->ext_points) : tr->points.p;
     void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
     uint32_t *d_n = tr->ext_points ? tr->ext_n_points : tr->d_n_points;
+    // synchronous call with the library's own outputs: the pack kernel writes the pinned host buffers itself
+    const bool hv = readback && tr->opt_host_output && !tr->ext_points;
+    if (hv && (rc = ensure_host_buffers(tr, shard_rays(tr)))) return rc;
+    auto host_targets = [&]() {
+        if (!hv) return;
+        d_points = tr->h_points;
+        if (tr->opt_readback_hits) d_hits = tr->h_hits;
+        d_n = tr->h_n_points;
+    };
+    host_targets();
     if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 32, s));
     if (use_projection(tr)) {
         // sensor-space projection engine: stream the triangles once, test only the covered rays
@@ -731,6 +987,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             d_hits = slot == 1 ? tr->hits_b.p : tr->hits_c.p;
             d_n = slot == 1 ? tr->d_n_points_b : tr->d_n_points_c;
         }
+        host_targets();
         if (!tr->keys_armed) {
             // first frame (or a new shard / raster): key set 0, all queue counters, the block counts.  In three-
             // stream mode the other streams' frames use those counters too: the initialisation completes first
@@ -742,11 +999,11 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         if (multi) {
             // the frame's stream first sees what is enqueued on the handle's stream: the library's own mesh copies,
             // or anything at all when the stream is the caller's (host API calls are not cheap: only when needed)
-            const bool dep = tr->main_dirty || tr->stream != tr->own_stream;
+            const bool dep = tr->slot_epoch[slot] != tr->main_epoch || tr->stream != tr->own_stream;
             if (dep) LS_HIP(hipEventRecord(tr->ev_main, s));
             s = tr->slot_stream[slot];
             if (dep) LS_HIP(hipStreamWaitEvent(s, tr->ev_main, 0));
-            tr->main_dirty = false;
+            tr->slot_epoch[slot] = tr->main_epoch;
         }
         if (slot == 1 && !tr->keys_b_armed) {
             LS_HIP(hipMemsetAsync(tr->best_keys_b.p, 0xFF, (size_t)shard_rays(tr) * 8, s));
@@ -798,6 +1055,14 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             fa.rearm_big_count = tr->d_big_count + 4u * ((tr->pipe_seq + 2u) % 3u);
             fa.status = tr->pack_status.p;
             fa.epoch = tr->pack_epoch;
+            fa.publish_epoch = tr->pack_epoch;
+            fa.spin_limit = 1u << 18;   // ~1 s of backed-off polls
+            fa.device_status = tr->h_status;
+            if (tr->opt_debug_fault) {   // LS_OPT_DEBUG_FAULT: this frame publishes a tag nobody waits for
+                fa.publish_epoch = tr->pack_epoch ^ 0x40000000u;
+                fa.spin_limit = 1u << 6;
+                tr->opt_debug_fault = 0;
+            }
             fa.gt = gt;
             fa.points32 = d_points;
             fa.hits = d_hits;
@@ -857,28 +1122,27 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     out->d_n_points = d_n;
     if (!readback) return LS_OK;
 
+    if (hv) {
+        LS_HIP(hipStreamSynchronize(s));   // the only host wait of the frame
+        if ((rc = check_device_status(tr))) return rc;
+        out->n_points = *tr->h_n_points;
+        out->points32 = tr->h_points;
+        out->hits = tr->opt_readback_hits ? tr->h_hits : nullptr;
+        return LS_OK;
+    }
     LS_HIP(hipMemcpyAsync(tr->h_n_points, d_n, 4, hipMemcpyDeviceToHost, s));
     LS_HIP(hipStreamSynchronize(s));
+    if ((rc = check_device_status(tr))) return rc;
     const uint32_t n = *tr->h_n_points;
-    if (n > tr->h_cap) {
-        if (tr->h_points) LS_HIP(hipHostFree(tr->h_points));
-        if (tr->h_hits) LS_HIP(hipHostFree(tr->h_hits));
-        tr->h_points = nullptr;
-        tr->h_hits = nullptr;
-        tr->h_cap = 0;
-        const size_t cap = std::max<size_t>(shard_rays(tr), n);
-        LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_points), cap * 32));
-        LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_hits), cap * 16));
-        tr->h_cap = cap;
-    }
+    if ((rc = ensure_host_buffers(tr, std::max<size_t>(shard_rays(tr), n)))) return rc;
     if (n) {
         LS_HIP(hipMemcpyAsync(tr->h_points, d_points, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-        LS_HIP(hipMemcpyAsync(tr->h_hits, d_hits, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+        if (tr->opt_readback_hits) LS_HIP(hipMemcpyAsync(tr->h_hits, d_hits, (size_t)n * 16, hipMemcpyDeviceToHost, s));
         LS_HIP(hipStreamSynchronize(s));
     }
     out->n_points = n;
     out->points32 = tr->h_points;
-    out->hits = tr->h_hits;
+    out->hits = tr->opt_readback_hits ? tr->h_hits : nullptr;
     return LS_OK;
 }
 
@@ -889,25 +1153,20 @@ extern "C" {
 
 int ls_abi_version(void) { return LS_ABI_VERSION; }
 
-int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
+// shared tail of the two create calls: `tr` holds the sensor (V, H, vertical, h_begin / h_step, pose and, for
+// ls_tracer_create_tables, the given factor tables)
+static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
 {
-    if (!out) return LS_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return LS_ERR_INVALID_ARGUMENT;
-    if ((unsigned long long)sd->n_vertical * sd->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;  // ray indices are 32-bit
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev) {
+        delete tr;
         return LS_ERR_NO_DEVICE;
-    if (hipSetDevice(hip_device) != hipSuccess) return LS_ERR_NO_DEVICE;
-    ls_tracer *tr = new ls_tracer();
+    }
+    if (hipSetDevice(hip_device) != hipSuccess) {
+        delete tr;
+        return LS_ERR_NO_DEVICE;
+    }
     tr->device = hip_device;
-    tr->V = sd->n_vertical;
-    tr->H = sd->h_count;
-    tr->vertical.assign(sd->vertical_deg, sd->vertical_deg + sd->n_vertical);
-    tr->h_begin = sd->h_begin;
-    tr->h_end = sd->h_end;
-    std::memcpy(tr->rinv, sd->Rinv, sizeof(tr->rinv));
-    std::memcpy(tr->t, sd->t, sizeof(tr->t));
     tr->az0 = 0;
     tr->naz = tr->H;
     auto bail = [&](int code) {
@@ -942,9 +1201,53 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
         if (const char *e = getenv("LS_TRACE_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) tr->refill_min = (uint32_t)v; }
     }
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_status), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    *tr->h_status = 0u;
     tr->slot_tri_first.assign(1, 0u);
     *out = tr;
     return LS_OK;
+}
+
+int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
+{
+    if (!out) return LS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return LS_ERR_INVALID_ARGUMENT;
+    if ((unsigned long long)sd->n_vertical * sd->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;  // ray indices are 32-bit
+    ls_tracer *tr = new ls_tracer();
+    tr->V = sd->n_vertical;
+    tr->H = sd->h_count;
+    tr->vertical.assign(sd->vertical_deg, sd->vertical_deg + sd->n_vertical);
+    tr->h_begin = sd->h_begin;
+    tr->h_end = sd->h_end;
+    tr->h_step = (sd->h_end - sd->h_begin) / static_cast<float>(sd->h_count - 1u);  // LidarDevice.cpp:611
+    std::memcpy(tr->rinv, sd->Rinv, sizeof(tr->rinv));
+    std::memcpy(tr->t, sd->t, sizeof(tr->t));
+    return create_device_state(tr, hip_device, out);
+}
+
+int ls_tracer_create_tables(const ls_sensor_tables *st, int hip_device, ls_tracer **out)
+{
+    if (!out) return LS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!st || !st->sin_theta || !st->cos_theta || !st->elevation_deg || !st->sin_phi || !st->cos_phi || st->n_vertical == 0 ||
+        st->h_count < 2)
+        return LS_ERR_INVALID_ARGUMENT;
+    if ((unsigned long long)st->n_vertical * st->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;
+    ls_tracer *tr = new ls_tracer();
+    const uint32_t V = tr->V = st->n_vertical, H = tr->H = st->h_count;
+    tr->vertical.assign(st->elevation_deg, st->elevation_deg + V);
+    tr->h_begin = st->h_begin_deg;
+    tr->h_step = st->h_step_deg;
+    tr->h_end = st->h_begin_deg + st->h_step_deg * static_cast<float>(H - 1u);
+    tr->given_tables.resize(2 * (size_t)V + 2 * (size_t)H);
+    std::memcpy(tr->given_tables.data(), st->sin_theta, V * sizeof(float));
+    std::memcpy(tr->given_tables.data() + V, st->cos_theta, V * sizeof(float));
+    std::memcpy(tr->given_tables.data() + 2 * (size_t)V, st->sin_phi, H * sizeof(float));
+    std::memcpy(tr->given_tables.data() + 2 * (size_t)V + H, st->cos_phi, H * sizeof(float));
+    std::memcpy(tr->rinv, st->Rinv, sizeof(tr->rinv));
+    std::memcpy(tr->t, st->t, sizeof(tr->t));
+    return create_device_state(tr, hip_device, out);
 }
 
 void ls_tracer_destroy(ls_tracer *tr)
@@ -982,6 +1285,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->h_points) (void)hipHostFree(tr->h_points);
     if (tr->h_hits) (void)hipHostFree(tr->h_hits);
     if (tr->h_n_points) (void)hipHostFree(tr->h_n_points);
+    if (tr->h_status) (void)hipHostFree(tr->h_status);
     for (auto &r : tr->trec)
         for (auto &e : r.ev)
             if (e) (void)hipEventDestroy(e);
@@ -1027,15 +1331,18 @@ int ls_remove_geometry(ls_tracer *tr, const char *name)
     auto it = tr->geoms.find(name);
     if (it == tr->geoms.end()) return -1;  // EmbreeTracer.cpp:224-225
     const int id = it->second.id;
-    (void)hipStreamSynchronize(tr->stream);
+    // frames in flight (on any of the handle's streams) may still read the mesh: order the handle's stream after
+    // them, then wait, before the buffers go
+    if (flush_pipeline(tr) != LS_OK) return LS_ERR_HIP;
+    LS_HIP(hipStreamSynchronize(tr->stream));
     free_geometry(it->second);
     tr->geoms.erase(it);
     tr->geometry_count -= 1;
     tr->layout_dirty = true;
-    // EmbreeTracer.cpp:252 commits here; the BVH still references the removed triangles, so the
-    // scene is simply marked uncommitted until the caller's next commitScene (every caller does,
-    // MeshProjector.cpp:458).
-    tr->committed = false;
+    // EmbreeTracer.cpp:252 commits here: a traceScene that follows traces the remaining geometry (-1 from
+    // the commit of a now empty scene is not an error of the removal)
+    const int rc = commit_locked(tr);
+    if (rc < -1) return rc;
     return id;
 }
 
@@ -1055,6 +1362,11 @@ int ls_update_geometry_components(ls_tracer *tr, const char *name, const float l
     float A[12];
     affine_from_components(lin, ang, A);
     return update_common(tr, name, A, verts, vert_stride, tri_idx, hipMemcpyHostToDevice);
+}
+
+void ls_affine_from_components(const float lin[3], const float ang[3], float affine3x4[12])
+{
+    if (lin && ang && affine3x4) affine_from_components(lin, ang, affine3x4);
 }
 
 int ls_update_geometry_device(ls_tracer *tr, const char *name, const float affine3x4[12], const void *d_verts,
@@ -1186,7 +1498,31 @@ int ls_tracer_synchronize(ls_tracer *tr)
     const int rc = flush_pipeline(tr);
     if (rc) return rc;
     LS_HIP(hipStreamSynchronize(tr->stream));
+    return check_device_status(tr);
+}
+
+int ls_parallel_copy(void *dst, const void *src, uint64_t bytes)
+{
+    if ((!dst || !src) && bytes) return LS_ERR_INVALID_ARGUMENT;
+    parallel_copy(dst, src, (size_t)bytes);
     return LS_OK;
+}
+
+long ls_get_info(ls_tracer *tr, int what)
+{
+    LS_ENTER(tr);
+    switch (what) {
+    case LS_INFO_CONCURRENT_STREAMS: return tr->concurrent_streams;
+    case LS_INFO_PIPELINE_MODE: return tr->opt_pipeline;
+    case LS_INFO_DEVICE_STATUS: {
+        const int rc = flush_pipeline(tr);
+        if (rc) return rc;
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        return (long)__atomic_exchange_n(tr->h_status, 0u, __ATOMIC_ACQ_REL);
+    }
+    case LS_INFO_HOST_THREADS: return HostPool::get().threads();
+    default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
+    }
 }
 
 int ls_tracer_flush(ls_tracer *tr)
@@ -1226,8 +1562,30 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         tr->trec_open = false;
         return LS_OK;
     case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
+    case LS_OPT_HOST_OUTPUT:
+        if (value < 0 || value > 1) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_HOST_OUTPUT: 0 or 1");
+        tr->opt_host_output = value;
+        return LS_OK;
+    case LS_OPT_READBACK_HITS:
+        if (value < 0 || value > 1) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_READBACK_HITS: 0 or 1");
+        tr->opt_readback_hits = value;
+        return LS_OK;
+    case LS_OPT_DEBUG_FAULT: tr->opt_debug_fault = value != 0; return LS_OK;
     case LS_OPT_PIPELINE: {
         if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_PIPELINE: 0 off, 1 two frames on one stream, 2 three streams");
+        if (value == 2) {
+            // three-stream mode needs three streams whose kernels really overlap; with fewer the frames would
+            // serialise silently, so the handle takes mode 1 (two frames on one stream) and says so
+            int rc = flush_pipeline(tr);
+            if (rc) return rc;
+            LS_HIP(hipStreamSynchronize(tr->stream));
+            if ((rc = ensure_slot_streams(tr))) return rc;
+            if (tr->concurrent_streams < 3) {
+                tr->err = "LS_OPT_PIPELINE = 2: only " + std::to_string(tr->concurrent_streams) +
+                          " mutually concurrent streams found on this device; using mode 1 (two frames in flight on one stream)";
+                value = 1;
+            }
+        }
         if (value == tr->opt_pipeline) return LS_OK;
         const int rc = flush_pipeline(tr);
         if (rc) return rc;

@@ -63,6 +63,22 @@ void lsh_device_init_message(lsh_device* d, int frame, unsigned* out6, unsigned*
     }
 }
 
+// field i of the message header initMessage builds (name copied into `name`, at most name_cap - 1 characters)
+int lsh_device_message_field(lsh_device* d, unsigned i, char* name, unsigned name_cap, unsigned* offset, unsigned* datatype, unsigned* count)
+{
+    PointCloud2 m;
+    d->p->initMessage(m, 0);
+    if (i >= m.fields.size()) return -1;
+    if (name && name_cap) {
+        std::strncpy(name, m.fields[i].name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    *offset = m.fields[i].offset;
+    *datatype = m.fields[i].datatype;
+    *count = m.fields[i].count;
+    return 0;
+}
+
 lsh_mesh* lsh_mesh_load_stl(const char* path)
 {
     auto* m = new lsh_mesh();

@@ -47,3 +47,21 @@ def shard_columns(H: int, world: int, rank: int):
     """Contiguous azimuth sector of `rank` out of `world`: -> (first_az, n_az)."""
     from .shards import shard_columns as _sc
     return _sc(H, world, rank)
+
+
+def write_sensor_json(template_path: str, out_path: str, vertical, h_begin: float, h_end: float, h_count: int) -> str:
+    """A sensor config like `template_path` (a shipped XT-32 JSON) with other channel tables: only the
+    `channels` block is rewritten, textually, so pose, message fields and comments stay as shipped."""
+    import re
+    txt = open(template_path).read()
+    vert = ", ".join(repr(float(np.float32(x))) for x in np.asarray(vertical, np.float32))   # float32 -> shortest double repr: round-trips
+    txt, n1 = re.subn(r'("vertical"\s*:\s*\[)[^\]]*(\])', lambda m: m.group(1) + vert + m.group(2), txt, count=1)
+    txt, n2 = re.subn(r'("begin"\s*:\s*)[-0-9.eE+]+', lambda m: m.group(1) + repr(float(np.float32(h_begin))), txt, count=1)
+    txt, n3 = re.subn(r'("end"\s*:\s*)[-0-9.eE+]+', lambda m: m.group(1) + repr(float(np.float32(h_end))), txt, count=1)
+    at = txt.index('"horizontal"', txt.index('"channels"'))   # "count" also names a field of every message pointField
+    tail, n4 = re.subn(r'("count"\s*:\s*)[0-9]+', lambda m: m.group(1) + str(int(h_count)), txt[at:], count=1)
+    txt = txt[:at] + tail
+    assert (n1, n2, n3, n4) == (1, 1, 1, 1), "template does not look like a lidarshooter sensor config"
+    with open(out_path, "w") as f:
+        f.write(txt)
+    return out_path

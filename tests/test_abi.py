@@ -23,7 +23,7 @@ def test_header_symbols_are_exported(capi):
 
 
 def test_abi_version(capi):
-    assert capi.load().ls_abi_version() == 1
+    assert capi.load().ls_abi_version() == 2
 
 
 def test_struct_sizes(capi):

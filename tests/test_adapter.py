@@ -1,0 +1,224 @@
+"""The ROS-typed adapter integration/HipTracer.hpp (lidarshooter::HipTracer : public ITracer), compiled against
+integration/stubs and driven the way MeshProjector drives a tracer (MeshProjector.cpp:322-340, :446-464).
+
+CPU part: the adapter compiles against the stand-in headers, and its sensor probe -- which may only use
+LidarDevice's PUBLIC interface (LidarDevice.hpp:116-300: nextRay1, originToSensor[Inverse], getTotal*) --
+recovers the oracle's ray tables and pose bit for bit.
+GPU part: the reference's known answers through the adapter (EmbreeTracer_test.cpp:122-135,
+OptixTracer_test.cpp:93-310: 1668 / 1781 / remove -> 1668 / empty -> 0), cloud bytes equal to the oracle's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import DATA, ROOT
+
+CFG = {u: os.path.join(DATA, "config", f"hesai-pandar-XT-32-lidar_{u}.json") for u in ("0000", "0001")}
+STL = {n: os.path.join(DATA, "mesh", f"{n}.stl") for n in ("ground", "ben")}
+
+
+@pytest.fixture(scope="module")
+def adapterapi():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "integration")], stdout=subprocess.DEVNULL)
+    from lidarshooter_amd import adapterapi as a
+    return a
+
+
+def test_adapter_compiles_against_stub_headers():
+    # g++ -fsyntax-only of integration/HipTracer.hpp against integration/stubs (the shapes of ITracer.hpp:29-152,
+    # LidarDevice.hpp:55-300, sensor_msgs::PointCloud2, pcl::PolygonMesh, Eigen, RTCGeometryType)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "integration"), "syntax"], stdout=subprocess.DEVNULL)
+
+
+def test_adapter_uses_only_public_lidar_device_members():
+    # the stub LidarDevice declares nothing but the reference's public interface, so compiling against it proves
+    # the adapter needs no new getter; spell the rule out against the text as well
+    txt = open(os.path.join(ROOT, "integration", "HipTracer.hpp")).read()
+    for name in ("verticalAngles", "horizontalBegin", "horizontalEnd", "rotationInverse", "translation()", "_channels", "_device."):
+        assert name not in txt, f"adapter touches {name}, which lidarshooter's LidarDevice does not expose"
+
+
+@pytest.mark.parametrize("uid", ["0000", "0001"])
+def test_probe_recovers_oracle_tables_and_pose(adapterapi, oracle, sensors, uid):
+    s = sensors[uid]
+    p = adapterapi.probe_sensor(CFG[uid])
+    assert (p["V"], p["H"]) == (s.V, s.H) and p["V"] * p["H"] == 4800          # LidarDevice_test.cpp:58
+    st, ct, sp, cp = oracle.ray_tables(s)
+    # the factor tables the kernels multiply: bit-equal to the oracle's libm tables
+    for got, want in ((p["sin_theta"], st), (p["cos_theta"], ct), (p["sin_phi"], sp), (p["cos_phi"], cp)):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # every direction the reference would form (LidarDevice.cpp:310-316)
+    d = oracle.ray_dirs(s).reshape(s.V, s.H, 3)
+    assert np.array_equal((p["sin_theta"][:, None] * p["cos_phi"][None, :]).view(np.uint32), d[:, :, 0].view(np.uint32))
+    assert np.array_equal((p["sin_theta"][:, None] * p["sin_phi"][None, :]).view(np.uint32), d[:, :, 1].view(np.uint32))
+    # pose: exact (LidarDevice.cpp:383-401, :812-813)
+    assert np.array_equal(p["Rinv"].view(np.uint32), s.Rinv.view(np.uint32))
+    assert np.array_equal(p["t"].view(np.uint32), s.t.view(np.uint32))
+    assert p["begin"] == s.h_begin and p["step"] == s.step()
+    assert np.allclose(p["elevation"], s.vertical, atol=1e-4)                  # only feeds conservative bounds
+
+
+def test_probe_syn128(adapterapi, oracle, sensors, tmp_path):
+    from lidarshooter_amd import synth
+    path = synth.write_sensor_json(CFG["0000"], str(tmp_path / "syn128.json"), synth.syn_vertical(128), 0.0, 360.0, 4096)
+    s = oracle.load_sensor(path)
+    assert (s.V, s.H) == (128, 4096)
+    p = adapterapi.probe_sensor(path)
+    st, ct, sp, cp = oracle.ray_tables(s)
+    for got, want in ((p["sin_theta"], st), (p["cos_theta"], ct), (p["sin_phi"], sp), (p["cos_phi"], cp)):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert p["begin"] == s.h_begin and p["step"] == s.step()
+
+
+@pytest.mark.parametrize("begin,end,count", [(-180.0, 180.0, 360), (10.0, 350.0, 200), (360.0, 0.0, 90), (0.0, 90.0, 2)])
+def test_probe_other_azimuth_ranges(adapterapi, oracle, tmp_path, begin, end, count):
+    # rasters that do not start at 0, run clockwise, or have just two columns
+    from lidarshooter_amd import synth
+    vertical = np.array([30.0, 1.5, 0.0, -0.25, -45.0, -89.0], np.float32)
+    path = synth.write_sensor_json(CFG["0001"], str(tmp_path / "odd.json"), vertical, begin, end, count)
+    s = oracle.load_sensor(path)
+    p = adapterapi.probe_sensor(path)
+    d = oracle.ray_dirs(s).reshape(s.V, s.H, 3)
+    assert np.array_equal((p["sin_theta"][:, None] * p["cos_phi"][None, :]).view(np.uint32), d[:, :, 0].view(np.uint32))
+    assert np.array_equal((p["sin_theta"][:, None] * p["sin_phi"][None, :]).view(np.uint32), d[:, :, 1].view(np.uint32))
+    assert np.array_equal(np.broadcast_to(p["cos_theta"][:, None], (s.V, s.H)).view(np.uint32), d[:, :, 2].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _points(cloud):
+    return cloud["data"].reshape(-1, 32)
+
+
+def _oracle_points(O, s, meshes, spec):
+    """spec: [(geomID, mesh name, affine)]"""
+    return O.trace_frame(s, [(g, *meshes[n], A) for g, n, A in spec])["points"]
+
+
+@pytest.mark.gpu
+def test_adapter_known_answers_and_remove_sequence(adapterapi, oracle, sensors, meshes):
+    s = sensors["0000"]
+    tr = adapterapi.AdapterTracer(CFG["0000"])
+    tr.meshFromSTL("mesh", STL["ground"])
+    tr.meshFromSTL("face", STL["ben"])
+    assert (tr.L.lsa_mesh_vertices(tr.c, b"mesh"), tr.L.lsa_mesh_polygons(tr.c, b"mesh")) == (98, 162)   # EmbreeTracer_test.cpp:86-91
+    # EmbreeTracer_test.cpp:122-135: ground alone, identity Affine3f -> 1668
+    assert tr.addGeometry("mesh") == 0 and tr.getGeometryCount() == 1
+    assert tr.updateGeometry("mesh", oracle.IDENTITY_AFFINE) == 0
+    assert tr.commitScene() == 0
+    assert tr.traceScene(1) == 0
+    c = tr.cloud()
+    assert c["width"] * c["height"] == 1668
+    # LidarDevice_test.cpp:61-76 header + EmbreeTracer.cpp:364
+    assert (c["height"], c["point_step"], c["row_step"], c["seq"], c["n_fields"]) == (1, 32, 0, 1, 5)
+    assert not c["is_bigendian"] and c["is_dense"] and c["data"].size == 1668 * 32
+    assert np.array_equal(_points(c), _oracle_points(oracle, s, {"mesh": meshes["ground"]}, [(0, "mesh", oracle.IDENTITY_AFFINE)]))
+    # OptixTracer_test.cpp:122-169: + ben through the (translation, rotation) overload with zero displacement -> 1781
+    assert tr.addGeometry("face") == 1 and tr.getGeometryCount() == 2
+    tr.updateGeometry("mesh")
+    tr.updateGeometry("face")
+    assert tr.commitScene() == 0 and tr.traceScene(2) == 0
+    c = tr.cloud()
+    assert c["width"] == 1781 and c["seq"] == 2
+    both = {"mesh": meshes["ground"], "face": meshes["ben"]}
+    assert np.array_equal(_points(c), _oracle_points(oracle, s, both, [(0, "mesh", oracle.IDENTITY_AFFINE), (1, "face", oracle.IDENTITY_AFFINE)]))
+    # OptixTracer_test.cpp:267-290: remove "face"; EmbreeTracer.cpp:252 re-commits inside removeGeometry, so a trace
+    # without another commit sees the remaining mesh
+    assert tr.removeGeometry("face") == 1 and tr.getGeometryCount() == 1
+    assert tr.traceScene(3) == 0
+    c = tr.cloud()
+    assert c["width"] == 1668 and c["data"].size == 1668 * 32
+    assert tr.removeGeometry("nope") == -1                                     # EmbreeTracer.cpp:224-225
+    # OptixTracer_test.cpp:292-310: empty scene -> commit and trace return -1, zero points
+    assert tr.removeGeometry("mesh") == 0 and tr.getGeometryCount() == 0
+    assert tr.commitScene() == -1
+    assert tr.traceScene(4) == -1
+    c = tr.cloud()
+    assert c["width"] == 0 and c["data"].size == 0
+    tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_second_sensor_and_moving_mesh(adapterapi, oracle, sensors, meshes):
+    # BASELINE.json configs[2]: lidar_0001 with its own pose; ben displaced and rotated per frame
+    s = sensors["0001"]
+    tr = adapterapi.AdapterTracer(CFG["0001"])
+    tr.meshFromSTL("mesh", STL["ground"])
+    tr.meshFromSTL("face", STL["ben"])
+    tr.addGeometry("mesh")
+    tr.addGeometry("face")
+    for frame, (lin, ang) in enumerate([((0, 0, 0), (0, 0, 0)), ((1.5, -2.0, 0.25), (0.0, 0.0, 0.6)), ((-3.0, 4.0, 0.5), (0.1, -0.2, 1.9))]):
+        tr.setDisplacement("face", lin, ang)
+        tr.updateGeometry("mesh")
+        tr.updateGeometry("face")
+        assert tr.commitScene() == 0 and tr.traceScene(frame) == 0
+        A = oracle.affine_from_components(np.array(lin, np.float32), np.array(ang, np.float32))
+        want = _oracle_points(oracle, s, {"mesh": meshes["ground"], "face": meshes["ben"]},
+                              [(0, "mesh", oracle.IDENTITY_AFFINE), (1, "face", A)])
+        c = tr.cloud()
+        assert c["width"] == want.shape[0] and np.array_equal(_points(c), want)
+        if frame == 0:
+            assert c["width"] == 1769
+    tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_mesh_policies(adapterapi, oracle, sensors, meshes):
+    """UploadAlways (default) sees an in-place edit of the cloud (MeshProjector.cpp:306-307) with the same header;
+    SkipUnchanged turns a repeated cloud into a transform-only update and still sees an edit that touches the
+    header sequence number or the probed vertices."""
+    s = sensors["0000"]
+    gv, gt = meshes["ground"]
+    tr = adapterapi.AdapterTracer(CFG["0000"])
+    tr.meshFromArrays("mesh", gv, gt, point_step=16)
+    tr.addGeometry("mesh")
+
+    def frame(i):
+        tr.updateGeometry("mesh")
+        assert tr.commitScene() == 0 and tr.traceScene(i) == 0
+        return _points(tr.cloud())
+
+    want0 = oracle.trace_frame(s, [(0, gv, gt, oracle.IDENTITY_AFFINE)])["points"]
+    assert np.array_equal(frame(0), want0)
+    assert tr.uploadCounts() == (1, 0)
+    lifted = gv.copy()
+    lifted[:, 2] += np.float32(0.5)
+    want1 = oracle.trace_frame(s, [(0, lifted, gt, oracle.IDENTITY_AFFINE)])["points"]
+    tr.setVertices("mesh", lifted, seq=0)                       # same buffer, same header: only the bytes differ
+    assert np.array_equal(frame(1), want1)
+    assert tr.uploadCounts() == (2, 0)
+    # ---- SkipUnchanged
+    tr.setSkipUnchanged(True)
+    assert np.array_equal(frame(2), want1)                      # first keyed frame records the key: still an upload
+    assert np.array_equal(frame(3), want1)
+    assert tr.uploadCounts() == (3, 1)
+    tr.setDisplacement("mesh", (0.5, 0.25, -0.125), (0.0, 0.0, 0.3))   # pose-only change: no vertex traffic
+    A = oracle.affine_from_components(np.array((0.5, 0.25, -0.125), np.float32), np.array((0.0, 0.0, 0.3), np.float32))
+    assert np.array_equal(frame(4), oracle.trace_frame(s, [(0, lifted, gt, A)])["points"])
+    assert tr.uploadCounts() == (3, 2)
+    tr.setVertices("mesh", gv, seq=7)                           # a new mesh message: header.seq differs -> upload
+    assert np.array_equal(frame(5), oracle.trace_frame(s, [(0, gv, gt, A)])["points"])
+    assert tr.uploadCounts() == (4, 2)
+    tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_syn128_over_grid(adapterapi, oracle, tmp_path):
+    """A dense sensor through the adapter: 128 x 1024 rays over a 200 x 100-cell grid (40 000 triangles), against
+    the oracle's BVH tracer; pcl::PointXYZ-sized vertex records (16 bytes)."""
+    from lidarshooter_amd import synth
+    path = synth.write_sensor_json(CFG["0000"], str(tmp_path / "syn.json"), synth.syn_vertical(128), 0.0, 360.0, 1024)
+    s = oracle.load_sensor(path)
+    v, t = synth.grid_mesh(200, 100)
+    tr = adapterapi.AdapterTracer(path)
+    tr.meshFromArrays("grid", v, t, point_step=16)
+    assert tr.addGeometry("grid") == 0
+    tr.updateGeometry("grid")
+    assert tr.commitScene() == 0 and tr.traceScene(9) == 0
+    want = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True)["points"]
+    c = tr.cloud()
+    assert c["width"] == want.shape[0] > 10000 and np.array_equal(_points(c), want)
+    spf = tr.frameLoop(5)                                        # MeshProjector::traceAffineMesh x5 in C++
+    assert spf > 0
+    assert np.array_equal(_points(tr.cloud()), want) and tr.cloud()["seq"] == 5
+    tr.close()

@@ -1,0 +1,186 @@
+"""GPU tests of the drop-in (ITracer-shaped, host-buffer) path of the C ABI and of the handle's failure reporting:
+asynchronous staged uploads, host-visible outputs, table-based creation (what the ROS adapter uses), remove ->
+commit semantics (EmbreeTracer.cpp:252), the device status word, the per-slot ordering of library mesh copies."""
+import numpy as np
+import pytest
+
+from conftest import make_tracer
+
+pytestmark = pytest.mark.gpu
+
+
+def _hits_array(hits):
+    return np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1)
+
+
+def _tracer_from_tables(capi, oracle, s):
+    import ctypes as C
+    st, ct, sp, cp = oracle.ray_tables(s)
+    elev = np.ascontiguousarray(s.vertical, np.float32)
+    tb = capi.SensorTables()
+    keep = [np.ascontiguousarray(a, np.float32) for a in (st, ct, elev, sp, cp)]
+    f32p = C.POINTER(C.c_float)
+    tb.sin_theta, tb.cos_theta, tb.elevation_deg, tb.sin_phi, tb.cos_phi = [a.ctypes.data_as(f32p) for a in keep]
+    tb.n_vertical, tb.h_count = s.V, s.H
+    tb.h_begin_deg, tb.h_step_deg = float(s.h_begin), float(s.step())
+    tb.Rinv = (C.c_float * 9)(*[float(x) for x in s.Rinv])
+    tb.t = (C.c_float * 3)(*[float(x) for x in s.t])
+    tr = capi.Tracer.__new__(capi.Tracer)
+    tr.L = capi.load()
+    h = C.c_void_p()
+    assert tr.L.ls_tracer_create_tables(C.byref(tb), 0, C.byref(h)) == 0
+    tr.h, tr.V, tr.H, tr.az0, tr.naz = h, s.V, s.H, 0, s.H
+    return tr
+
+
+@pytest.mark.parametrize("uid", ["0000", "0001"])
+def test_create_from_tables_equals_create_from_desc(oracle, capi, sensors, meshes, uid, engine):
+    # ls_tracer_create_tables (the adapter's entry: tables recovered through LidarDevice's public interface) gives the
+    # oracle's frame, like ls_tracer_create
+    from conftest import ENGINES
+    s = sensors[uid]
+    tr = _tracer_from_tables(capi, oracle, s)
+    tr.setOption(capi.LS_OPT_ENGINE, ENGINES[engine])
+    for name, key in (("ground", "ground"), ("face", "ben")):
+        assert tr.addGeometry(name, meshes[key][0].shape[0], meshes[key][1].shape[0]) >= 0
+        tr.updateGeometry(name, oracle.IDENTITY_AFFINE, *meshes[key])
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
+    assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    tr.close()
+
+
+@pytest.mark.parametrize("host_output,readback_hits", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_host_output_modes(oracle, capi, sensors, meshes, host_output, readback_hits, engine):
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, engine)
+    tr.setOption(capi.LS_OPT_HOST_OUTPUT, host_output)
+    tr.setOption(capi.LS_OPT_READBACK_HITS, readback_hits)
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.addGeometry("face", *[a.shape[0] for a in meshes["ben"]])
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
+    for frame in range(3):   # repeated frames reuse the pinned buffers
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+        tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(frame)
+        assert rc == 0 and np.array_equal(pts, ref["points"])
+        if readback_hits:
+            assert np.array_equal(_hits_array(hits), ref["hits"])
+        else:
+            assert hits.shape[0] == 0 and not tr.last_frame.hits and tr.last_frame.d_hits
+        t, gid = tr.denseHits()                      # rebuilt from the records wherever they live
+        assert np.array_equal(gid, ref["gid"]) and np.array_equal(t, ref["t"])
+    tr.close()
+
+
+def test_host_upload_returns_with_caller_memory_free(oracle, capi, sensors):
+    """ls_update_geometry copies through the pinned staging ring with the pool's threads and never waits for the
+    device; when it returns the caller may overwrite its buffers (MeshProjector.cpp:448-461 does).  A mesh large
+    enough for many 512 KB chunks; the arrays are scribbled over right after every call."""
+    from lidarshooter_amd import synth
+    s = sensors["0001"]
+    v, t = synth.grid_mesh(400, 300)                 # 120 701 vertices x 16 B = 1.9 MB, 240 000 triangles = 2.9 MB
+    padded = np.zeros((v.shape[0], 4), np.float32)   # pcl::PointXYZ records
+    padded[:, :3] = v
+    tr = make_tracer(capi, s, "projection")
+    assert tr.info(capi.LS_INFO_HOST_THREADS) >= 1
+    tr.addGeometry("grid", v.shape[0], t.shape[0])
+    ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True)
+    for frame in range(4):
+        vv, tt = padded.copy(), t.copy()
+        tr.updateGeometry("grid", oracle.IDENTITY_AFFINE, vv, tt if frame == 0 else None, stride=16)
+        vv[:] = np.float32(1e9)                      # the caller's memory is its own again
+        tt[:] = 0
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(frame)
+        assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    tr.close()
+
+
+def test_remove_geometry_commits(oracle, capi, sensors, meshes, engine):
+    # EmbreeTracer.cpp:252: removeGeometry commits, so a traceScene that follows traces what is left
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, engine)
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.addGeometry("face", *[a.shape[0] for a in meshes["ben"]])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    assert tr.commitScene() == 0
+    assert len(tr.traceScene(0)[1]) == 1781
+    assert tr.removeGeometry("face") == 1
+    rc, pts, hits = tr.traceScene(1)                 # no commitScene in between
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    assert rc == 0 and len(pts) == 1668 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    assert tr.removeGeometry("ground") == 0          # the commit inside finds an empty scene: not an error of the removal
+    rc, pts, _ = tr.traceScene(2)
+    assert rc == -1 and len(pts) == 0
+    tr.close()
+
+
+def test_three_stream_mode_orders_every_slot_after_a_library_copy(oracle, capi, sensors, meshes):
+    """LS_OPT_PIPELINE = 2 on the handle's own stream: ls_update_geometry_device enqueues a D2D copy on that stream
+    with no host wait; ALL three slot streams (not only the first frame's) have to order themselves after it."""
+    import torch
+    s = sensors["0000"]
+    dev = torch.device("cuda", 0)
+    gv, gt = meshes["ground"]
+    bv, bt = meshes["ben"]
+    tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_PIPELINE, 2)
+    mode = tr.info(capi.LS_INFO_PIPELINE_MODE)
+    assert mode in (1, 2) and (mode == 2) == (tr.info(capi.LS_INFO_CONCURRENT_STREAMS) >= 3)
+    tr.addGeometry("ground", gv.shape[0], gt.shape[0])
+    tr.addGeometry("face", bv.shape[0], bt.shape[0])
+    d_gt = torch.from_numpy(gt.view(np.int32)).to(dev)
+    d_bt = torch.from_numpy(bt.view(np.int32)).to(dev)
+    cap = s.V * s.H
+    bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device=dev), torch.zeros(16 * cap, dtype=torch.uint8, device=dev),
+             torch.zeros(4, dtype=torch.int32, device=dev)) for _ in range(3)]
+    for rnd in range(6):
+        shift = np.float32(0.75 * rnd)
+        bv2 = (bv + np.array([shift, -shift, 0.1 * rnd], np.float32)).astype(np.float32)
+        d_gv = torch.from_numpy(gv).to(dev)
+        d_bv = torch.from_numpy(bv2).to(dev)
+        torch.cuda.synchronize()
+        tr.updateGeometryDevice("ground", oracle.IDENTITY_AFFINE, d_gv.data_ptr(), 12, d_gt.data_ptr())
+        tr.updateGeometryDevice("face", oracle.IDENTITY_AFFINE, d_bv.data_ptr(), 12, d_bt.data_ptr())
+        assert tr.commitScene() == 0
+        for k in range(3):                           # three frames, one per slot stream, right behind the copies
+            p, h, n = bufs[k]
+            tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
+            tr.traceSceneAsync(3 * rnd + k)
+        tr.synchronize()
+        ref = oracle.trace_frame(s, [(0, gv, gt, oracle.IDENTITY_AFFINE), (1, bv2, bt, oracle.IDENTITY_AFFINE)])
+        for p, h, n in bufs:
+            cnt = int(n[0].item())
+            assert cnt == ref["points"].shape[0]
+            assert np.array_equal(p.cpu().numpy()[:32 * cnt].reshape(cnt, 32), ref["points"])
+    tr.close()
+
+
+def test_stuck_chained_prefix_is_reported(oracle, capi, sensors, meshes):
+    """LS_OPT_DEBUG_FAULT makes one pipelined frame publish a tag nobody waits for: its workgroups give up, raise the
+    device status word, and the next host wait returns LS_ERR_HIP instead of an empty cloud with rc 0.  The handle
+    keeps working afterwards."""
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_PIPELINE, 1)
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    assert tr.commitScene() == 0
+    tr.traceSceneAsync(0)
+    tr.synchronize()                                  # a healthy frame: no error
+    tr.setOption(capi.LS_OPT_DEBUG_FAULT, 1)
+    tr.traceSceneAsync(1)                             # this frame's finish + pack will publish the wrong tag
+    with pytest.raises(capi.LidarShooterHipError, match="chained prefix"):
+        tr.synchronize()
+    assert tr.info(capi.LS_INFO_DEVICE_STATUS) == 0   # read-and-clear happened with the error
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    for k in range(3):                                # both key sets and the epoch tags are intact
+        tr.traceSceneAsync(2 + k)
+    tr.synchronize()
+    rc, pts, hits = tr.traceScene(9)
+    assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    tr.close()

@@ -161,6 +161,13 @@ def test_moved_mesh_components(oracle, capi, sensors, meshes, engine):
     assert tr.commitScene() == 0
     rc, pts, hits = tr.traceScene(1)
     assert len(pts) == 1781
+    _assert_parity(oracle, s, tr, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)], pts, hits)
+    # and to a third pose, still without vertex traffic
+    A2 = oracle.affine_from_components([-3.0, 4.0, 0.5], [0.0, 0.3, -1.1])
+    tr.updateGeometryTransform("face", A2)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(2)
+    _assert_parity(oracle, s, tr, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A2)], pts, hits)
     tr.close()
 
 
