@@ -102,6 +102,9 @@ typedef struct ls_frame {
     const void *d_points32;  /* the same data in device memory (for RCCL gathers)  */
     const void *d_hits;
     const uint32_t *d_n_points; /* device word holding n_points                    */
+    const void *compact16;   /* LS_OPT_HOST_OUTPUT = 2: n_points records of 16 bytes (x, y, z f32, ring i32) in pinned
+                              * host memory instead of points32 (which is NULL then); ls_expand_points rebuilds the
+                              * 32-byte records -- half the bytes cross PCIe                                        */
 } ls_frame;
 
 /* ---- lifetime: EmbreeTracer::create / ~EmbreeTracer (EmbreeTracer.cpp:10-70),
@@ -123,9 +126,10 @@ int ls_remove_geometry(ls_tracer *tr, const char *name);
  * records of vert_stride bytes whose first 12 bytes are x,y,z float32 (pcl cloud.data with
  * point_step, MeshTransformer.cpp:176-181).  tri_idx: 3*n_elements vertex indices (polygons[i].vertices,
  * MeshTransformer.cpp:512-518); NULL keeps the indices of the previous update.  Host pointers; the
- * caller may reuse them as soon as the call returns (MeshProjector.cpp:448-461 does): the data is copied
- * by the library's worker threads into a pinned staging buffer, chunk by chunk, and each chunk's DMA is
- * enqueued on the handle's stream behind it -- the call never waits for the device. */
+ * caller may reuse them as soon as the call returns (MeshProjector.cpp:448-461 does).  By default the copy
+ * goes straight from the caller's pageable memory at PCIe rate and the call returns when the memory has been
+ * read; with LS_UPLOAD_MODE=0 in the environment the library's worker threads stage it through pinned memory
+ * instead and the call never waits for the device. */
 int ls_update_geometry(ls_tracer *tr, const char *name, const float affine3x4[12], const void *verts,
                        uint32_t vert_stride, const uint32_t *tri_idx);
 
@@ -244,8 +248,9 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
                                  * ls_update_geometry_device_shared must stay unchanged while frames are in flight.  */
 #define LS_OPT_HOST_OUTPUT 7    /* synchronous ls_trace_scene: 1 (default) the pack kernel writes points (and hit
                                  *    records) straight into the pinned host buffers that ls_frame returns -- one
-                                 *    host wait per frame, no copy engine; 0: device buffers, then count + sized D2H
-                                 *    copies (two waits).                                                      */
+                                 *    host wait per frame, no copy engine; 2: the same with 16-byte compact point
+                                 *    records (ls_frame.compact16, expanded by ls_expand_points); 0: device buffers,
+                                 *    then count + sized D2H copies (two waits).                               */
 #define LS_OPT_READBACK_HITS 8  /* synchronous ls_trace_scene: 1 (default) ls_frame.hits is filled; 0: the 16-byte
                                  *    hit records stay on the device (ls_frame.hits = NULL, d_hits valid) -- the ITracer
                                  *    adapter only needs the 32-byte points.                                   */
@@ -255,6 +260,10 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */
 int ls_tracer_set_option(ls_tracer *tr, int option, int value);
+
+/* Rebuild n_points 32-byte PointCloud2 records (XYZIRBytes.cpp:24-40; intensity 64.0, EmbreeTracer.cpp:343) at
+ * dst_points32 from the compact records of ls_frame.compact16, with the library's worker threads. */
+int ls_expand_points(void *dst_points32, const void *compact16, uint32_t n_points);
 
 /* Copy `bytes` from src to dst with the library's worker threads (both host pointers).  The adapter
  * uses it to move a frame's points from the pinned buffer of ls_frame into PointCloud2::data; a single

@@ -20,8 +20,9 @@
 //     (buffer, size, header.seq, header.stamp, 256-vertex probe) a transform-only update: no copy at all
 //     -- what a joystick-driven pose change is (AffineMesh.cpp:108-128);
 //   * the vertex transform (MeshTransformer.cpp:142-205), ray generation, closest hit and 32-byte point
-//     packing (XYZIRBytes.cpp:24-40) run on the GPU; the points land in pinned host memory with one host
-//     wait and are moved into PointCloud2::data by the library's copy threads.
+//     packing (XYZIRBytes.cpp:24-40) run on the GPU; the points land in pinned host memory (16 bytes each:
+//     the other 16 of a record are constants) with one host wait and are expanded into PointCloud2::data by
+//     the library's copy threads.
 #pragma once
 
 #include <lidarshooter_hip.h>
@@ -142,7 +143,7 @@ public:
         // no clear() first: shrinking costs nothing and growing value-initialises only the difference
         const std::size_t bytes = static_cast<std::size_t>(frame.n_points) * 32u;
         cloud->data.resize(bytes);
-        if (bytes != 0) ls_parallel_copy(cloud->data.data(), frame.points32, bytes);
+        if (bytes != 0) ls_expand_points(cloud->data.data(), frame.compact16, frame.n_points);
         cloud->width = frame.n_points;   // EmbreeTracer.cpp:364; height 1, row_step 0 from initMessage
         return rc;
     }
@@ -210,6 +211,7 @@ private:
             throw TraceException(__FILE__, rc == LS_ERR_NO_DEVICE ? "no usable HIP device for the MI355X tracer (there is no CPU fallback)"
                                                                   : "ls_tracer_create_tables rejected the probed sensor", rc);
         ls_tracer_set_option(_handle, LS_OPT_READBACK_HITS, 0);   // the cloud only carries the 32-byte points
+        ls_tracer_set_option(_handle, LS_OPT_HOST_OUTPUT, 2);     // 16 bytes per point over PCIe, expanded into cloud->data
         if (_logger) _logger->debug("HipTracer: {} channels x {} azimuths, {} host copy threads", tables.n_vertical, tables.h_count,
                                     ls_get_info(_handle, LS_INFO_HOST_THREADS));
     }

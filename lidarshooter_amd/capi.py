@@ -25,7 +25,7 @@ STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "t
 
 # every symbol include/lidarshooter_hip.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = (
-    "ls_abi_version", "ls_tracer_create", "ls_tracer_create_tables", "ls_tracer_destroy", "ls_parallel_copy", "ls_get_info", "ls_affine_from_components", "ls_add_geometry", "ls_remove_geometry",
+    "ls_abi_version", "ls_tracer_create", "ls_tracer_create_tables", "ls_tracer_destroy", "ls_parallel_copy", "ls_expand_points", "ls_get_info", "ls_affine_from_components", "ls_add_geometry", "ls_remove_geometry",
     "ls_update_geometry", "ls_update_geometry_components", "ls_update_geometry_device",
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
@@ -51,7 +51,7 @@ class SensorTables(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("points32", C.POINTER(C.c_uint8)), ("hits", C.c_void_p), ("n_points", C.c_uint32),
                 ("n_rays", C.c_uint32), ("frame", C.c_uint32), ("d_points32", C.c_void_p),
-                ("d_hits", C.c_void_p), ("d_n_points", C.c_void_p)]
+                ("d_hits", C.c_void_p), ("d_n_points", C.c_void_p), ("compact16", C.c_void_p)]
 
 
 HIT_DTYPE = np.dtype([("ray", "<u4"), ("geom", "<u4"), ("prim", "<u4"), ("t", "<f4")])
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     L.ls_tracer_create_tables.argtypes = [C.POINTER(SensorTables), i32, C.POINTER(vp)]
     L.ls_affine_from_components.argtypes = [f32p, f32p, f32p]
     L.ls_affine_from_components.restype = None
+    L.ls_expand_points.argtypes = [vp, vp, u32]
     L.ls_parallel_copy.argtypes = [vp, vp, C.c_uint64]
     L.ls_get_info.argtypes = [vp, i32]
     L.ls_get_info.restype = C.c_long
@@ -243,7 +244,11 @@ class Tracer:
         fr = Frame()
         rc = self._check(self.L.ls_trace_scene(self.h, frame_index, C.byref(fr)), "ls_trace_scene")
         n = int(fr.n_points)
-        if n:
+        if n and fr.compact16:   # LS_OPT_HOST_OUTPUT = 2
+            pts = np.zeros((n, 32), np.uint8)
+            self._check(self.L.ls_expand_points(pts.ctypes.data, fr.compact16, n), "ls_expand_points")
+            hits = (np.frombuffer(C.string_at(fr.hits, n * 16), dtype=HIT_DTYPE).copy() if fr.hits else np.zeros(0, HIT_DTYPE))
+        elif n:
             pts = np.ctypeslib.as_array(fr.points32, shape=(n * 32,)).reshape(n, 32).copy()
             hits = (np.frombuffer(C.string_at(fr.hits, n * 16), dtype=HIT_DTYPE).copy() if fr.hits
                     else np.zeros(0, HIT_DTYPE))   # LS_OPT_READBACK_HITS = 0: the records stay on the device

@@ -134,12 +134,13 @@ void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, c
                   uint32_t ntris, float *t_out, uint32_t *gid_out, uint32_t *spill,
                   unsigned long long *visit_counts /* nullptr = do not count */);
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts);
+// compact != 0: points are written as 16-byte records (x, y, z, ring) instead of the 32-byte PointCloud2 layout
 void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,
-                 const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points);
+                 const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact = 0);
 // projection engine: pack straight from the closest-hit keys (also re-arms keys, counters, queue)
 void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
                       const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
-                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points);
+                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact = 0);
 // projection engine: per-geometry streaming kernel, big-footprint kernel, resolve (+ row counts)
 size_t project_big_item_bytes();
 void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,
@@ -162,6 +163,7 @@ struct FinishPackArgs {
     void *hits;
     uint32_t *n_points;
     uint32_t n_blocks;              // ceil(rays / 256)
+    uint32_t compact;               // points as 16-byte (x, y, z, ring) records (LS_OPT_HOST_OUTPUT = 2)
 };
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
                     void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats,

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
                                                  const uint32_t *__restrict__ block_counts,
                                                  uint32_t *__restrict__ next_block_counts, uint32_t *__restrict__ big_count,
                                                  GeomTable gt, float4 *__restrict__ points, uint4 *__restrict__ hits,
-                                                 uint32_t *__restrict__ n_points)
+                                                 uint32_t *__restrict__ n_points, uint32_t compact)
 {
     __shared__ uint32_t s_part[kBlock / 64];
     __shared__ uint32_t s_wave[kBlock / 64];
@@ -510,8 +510,13 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     const float st = tb.sin_theta[v];
     const float2 cs = tb.cs_phi[h];
     // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
-    points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * tb.cos_theta[v], 0.0f);
-    points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+    if (compact) {
+        // host-visible compact form (LS_OPT_HOST_OUTPUT = 2): 16 bytes cross PCIe, ls_expand_points rebuilds the record
+        points[dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * tb.cos_theta[v], __int_as_float((int)v));
+    } else {
+        points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * tb.cos_theta[v], 0.0f);
+        points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+    }
     // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
     uint32_t lo = 0, hi = gt.n;
     while (hi - lo > 1) {
@@ -778,25 +783,25 @@ void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_
 }
 
 void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,
-                 const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
+                 const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact)
 {
     const uint32_t nq = tb.V * tb.naz;
     if (!nq) return;
     hipLaunchKernelGGL(k_pack<false>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid,
                        static_cast<unsigned long long *>(nullptr), block_counts, static_cast<uint32_t *>(nullptr),
                        static_cast<uint32_t *>(nullptr), gt, reinterpret_cast<float4 *>(points32),
-                       reinterpret_cast<uint4 *>(hits), n_points);
+                       reinterpret_cast<uint4 *>(hits), n_points, compact);
 }
 
 void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
                       const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
-                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points)
+                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact)
 {
     const uint32_t nq = tb.V * tb.naz;
     if (!nq) return;
     hipLaunchKernelGGL(k_pack<true>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts,
                        next_block_counts, big_count, gt, reinterpret_cast<float4 *>(points32),
-                       reinterpret_cast<uint4 *>(hits), n_points);
+                       reinterpret_cast<uint4 *>(hits), n_points, compact);
 }
 
 // One wave that does nothing for `ticks` of the 100 MHz wall clock: ls_tracer.cpp uses it to find out which

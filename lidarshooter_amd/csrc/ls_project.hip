@@ -644,8 +644,12 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     float4 *__restrict__ points = reinterpret_cast<float4 *>(fa.points32);
     uint4 *__restrict__ hits = reinterpret_cast<uint4 *>(fa.hits);
     // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
-    points[2 * (size_t)dst] = make_float4(t * d.x, t * d.y, t * d.z, 0.0f);
-    points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+    if (fa.compact) {
+        points[dst] = make_float4(t * d.x, t * d.y, t * d.z, __int_as_float((int)v));
+    } else {
+        points[2 * (size_t)dst] = make_float4(t * d.x, t * d.y, t * d.z, 0.0f);
+        points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+    }
     // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
     uint32_t lo = 0, hi = fa.gt.n;
     while (hi - lo > 1) {

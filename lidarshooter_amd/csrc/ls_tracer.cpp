@@ -157,7 +157,14 @@ private:
     bool stop_ = false;
 };
 
-constexpr size_t kCopyChunk = 512u << 10;   // host copy / DMA granularity of an upload
+// host copy / DMA granularity of an upload (LS_COPY_CHUNK_KB, LS_DMA_RUN: tuning knobs of tools/dropin_bench.py)
+static const size_t kCopyChunk = (getenv("LS_COPY_CHUNK_KB") ? (size_t)std::max(16, atoi(getenv("LS_COPY_CHUNK_KB"))) : 512u) << 10;
+static const size_t kDmaRun = getenv("LS_DMA_RUN") ? (size_t)std::max(1, atoi(getenv("LS_DMA_RUN"))) : 4u;
+// LS_UPLOAD_MODE: 1 (default) hipMemcpyAsync straight from the caller's pageable memory -- the runtime pins the pages
+// for the duration of the call and the copy runs at PCIe rate (8 MB in 0.154 ms = 52 GB/s on the MI355X box);
+// 0: copy pool -> pinned staging -> DMA, never waits for the device but costs 0.26-0.31 ms of host time for the same
+// 8 MB; 2: one thread, one DMA (0.33 ms).  tools/upload_sweep.py.
+static const int kUploadMode = getenv("LS_UPLOAD_MODE") ? atoi(getenv("LS_UPLOAD_MODE")) : 1;
 
 void parallel_copy(void *dst, const void *src, size_t bytes)
 {
@@ -689,6 +696,13 @@ void affine_from_components(const float *lin, const float *ang, float *A)
 int stage_upload(ls_tracer *tr, void *&stage, size_t &stage_cap, hipEvent_t &ev, void *d_dst, const void *src, size_t bytes)
 {
     if (!bytes) return LS_OK;
+    if (kUploadMode == 1) {
+        // the call returns once the caller's memory has been read (pageable source: the runtime waits for its own
+        // staging / pinning); what follows on the stream is ordered behind the copy
+        LS_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, tr->stream));
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        return LS_OK;
+    }
     if (bytes > stage_cap) {
         if (stage) { LS_HIP(hipStreamSynchronize(tr->stream)); LS_HIP(hipHostFree(stage)); }
         stage = nullptr;
@@ -716,10 +730,17 @@ int stage_upload(ls_tracer *tr, void *&stage, size_t &stage_cap, hipEvent_t &ev,
     };
     const std::function<void(size_t)> dma = [&](size_t i) {
         if (!run_len) run_first = i;
-        if (++run_len == 4 || i + 1 == n) flush_run();
+        if (++run_len == kDmaRun || i + 1 == n) flush_run();
     };
-    HostPool::get().run(n, copy, &dma);
-    flush_run();
+    if (kUploadMode == 2) {   // ablation: one thread, one DMA
+        std::memcpy(stage, src, bytes);
+        run_first = 0;
+        run_len = n;
+        flush_run();
+    } else {
+        HostPool::get().run(n, copy, &dma);
+        flush_run();
+    }
     if (err != hipSuccess) { tr->err = std::string("hipMemcpyAsync (upload): ") + hipGetErrorString(err); return LS_ERR_HIP; }
     LS_HIP(hipEventRecord(ev, tr->stream));
     return LS_OK;
@@ -957,6 +978,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     // synchronous call with the library's own outputs: the pack kernel writes the pinned host buffers itself
     const bool hv = readback && tr->opt_host_output && !tr->ext_points;
     if (hv && (rc = ensure_host_buffers(tr, shard_rays(tr)))) return rc;
+    const uint32_t compact = hv && tr->opt_host_output == 2 ? 1u : 0u;
     auto host_targets = [&]() {
         if (!hv) return;
         d_points = tr->h_points;
@@ -1068,6 +1090,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             fa.hits = d_hits;
             fa.n_points = d_n;
             fa.n_blocks = n_blocks;
+            fa.compact = compact;
             tr->pipe_pending = true;
             ++tr->pipe_seq;
             if (readback && (rc = flush_pipeline(tr))) return rc;
@@ -1077,7 +1100,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             mark(tr, 8);
             ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
             mark(tr, 9);
-            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n);
+            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n, compact);
             mark(tr, 10);
             if (multi) {
                 // no event per frame: a flush (or a mesh copy) records one per stream and orders the handle's stream after it
@@ -1111,7 +1134,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         gt.n = (uint32_t)tr->slot_geom_ids.size();
         gt.tri_first = tr->geom_table.p;
         gt.geom_ids = tr->geom_table.p + gt.n + 1;
-        ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n);
+        ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n, compact);
         tr->traced_projection = false;
         mark(tr, 10);
     }
@@ -1126,7 +1149,8 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         LS_HIP(hipStreamSynchronize(s));   // the only host wait of the frame
         if ((rc = check_device_status(tr))) return rc;
         out->n_points = *tr->h_n_points;
-        out->points32 = tr->h_points;
+        out->points32 = compact ? nullptr : tr->h_points;
+        out->compact16 = compact ? tr->h_points : nullptr;
         out->hits = tr->opt_readback_hits ? tr->h_hits : nullptr;
         return LS_OK;
     }
@@ -1501,6 +1525,34 @@ int ls_tracer_synchronize(ls_tracer *tr)
     return check_device_status(tr);
 }
 
+int ls_expand_points(void *dst_points32, const void *compact16, uint32_t n_points)
+{
+    if ((!dst_points32 || !compact16) && n_points) return LS_ERR_INVALID_ARGUMENT;
+    // XYZIRBytes.cpp:24-40: x@0 y@4 z@8 0@12 intensity@16 ring@20 0@24..31; intensity is the constant 64.0 (EmbreeTracer.cpp:343)
+    constexpr size_t kPer = 16384;   // points per work item: 256 KB read, 512 KB written
+    const size_t n = n_points, items = (n + kPer - 1) / kPer;
+    const float intensity = 64.0f;
+    uint32_t ibits;
+    std::memcpy(&ibits, &intensity, 4);
+    const std::function<void(size_t)> work = [&](size_t i) {
+        const uint32_t *src = static_cast<const uint32_t *>(compact16) + 4 * i * kPer;
+        uint32_t *dst = static_cast<uint32_t *>(dst_points32) + 8 * i * kPer;
+        const size_t cnt = std::min(kPer, n - i * kPer);
+        for (size_t k = 0; k < cnt; ++k) {
+            dst[8 * k + 0] = src[4 * k + 0];
+            dst[8 * k + 1] = src[4 * k + 1];
+            dst[8 * k + 2] = src[4 * k + 2];
+            dst[8 * k + 3] = 0u;
+            dst[8 * k + 4] = ibits;
+            dst[8 * k + 5] = src[4 * k + 3];
+            dst[8 * k + 6] = 0u;
+            dst[8 * k + 7] = 0u;
+        }
+    };
+    HostPool::get().run(items, work);
+    return LS_OK;
+}
+
 int ls_parallel_copy(void *dst, const void *src, uint64_t bytes)
 {
     if ((!dst || !src) && bytes) return LS_ERR_INVALID_ARGUMENT;
@@ -1563,7 +1615,7 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         return LS_OK;
     case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
     case LS_OPT_HOST_OUTPUT:
-        if (value < 0 || value > 1) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_HOST_OUTPUT: 0 or 1");
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_HOST_OUTPUT: 0, 1 or 2");
         tr->opt_host_output = value;
         return LS_OK;
     case LS_OPT_READBACK_HITS:

@@ -51,7 +51,7 @@ def test_create_from_tables_equals_create_from_desc(oracle, capi, sensors, meshe
     tr.close()
 
 
-@pytest.mark.parametrize("host_output,readback_hits", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("host_output,readback_hits", [(1, 1), (1, 0), (0, 1), (0, 0), (2, 1), (2, 0)])
 def test_host_output_modes(oracle, capi, sensors, meshes, host_output, readback_hits, engine):
     s = sensors["0000"]
     tr = make_tracer(capi, s, engine)
@@ -76,9 +76,9 @@ def test_host_output_modes(oracle, capi, sensors, meshes, host_output, readback_
 
 
 def test_host_upload_returns_with_caller_memory_free(oracle, capi, sensors):
-    """ls_update_geometry copies through the pinned staging ring with the pool's threads and never waits for the
-    device; when it returns the caller may overwrite its buffers (MeshProjector.cpp:448-461 does).  A mesh large
-    enough for many 512 KB chunks; the arrays are scribbled over right after every call."""
+    """When ls_update_geometry returns, the caller may overwrite its buffers (MeshProjector.cpp:448-461 does),
+    whichever way the bytes travel (straight from pageable memory by default; LS_UPLOAD_MODE=0: copy pool -> pinned
+    staging -> chunked DMA).  A mesh of several 512 KB chunks; the arrays are scribbled over right after every call."""
     from lidarshooter_amd import synth
     s = sensors["0001"]
     v, t = synth.grid_mesh(400, 300)                 # 120 701 vertices x 16 B = 1.9 MB, 240 000 triangles = 2.9 MB
