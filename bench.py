@@ -58,6 +58,11 @@ def parse_args():
     ap.add_argument("--leaf", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
     ap.add_argument("--engine", default="auto", choices=["auto", "bvh", "projection"],
                     help="closest-hit engine (auto = the library default: sensor-space projection)")
+    ap.add_argument("--reregister", action="store_true",
+                    help="hand the (unchanged) device mesh over again every frame (ls_update_geometry_device_shared) instead of "
+                         "a transform-only update: the library must then assume new vertices and redo its per-block bounds")
+    ap.add_argument("--no-cull", action="store_true", help="LS_OPT_BLOCK_CULL off")
+    ap.add_argument("--cull", action="store_true", help="LS_OPT_BLOCK_CULL on (default: the library's auto rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--breakdown", action="store_true", help="extra pass with per-stage hipEvent timings")
@@ -172,6 +177,8 @@ def main():
     if args.leaf:
         tr.setOption(capi.LS_OPT_LEAF_SIZE, args.leaf)
     tr.setOption(capi.LS_OPT_ENGINE, {"auto": 0, "bvh": 1, "projection": 2}[args.engine])
+    if args.no_cull or args.cull:
+        tr.setOption(capi.LS_OPT_BLOCK_CULL, 1 if args.cull else 0)
     engine = "bvh" if args.engine == "bvh" else "projection"
     tr.setShard(first_az, n_az)
     # a dedicated (non-default) stream shared by the tracer's kernels and, through torch, by RCCL's
@@ -227,10 +234,20 @@ def main():
     fast_frame_struct = capi.Frame()
     fast_out = [(C.c_void_p(b.data_ptr() + 64), C.c_void_p(b.data_ptr() + 64 + 32 * cap), C.c_void_p(b.data_ptr())) for b in out_bufs] if single else None
 
+    registered = set()
+
     def fast_update_and_trace(i):
         for nm, pv, pt, moving in fast_meshes:
             a = fast_aff[i % len(fast_aff)] if (moving and replicas) else ident_c
-            if L.ls_update_geometry_device_shared(h, nm, C.cast(a, f32p), pv, 12, pt) < 0:
+            if args.reregister or nm not in registered:
+                # the mesh is handed over (in place, in HBM): the library may find any vertices there
+                rc = L.ls_update_geometry_device_shared(h, nm, C.cast(a, f32p), pv, 12, pt)
+                registered.add(nm)
+            else:
+                # steady state: the mesh has not changed, only its pose is (re)stated -- what the ITracer adapter does
+                # for an unchanged pcl::PolygonMesh and what AffineMesh's pose integration produces (AffineMesh.cpp:108-128)
+                rc = L.ls_update_geometry_transform(h, nm, C.cast(a, f32p))
+            if rc < 0:
                 raise RuntimeError(tr.last_error())
         if L.ls_commit_scene(h) < -1:
             raise RuntimeError(tr.last_error())

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("LS_LIB_PATH") or os.path.join(_HERE, "liblidarshooter
 INVALID = 0xFFFFFFFF
 
 LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPELINE = 1, 2, 3, 5, 6
-LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT = 7, 8, 9
+LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL = 7, 8, 9, 10
 LS_INFO_CONCURRENT_STREAMS, LS_INFO_PIPELINE_MODE, LS_INFO_DEVICE_STATUS, LS_INFO_HOST_THREADS = 1, 2, 3, 4
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
 STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "trace_aux", "pack")

@@ -89,6 +89,8 @@ struct ProjectParams {
     float sec_a[2], sec_b[2];      // unit vectors (cos, sin) of the padded sector's first / second boundary, counter-clockwise
     uint32_t big_cells;            // footprints above this many cells go to the gather queue
     int debug;                     // diagnostic: 1 = stop after the vertex loads, 2 = after the footprints
+    int spread;                    // big meshes: a wave takes its triangles in runs spread over the whole mesh (balances the cells per
+                                   // wave: shorter kernel) instead of one contiguous run (fewer cache lines: better with frames overlapping)
 };
 
 // one geometry as uploaded (xform = 1: vertices still need A / Rinv / t) or the committed scene
@@ -100,6 +102,11 @@ struct GeomSource {
     uint32_t gid_first;            // global triangle id of triangle 0
     int xform;                     // 0: verts already in the sensor frame, 1: full transform, 2: A is the identity
     Affine m;
+    // group culling (meshes large enough for 64 triangles per wave): idx is then the library's Morton-ordered
+    // copy of the indices, perm[k] the original triangle of sorted position k, boxes[2g], boxes[2g+1] the
+    // mesh-space sheared-box bound of sorted triangles [kCullGroup g, kCullGroup (g+1)).  nullptr: no culling.
+    const uint32_t *perm;
+    const float4 *boxes;
 };
 
 // the geometries of one k_project launch (kernel argument: no upload)
@@ -108,8 +115,20 @@ struct GeomBatch {
     uint32_t n;
     uint32_t block_first[kGeomsPerLaunch + 1];   // first workgroup of geometry i; [n] = grid size
     uint32_t tris_per_wave[kGeomsPerLaunch];     // 64, or less for a small mesh
+    uint32_t list_first[kGeomsPerLaunch + 1];    // group culling: first entry of geometry i in the survivor list (multiples of 256)
     GeomSource g[kGeomsPerLaunch];
 };
+
+// group culling (ls_project.hip): sorted triangles are bounded and culled in groups of kCullGroup; the per-geometry
+// survivor counts of a frame live at words [kCullCountAt, kCullCountAt + kGeomsPerLaunch) of its counter slot, whose
+// word 0 is the length of the big-footprint queue; a slot is kCounterSlotWords words
+#ifndef LS_CULL_GROUP
+#define LS_CULL_GROUP 4
+#endif
+constexpr uint32_t kCullGroup = LS_CULL_GROUP;
+constexpr uint32_t kCullCountAt = 16;
+constexpr uint32_t kCounterSlotWords = 32;
+static_assert(64 % LS_CULL_GROUP == 0, "a wave takes a whole number of groups");
 
 // ---- build ---------------------------------------------------------------------------------
 void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t n, const float *affine12,
@@ -165,9 +184,21 @@ struct FinishPackArgs {
     uint32_t n_blocks;              // ceil(rays / 256)
     uint32_t compact;               // points as 16-byte (x, y, z, ring) records (LS_OPT_HOST_OUTPUT = 2)
 };
+// cull_list (nullable): room for project_cull_entries() words; the groups that survive k_cull are appended there per
+// geometry (counts in big_count[kCullCountAt + i], re-armed wherever big_count[0] is) and the waves of the culled
+// geometries' k_project launch take 64 / kCullGroup of them each.  Geometries without bounds go in a launch of their own.
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
                     void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats,
-                    const FinishPackArgs *rider = nullptr);
+                    const FinishPackArgs *rider = nullptr, uint32_t *cull_list = nullptr);
+uint32_t project_tris_per_wave(uint32_t ntris);   // 64 for big meshes, fewer for small ones (more waves than ntris / 64)
+uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs);   // survivor-list words for the geometries with bounds (0: none, or too many for one launch)
+// one-off per topology: Morton order of the triangles (centroids in mesh space) -> perm (sorted position -> triangle),
+// idx_sorted; scratch: keys_a/keys_b/vals_a (ntris words each), aabb (6 words), sort temp
+void launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,
+                       uint32_t *aabb6, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, void *sort_temp, size_t sort_temp_bytes,
+                       uint32_t *perm, uint32_t *idx_sorted);
+// per vertex upload: mesh-space sheared-box bound of every kCullGroup sorted triangles (2 float4 per group)
+void launch_group_bounds(hipStream_t s, const uint8_t *verts, uint32_t stride, const uint32_t *idx_sorted, uint32_t ntris, float4 *boxes);
 void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats);
 // per ray: gather the queued big-footprint triangles, then hits per 256-ray block
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,

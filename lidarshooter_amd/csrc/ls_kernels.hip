@@ -493,7 +493,8 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     }
     if (FROM_KEYS) {
         if (threadIdx.x == 0) next_block_counts[blockIdx.x] = 0u;
-        if (q == 0) *big_count = 0u;
+        if (q == 0) big_count[0] = 0u;                                             // queue length
+        if (q < (uint32_t)kGeomsPerLaunch) big_count[kCullCountAt + q] = 0u;        // group-cull survivor counts
     }
     const bool hit = gid != kInvalid;
     const unsigned long long m = __ballot(hit);

@@ -67,6 +67,31 @@ struct ChanTables {
 // The footprint is computed in two steps: band() (elevation -> channel range; run for every triangle --
 // most triangles of a large scene fall between two channels and end there) and columns() (azimuth ->
 // column intervals; only for the survivors).
+// channels whose elevation (widened by the angular margin) can meet points with z in [zmin, zmax] at horizontal
+// distance in [rho_min, rho_max] from the vertical axis (rho_max already carries its 1e-4 slack, rho_min its own)
+__device__ __forceinline__ void band_from_ranges(const ProjectParams &pp, const ChanTables &ct, float zmin, float zmax, float rho_min,
+                                                 float rho_max, uint32_t &i0_out, uint32_t &nch_out)
+{
+    float tan_lo = -INFINITY, tan_hi = INFINITY;
+    if (rho_max > 0.0f) {
+        // quotients rounded outwards by 1e-5 relative (the reciprocal is good to 1 ulp)
+        const float inv_max = fast_rcp(rho_max), inv_min = rho_min > 0.0f ? fast_rcp(rho_min) : 0.0f;
+        if (zmin >= 0.0f) tan_lo = zmin * inv_max * 0.99999f;
+        else if (rho_min > 0.0f) tan_lo = zmin * inv_min * 1.00001f;
+        if (zmax <= 0.0f) tan_hi = zmax * inv_max * 0.99999f;
+        else if (rho_min > 0.0f) tan_hi = zmax * inv_min * 1.00001f;
+    }
+    // channels whose elevation (widened by the angular margin) meets the band: chan_tan_up[i] =
+    // tan(chi_i + margin), chan_tan_dn[i] = tan(chi_i - margin), both ascending
+    uint32_t lo = 0, hi = pp.tb.V;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (ct.tan_up[m] < tan_lo) lo = m + 1; else hi = m; }
+    const uint32_t i0 = lo;
+    uint32_t i1 = i0;  // bands are narrow: walk forward instead of a second search
+    while (i1 < pp.tb.V && ct.tan_dn[i1] <= tan_hi) ++i1;
+    i0_out = i0;
+    nch_out = i1 > i0 ? i1 - i0 : 0u;
+}
+
 __device__ __forceinline__ void band(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 v1, V3 v2, uint32_t &i0_out,
                                      uint32_t &nch_out)
 {
@@ -86,24 +111,7 @@ __device__ __forceinline__ void band(const ProjectParams &pp, const ChanTables &
         // 1e-4 relative for the reciprocal square root and |u|, 1e-6 rho_max absolute for the rounding of the dots
         rho_min = fmaxf(fminf(p0, fminf(p1, p2)) * __builtin_amdgcn_rsqf(cc) * 0.9999f - 1e-6f * rho_max, 0.0f);
     }
-    float tan_lo = -INFINITY, tan_hi = INFINITY;
-    if (rho_max > 0.0f) {
-        // quotients rounded outwards by 1e-5 relative (the reciprocal is good to 1 ulp)
-        const float inv_max = fast_rcp(rho_max), inv_min = rho_min > 0.0f ? fast_rcp(rho_min) : 0.0f;
-        if (zmin >= 0.0f) tan_lo = zmin * inv_max * 0.99999f;
-        else if (rho_min > 0.0f) tan_lo = zmin * inv_min * 1.00001f;
-        if (zmax <= 0.0f) tan_hi = zmax * inv_max * 0.99999f;
-        else if (rho_min > 0.0f) tan_hi = zmax * inv_min * 1.00001f;
-    }
-    // channels whose elevation (widened by the angular margin) meets the band: chan_tan_up[i] =
-    // tan(chi_i + margin), chan_tan_dn[i] = tan(chi_i - margin), both ascending
-    uint32_t lo = 0, hi = pp.tb.V;
-    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (ct.tan_up[m] < tan_lo) lo = m + 1; else hi = m; }
-    const uint32_t i0 = lo;
-    uint32_t i1 = i0;  // bands are narrow: walk forward instead of a second search
-    while (i1 < pp.tb.V && ct.tan_dn[i1] <= tan_hi) ++i1;
-    i0_out = i0;
-    nch_out = i1 > i0 ? i1 - i0 : 0u;
+    band_from_ranges(pp, ct, zmin, zmax, rho_min, rho_max, i0_out, nch_out);
 }
 
 __device__ __forceinline__ void columns(const ProjectParams &pp, V3 v0, V3 v1, V3 v2, uint32_t &h0a, uint32_t &na, uint32_t &h0b,
@@ -272,12 +280,12 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <bool COUNT, bool LDS_TABLES, bool MULTI>
+template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
 __device__ __forceinline__ void project_body(const ProjectParams &pp, const GeomBatch &batch, uint32_t block_idx, ProjectLds &lds,
                                              float *s_chan /* LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm */,
                                              unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                              uint32_t big_capacity, uint32_t *__restrict__ big_count,
-                                             unsigned long long *__restrict__ stats)
+                                             unsigned long long *__restrict__ stats, const uint32_t *__restrict__ cull_list)
 {
     auto &s_tri = lds.tri;
     auto &s_meta = lds.meta;
@@ -288,11 +296,16 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     if (MULTI)
         while (gi + 1u < batch.n && block_idx >= batch.block_first[gi + 1u]) ++gi;
     const GeomSource &src = batch.g[gi];
-    // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
-    // join the cell tests): its footprints are large, and the cells are what takes the time
-    const uint32_t tris_per_wave = batch.tris_per_wave[gi];
     const uint32_t block = MULTI ? block_idx - batch.block_first[gi] : block_idx;
-    const uint32_t k = lane < tris_per_wave ? (block * (kBlock / 64) + w) * tris_per_wave + lane : 0xFFFFFFFFu;
+    // CULLED: the groups of kCullGroup sorted triangles that survived k_cull sit packed at the front of this geometry's
+    // part of cull_list (count in big_count[kCullCountAt + gi]); a wave takes 64 / kCullGroup of them, so its lanes
+    // are dense; workgroups behind the survivors have nothing to do
+    constexpr uint32_t kPerWave = 64u / kCullGroup;
+    uint32_t n_live = 0;
+    if (CULLED) {
+        n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)big_count[kCullCountAt + gi]);
+        if (block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
+    }
     ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
     if (LDS_TABLES) {
         const uint32_t V = pp.tb.V;
@@ -305,6 +318,30 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         }
         ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V)};
         __syncthreads();
+    }
+    uint32_t k = 0xFFFFFFFFu;
+    if (CULLED) {
+        const uint32_t rank = block * (kBlock / 64) + w;   // this wave among the geometry's waves
+        if (COUNT && rank == 0 && lane == 0) atomicAdd(&stats[1], (unsigned long long)n_live);   // counts[2]: surviving groups
+        if (rank * kPerWave >= n_live) return;             // the survivors' last, partly filled workgroup (no barrier follows)
+        // a wave's groups are taken at a stride of the number of live waves: the survivors list is in mesh order, and the
+        // cells a group expands to vary by orders of magnitude with its distance from the sensor -- consecutive groups
+        // would make a few waves next to the sensor walk ten times the cells of the others (and the kernel wait for them)
+        const uint32_t live_waves = (n_live + kPerWave - 1u) / kPerWave;
+        const uint32_t e = pp.spread ? (lane / kCullGroup) * live_waves + rank : rank * kPerWave + lane / kCullGroup;
+        if (e < n_live) k = cull_list[batch.list_first[gi] + e] * kCullGroup + (lane % kCullGroup);
+    } else {
+        // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
+        // join the cell tests): its footprints are large, and the cells are what takes the time
+        const uint32_t tris_per_wave = batch.tris_per_wave[gi];
+        if (tris_per_wave == 64u && pp.spread) {
+            // big mesh: eight runs of eight triangles, a stride of the wave count apart (same reason as above: a wave's
+            // share of the near field, where the cells are, is then the same for every wave)
+            const uint32_t n_waves = (src.ntris + 63u) / 64u;
+            k = ((lane >> 3) * n_waves + (block * (kBlock / 64) + w)) * 8u + (lane & 7u);
+        } else if (lane < tris_per_wave) {
+            k = (block * (kBlock / 64) + w) * tris_per_wave + lane;
+        }
     }
     uint32_t cells = 0, slot = 0;
     if (k < src.ntris) {
@@ -343,7 +380,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         if (cells) {
             const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
             const float NgC = dot_fma(cross_fma(e2, e1), v0);
-            const uint32_t gid = src.gid_first + k;
+            const uint32_t gid = src.gid_first + (src.perm ? src.perm[k] : k);   // perm: Morton-sorted position -> triangle
             bool queued = false;
             if (cells > pp.big_cells) {
                 const uint32_t slot = atomicAdd(big_count, 1u);
@@ -406,15 +443,303 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
 }
 
-template <bool COUNT, bool LDS_TABLES, bool MULTI>
+template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_project(ProjectParams pp, GeomBatch batch,
                                                     unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                                     uint32_t big_capacity, uint32_t *__restrict__ big_count,
-                                                    unsigned long long *__restrict__ stats)
+                                                    unsigned long long *__restrict__ stats, const uint32_t *__restrict__ cull_list)
 {
     __shared__ ProjectLds lds;
     extern __shared__ float s_chan[];
-    project_body<COUNT, LDS_TABLES, MULTI>(pp, batch, blockIdx.x, lds, s_chan, best, big, big_capacity, big_count, stats);
+    project_body<COUNT, LDS_TABLES, MULTI, CULLED>(pp, batch, blockIdx.x, lds, s_chan, best, big, big_capacity, big_count, stats, cull_list);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Group culling.  A mesh large enough for 64 triangles per wave is kept in Morton order (centroids in mesh space;
+// one-off per topology: k_mesh_aabb, k_mesh_morton, radix sort, k_permute_indices) together with a bound for every
+// kCullGroup consecutive sorted triangles (k_group_bounds, once per vertex upload, 32 bytes per group): a sheared
+// box  { c + a e1 + b e2 + g e3 : |a|,|b|,|g| <= 1 },  e1 = (hx, 0, sx hx), e2 = (0, hy, sy hy), e3 = (0, 0, hz),
+// i.e. the footprint rectangle of the group, tilted along its least-squares plane, hz thick.  Per frame k_cull --
+// one lane per group -- carries centre and edges into the sensor frame with THIS frame's matrix and bounds
+// tan(elevation) = z / rho over the box by its value at the centre +- (first-order variation along the three
+// edges + a bound of the second-order remainder); the group is kept only if some channel (angular margin
+// included) lies inside, and, for an azimuth shard, if the box reaches into the shard's sector.  Survivors are
+// appended to a per-geometry list; k_project<CULLED> takes 64 / kCullGroup of them per wave, so its lanes are dense.
+// On the headline frame 57 % of the groups of 4 fall between two rings (a patch of ground 40 m away subtends a
+// fifth of the channel spacing); an 8-way azimuth shard keeps an eighth of the rest.
+// The bound is evaluated in float with explicit slack (1e-5 relative + the channel tables' 0.005 degrees).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ordered_bits(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // unsigned order == float order
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// aabb6: lo.xyz as ordered bits (initialised to 0xFFFFFFFF), hi.xyz (initialised to 0)
+__global__ __launch_bounds__(kBlock) void k_mesh_aabb(const uint8_t *__restrict__ verts, uint32_t stride, uint32_t nverts,
+                                                      uint32_t *__restrict__ aabb6)
+{
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < nverts; j += gridDim.x * kBlock) {
+        const float *p = reinterpret_cast<const float *>(verts + (size_t)j * stride);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+    }
+    // six atomics per workgroup, at most 256 workgroups (a hot address sustains ~90 atomics per microsecond)
+    __shared__ float s_red[6][kBlock / 64];
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_red[a][threadIdx.x >> 6] = lo[a]; s_red[3 + a][threadIdx.x >> 6] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = (int)threadIdx.x;
+        const float l = fminf(fminf(s_red[a][0], s_red[a][1]), fminf(s_red[a][2], s_red[a][3]));
+        const float h = fmaxf(fmaxf(s_red[3 + a][0], s_red[3 + a][1]), fmaxf(s_red[3 + a][2], s_red[3 + a][3]));
+        if (l <= h) { atomicMin(&aabb6[a], ordered_bits(l)); atomicMax(&aabb6[3 + a], ordered_bits(h)); }
+    }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// 30-bit Morton key of the triangle's centroid inside the mesh's bounding cube
+__global__ __launch_bounds__(kBlock) void k_mesh_morton(const uint8_t *__restrict__ verts, uint32_t stride, const uint32_t *__restrict__ idx,
+                                                        uint32_t ntris, const uint32_t *__restrict__ aabb6, uint32_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ vals)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ntris) return;
+    const float *a = reinterpret_cast<const float *>(verts + (size_t)idx[3 * (size_t)k + 0] * stride);
+    const float *b = reinterpret_cast<const float *>(verts + (size_t)idx[3 * (size_t)k + 1] * stride);
+    const float *c = reinterpret_cast<const float *>(verts + (size_t)idx[3 * (size_t)k + 2] * stride);
+    uint32_t key = 0;
+    // one scale for the three axes (the largest extent): a flat mesh must not spend a third of its key bits on the
+    // noise of its thin direction
+    float ext = 0.0f;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) ext = fmaxf(ext, from_ordered_bits(aabb6[3 + ax]) - from_ordered_bits(aabb6[ax]));
+    const float scale = ext > 0.0f ? 1024.0f / ext : 0.0f;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float lo = from_ordered_bits(aabb6[ax]);
+        const float cen = (a[ax] + b[ax] + c[ax]) * (1.0f / 3.0f);
+        const uint32_t q = (uint32_t)fminf(fmaxf((cen - lo) * scale, 0.0f), 1023.0f);
+        key |= spread10(q) << ax;
+    }
+    keys[k] = key;
+    vals[k] = k;
+}
+
+__global__ __launch_bounds__(kBlock) void k_permute_indices(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ perm,
+                                                            uint32_t ntris, uint32_t *__restrict__ out)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ntris) return;
+    const uint32_t t = perm[k];
+    out[3 * (size_t)k + 0] = idx[3 * (size_t)t + 0];
+    out[3 * (size_t)k + 1] = idx[3 * (size_t)t + 1];
+    out[3 * (size_t)k + 2] = idx[3 * (size_t)t + 2];
+}
+
+// one lane per group of kCullGroup sorted triangles: bounds[2g] = (cx, cy, cz, hx), bounds[2g+1] = (hy, hz, sx, sy)
+__global__ __launch_bounds__(kBlock) void k_group_bounds(const uint8_t *__restrict__ verts, uint32_t stride,
+                                                         const uint32_t *__restrict__ idx_sorted, uint32_t ntris, float4 *__restrict__ bounds)
+{
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t first = g * kCullGroup;
+    if (first >= ntris) return;
+    const uint32_t n = min(kCullGroup, ntris - first) * 3u;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t j = 0; j < n; ++j) {
+        const float *p = reinterpret_cast<const float *>(verts + (size_t)idx_sorted[3 * (size_t)first + j] * stride);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+    }
+    if (!(lo[0] <= hi[0]) || !(lo[1] <= hi[1]) || !(lo[2] <= hi[2]) || !(hi[0] - lo[0] < INFINITY) || !(hi[1] - lo[1] < INFINITY) ||
+        !(hi[2] - lo[2] < INFINITY)) {
+        // NaN / infinite coordinates: a bound that k_cull never rejects
+        bounds[2 * (size_t)g] = make_float4(0.f, 0.f, 0.f, INFINITY);
+        bounds[2 * (size_t)g + 1] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+        return;
+    }
+    const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+    // least-squares plane z = cz + sx (x - cx) + sy (y - cy) through the vertices (any slopes give a valid bound: the
+    // thickness below is measured against whatever plane is chosen)
+    float sxx = 0.f, syy = 0.f, sxy = 0.f, sxz = 0.f, syz = 0.f;
+    for (uint32_t j = 0; j < n; ++j) {
+        const float *p = reinterpret_cast<const float *>(verts + (size_t)idx_sorted[3 * (size_t)first + j] * stride);
+        const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+        sxx += dx * dx; syy += dy * dy; sxy += dx * dy; sxz += dx * dz; syz += dy * dz;
+    }
+    const float det = sxx * syy - sxy * sxy;
+    float sx = 0.f, sy = 0.f;
+    if (det > 1e-6f * (sxx + syy) * (sxx + syy) && det > 0.f) {
+        sx = (sxz * syy - syz * sxy) / det;
+        sy = (syz * sxx - sxz * sxy) / det;
+        if (!(fabsf(sx) <= 8.f) || !(fabsf(sy) <= 8.f)) sx = sy = 0.f;   // a wall: plain axis-aligned box
+    }
+    float rmin = INFINITY, rmax = -INFINITY;
+    for (uint32_t j = 0; j < n; ++j) {
+        const float *p = reinterpret_cast<const float *>(verts + (size_t)idx_sorted[3 * (size_t)first + j] * stride);
+        const float r = (p[2] - cz) - (sx * (p[0] - cx) + sy * (p[1] - cy));
+        rmin = fminf(rmin, r); rmax = fmaxf(rmax, r);
+    }
+    // half extents rounded outwards: the residuals above carry a few ulps of |z| and of sx*dx
+    const float zc = cz + 0.5f * (rmin + rmax);
+    const float scale_ulps = 4e-7f * (fabsf(cz) + fabsf(lo[2]) + fabsf(hi[2]) + (fabsf(sx) * (hi[0] - lo[0]) + fabsf(sy) * (hi[1] - lo[1])));
+    const float hx = 0.5f * (hi[0] - lo[0]) * 1.000001f + 1e-7f * (fabsf(lo[0]) + fabsf(hi[0]));
+    const float hy = 0.5f * (hi[1] - lo[1]) * 1.000001f + 1e-7f * (fabsf(lo[1]) + fabsf(hi[1]));
+    const float hz = 0.5f * (rmax - rmin) * 1.000001f + scale_ulps;
+    bounds[2 * (size_t)g] = make_float4(cx, cy, zc, hx);
+    bounds[2 * (size_t)g + 1] = make_float4(hy, hz, sx, sy);
+}
+
+// linear part L = Rinv * A and offset o = Rinv * (A.t - t) of the vertex transform p' = Rinv ((A v) - t), per geometry
+struct LinearMap { float l[9], o[3]; };
+
+__device__ __forceinline__ LinearMap linear_map(const GeomSource &src)
+{
+    LinearMap m;
+    if (src.xform == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m.l[i] = (i % 4 == 0) ? 1.f : 0.f;
+        m.o[0] = m.o[1] = m.o[2] = 0.f;
+        return m;
+    }
+    const Affine &a = src.m;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            m.l[3 * i + j] = a.rinv[3 * i] * a.a[j] + a.rinv[3 * i + 1] * a.a[4 + j] + a.rinv[3 * i + 2] * a.a[8 + j];
+        m.o[i] = a.rinv[3 * i] * (a.a[3] - a.t[0]) + a.rinv[3 * i + 1] * (a.a[7] - a.t[1]) + a.rinv[3 * i + 2] * (a.a[11] - a.t[2]);
+    }
+    return m;
+}
+
+// can any ray of this handle's raster meet the sheared box (centre, hx | hy, hz, sx, sy) of a group?
+__device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, const ChanTables &ct, const LinearMap &m, float4 b0, float4 b1)
+{
+    const float hx = b0.w, hy = b1.x, hz = b1.y, sx = b1.z, sy = b1.w;
+    if (!(hx < INFINITY)) return true;
+    // centre and edge vectors in the sensor frame
+    float c[3], e1[3], e2[3], e3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        c[i] = (m.l[3 * i] * b0.x + m.l[3 * i + 1] * b0.y) + (m.l[3 * i + 2] * b0.z + m.o[i]);
+        e1[i] = hx * (m.l[3 * i] + sx * m.l[3 * i + 2]);
+        e2[i] = hy * (m.l[3 * i + 1] + sy * m.l[3 * i + 2]);
+        e3[i] = hz * m.l[3 * i + 2];
+    }
+    const float rho2 = c[0] * c[0] + c[1] * c[1];
+    if (!(rho2 > 1e-12f) || !(rho2 < INFINITY)) return true;
+    const float inv_rho = __builtin_amdgcn_rsqf(rho2), rho = rho2 * inv_rho;
+    const float ux = c[0] * inv_rho, uy = c[1] * inv_rho;   // radial unit vector (1 ulp-ish: enters only bounds with slack)
+    // radial / tangential / vertical half extents
+    const float r1 = e1[0] * ux + e1[1] * uy, r2 = e2[0] * ux + e2[1] * uy, r3 = e3[0] * ux + e3[1] * uy;
+    const float t1 = e1[1] * ux - e1[0] * uy, t2 = e2[1] * ux - e2[0] * uy, t3 = e3[1] * ux - e3[0] * uy;
+    const float er = fabsf(r1) + fabsf(r2) + fabsf(r3), et = fabsf(t1) + fabsf(t2) + fabsf(t3);
+    const float ez = fabsf(e1[2]) + fabsf(e2[2]) + fabsf(e3[2]);
+    if (pp.sector_on) {
+        // the box lies inside the disc of radius er + et around its centre (seen from above): outside a boundary plane of
+        // the shard's sector if the centre is further out than that
+        const float reach = (er + et) * 1.0001f + 1e-6f * rho;
+        if (pp.sec_a[0] * c[1] - pp.sec_a[1] * c[0] < -reach) return false;
+        if (c[0] * pp.sec_b[1] - c[1] * pp.sec_b[0] < -reach) return false;
+    }
+    const float eps = (er + et) * inv_rho;
+    if (!(eps < 0.25f)) return true;   // next to the vertical axis: no first-order bound
+    // f = z / rho;  f(c + d) = f(c) + dz / rho - z dr / rho^2 + R,  |R| <= (ez eps + (|z| + ez) 2 eps^2) / rho  for eps < 1/4
+    const float fc = c[2] * inv_rho, k = c[2] * inv_rho * inv_rho;
+    const float w = fabsf(e1[2] * inv_rho - k * r1) + fabsf(e2[2] * inv_rho - k * r2) + fabsf(e3[2] * inv_rho - k * r3);
+    const float rem = (ez * eps + (fabsf(c[2]) + ez) * 2.0f * eps * eps) * inv_rho;
+    const float half = (w + rem) * 1.0001f + 2e-6f * (fabsf(fc) + 1e-3f);   // rounding of the dozen products above
+    const float tan_lo = fc - half, tan_hi = fc + half;
+    uint32_t lo_i = 0, hi_i = pp.tb.V;
+    while (lo_i < hi_i) { const uint32_t mid = (lo_i + hi_i) >> 1; if (ct.tan_up[mid] < tan_lo) lo_i = mid + 1; else hi_i = mid; }
+    return lo_i < pp.tb.V && ct.tan_dn[lo_i] <= tan_hi;
+}
+
+// kCullPerBlock groups per workgroup (one lane per group, four rounds); every geometry's groups start at a multiple of
+// kCullPerBlock in the numbering (batch.list_first), so a workgroup belongs to one geometry.  Survivors are collected
+// in LDS and appended to the geometry's list with ONE global atomic per workgroup (a hot address sustains ~90 atomics
+// per microsecond: one per wave of a million-triangle mesh would take 40 us).
+constexpr uint32_t kCullPerBlock = 1024;
+
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, GeomBatch batch, uint32_t *__restrict__ list, uint32_t *__restrict__ counts)
+{
+    extern __shared__ float s_tan[];   // LDS_TABLES: tan_up[V], tan_dn[V]
+    __shared__ uint32_t s_keep[kCullPerBlock];
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t first = blockIdx.x * kCullPerBlock;
+    uint32_t gi = 0;
+    while (gi + 1u < batch.n && first >= batch.list_first[gi + 1u]) ++gi;
+    const GeomSource &src = batch.g[gi];
+    const uint32_t g0 = first - batch.list_first[gi];
+    // the four rounds are independent: all eight bound loads go out first (before the channel tables are staged: the
+    // two waits overlap), then four dependency chains interleave -- one workgroup per CU leaves nothing else to hide
+    // their latency behind
+    constexpr uint32_t kRounds = kCullPerBlock / kBlock;
+    float4 b0[kRounds], b1[kRounds];
+    const uint32_t n_groups = (src.ntris + kCullGroup - 1u) / kCullGroup;
+#pragma unroll
+    for (uint32_t it = 0; it < kRounds; ++it) {
+        const uint32_t g = min(g0 + it * kBlock + threadIdx.x, n_groups - 1u);
+        b0[it] = src.boxes[2 * (size_t)g];
+        b1[it] = src.boxes[2 * (size_t)g + 1];
+    }
+    ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
+    if (threadIdx.x == 0) s_n = 0;
+    if (LDS_TABLES) {
+        const uint32_t V = pp.tb.V;
+        for (uint32_t i = threadIdx.x; i < V; i += kBlock) { s_tan[i] = pp.chan_tan_up[i]; s_tan[V + i] = pp.chan_tan_dn[i]; }
+        ct.tan_up = s_tan;
+        ct.tan_dn = s_tan + V;
+    }
+    __syncthreads();
+    const LinearMap m = linear_map(src);
+    bool keeps[kRounds];
+#pragma unroll
+    for (uint32_t it = 0; it < kRounds; ++it)
+        keeps[it] = g0 + it * kBlock + threadIdx.x < n_groups && group_meets_raster(pp, ct, m, b0[it], b1[it]);
+#pragma unroll
+    for (uint32_t it = 0; it < kRounds; ++it) {
+        const uint32_t g = g0 + it * kBlock + threadIdx.x;
+        const bool keep = keeps[it];
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {   // uniform over the wave
+            uint32_t at = 0;
+            if ((threadIdx.x & 63u) == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (keep) s_keep[at + lanes_below(mask)] = g;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (!n) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&counts[gi], n);
+    __syncthreads();
+    uint32_t *out = list + batch.list_first[gi] + s_base;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) out[i] = s_keep[i];
 }
 
 // Finish pass, one thread per ray: (1) triangles whose footprint was too large for one wave were
@@ -601,9 +926,11 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
     __syncthreads();
     const uint32_t mine = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0)
         __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)fa.publish_epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (block_idx == 0) *fa.rearm_big_count = 0u;   // the queue counter of the frame after the next: nobody reads it now
+    if (block_idx == 0) {   // the queue / survivor counters of the frame after the next: nobody reads them now
+        if (threadIdx.x == 0) fa.rearm_big_count[0] = 0u;
+        if (threadIdx.x < (uint32_t)kGeomsPerLaunch) fa.rearm_big_count[kCullCountAt + threadIdx.x] = 0u;
     }
     // hits of all workgroups before this one.  Waiting is rare (every workgroup publishes within a few
     // microseconds of its neighbours unless the queue gather is heavy) and must stay cheap for the ones
@@ -669,10 +996,11 @@ __global__ __launch_bounds__(kBlock) void k_finish_pack(ProjectParams pp, Finish
 // One launch per frame: the workgroups of this frame's k_project and, from workgroup fp_start on, those
 // of the previous frame's finish + pack (contiguous and in order, as their chained prefix needs).
 // (at most 80 SGPRs: one more and a CU admits 7 of these workgroups instead of 8, MI355X_MICROARCH.md "Residency")
-template <bool LDS_TABLES, bool MULTI>
+template <bool LDS_TABLES, bool MULTI, bool CULLED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_frame(ProjectParams pp, GeomBatch batch, uint32_t fp_start,
                                                   unsigned long long *__restrict__ best, BigItem *__restrict__ big,
-                                                  uint32_t big_capacity, uint32_t *__restrict__ big_count, FinishPackArgs fa)
+                                                  uint32_t big_capacity, uint32_t *__restrict__ big_count, FinishPackArgs fa,
+                                                  const uint32_t *__restrict__ cull_list)
 {
     __shared__ ProjectLds lds;
     extern __shared__ float s_chan[];
@@ -680,8 +1008,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k
     if (rel < fa.n_blocks)
         finish_pack_body<false>(pp, fa, rel, reinterpret_cast<uint32_t *>(&lds), nullptr);
     else
-        project_body<false, LDS_TABLES, MULTI>(pp, batch, blockIdx.x < fp_start ? blockIdx.x : blockIdx.x - fa.n_blocks, lds, s_chan, best,
-                                               big, big_capacity, big_count, nullptr);
+        project_body<false, LDS_TABLES, MULTI, CULLED>(pp, batch, blockIdx.x < fp_start ? blockIdx.x : blockIdx.x - fa.n_blocks, lds, s_chan, best,
+                                               big, big_capacity, big_count, nullptr, cull_list);
 }
 
 }  // namespace
@@ -709,20 +1037,111 @@ void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long l
     const uint32_t nq = pp.tb.V * pp.tb.naz;
     if (!nq) return;
     (void)hipMemsetAsync(best, 0xFF, (size_t)nq * sizeof(unsigned long long), s);
-    (void)hipMemsetAsync(big_count, 0, sizeof(uint32_t), s);
+    (void)hipMemsetAsync(big_count, 0, 4 * kCounterSlotWords * sizeof(uint32_t), s);   // every slot's queue length and survivor counts (only ever called with nothing in flight)
     (void)hipMemsetAsync(block_counts2, 0, 2 * (size_t)((nq + kBlock - 1) / kBlock) * sizeof(uint32_t), s);
 }
 
+namespace {
+uint32_t min_tpw() { static const uint32_t v = getenv("LS_PROJECT_MIN_TPW") ? (uint32_t)std::max(1, atoi(getenv("LS_PROJECT_MIN_TPW"))) : 1u; return v; }
+uint32_t tpw_waves() { static const uint32_t v = getenv("LS_PROJECT_TPW_WAVES") ? (uint32_t)atoi(getenv("LS_PROJECT_TPW_WAVES")) : 8192u; return v; }
+
+}  // namespace
+
+// 64 triangles per wave when that still gives every SIMD a few waves; fewer for small meshes
+uint32_t project_tris_per_wave(uint32_t ntris)
+{
+    uint32_t tpw = 64u;
+    while (tpw > min_tpw() && (ntris + tpw - 1u) / tpw < tpw_waves()) tpw >>= 1;
+    return tpw;
+}
+
+namespace {
+// the geometries that carry group bounds, as one batch: false if there are none or more than a launch takes
+bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch, uint32_t &blocks, uint32_t &entries)
+{
+    batch.n = 0;
+    blocks = entries = 0;
+    for (uint32_t i = 0; i < n_srcs; ++i) {
+        const GeomSource &src = srcs[i];
+        if (!src.boxes || !src.ntris) continue;
+        if (batch.n == (uint32_t)kGeomsPerLaunch) return false;
+        batch.block_first[batch.n] = blocks;
+        batch.tris_per_wave[batch.n] = 64u;
+        batch.list_first[batch.n] = entries;
+        batch.g[batch.n] = src;
+        blocks += (src.ntris + kBlock - 1) / kBlock;                       // worst case: every group survives
+        const uint32_t groups = (src.ntris + kCullGroup - 1) / kCullGroup;
+        entries += (groups + kCullPerBlock - 1) / kCullPerBlock * kCullPerBlock;   // a k_cull workgroup belongs to one geometry
+        ++batch.n;
+    }
+    batch.block_first[batch.n] = blocks;
+    batch.list_first[batch.n] = entries;
+    return batch.n > 0;
+}
+}  // namespace
+
+uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs)
+{
+    GeomBatch batch;
+    uint32_t blocks, entries;
+    return fill_culled_batch(srcs, n_srcs, batch, blocks, entries) ? entries : 0u;
+}
+
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
-                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats, const FinishPackArgs *rider)
+                    void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats, const FinishPackArgs *rider,
+                    uint32_t *cull_list)
 {
     if (!(pp.tb.V * pp.tb.naz)) return;
-    // 64 triangles per wave when that still gives every SIMD a few waves; fewer for small meshes
-    static const uint32_t min_tpw = getenv("LS_PROJECT_MIN_TPW") ? (uint32_t)std::max(1, atoi(getenv("LS_PROJECT_MIN_TPW"))) : 1u;
-    static const uint32_t tpw_waves = getenv("LS_PROJECT_TPW_WAVES") ? (uint32_t)atoi(getenv("LS_PROJECT_TPW_WAVES")) : 8192u;
     static const int fp_at = getenv("LS_PROJECT_FP_AT") ? atoi(getenv("LS_PROJECT_FP_AT")) : -1;
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
+    const bool lt = pp.tb.V <= 2048u;   // channel tables fit in LDS (40 KB at most)
+
+    // one launch over `batch` (the previous frame's finish + pack workgroups ride in the first launch of the frame)
+    auto launch = [&](const GeomBatch &batch, uint32_t blocks, const uint32_t *list) {
+        const bool multi = batch.n > 1, culled = list != nullptr;
+        if (rider && !stats) {
+            const dim3 grid(blocks + rider->n_blocks);
+            // where the riders sit in the grid: behind the triangle workgroups by default (they fill the tail)
+            const uint32_t fp_start = fp_at < 0 ? blocks : std::min((uint32_t)fp_at, blocks);
+#define LS_FRAME(L, M, C) hipLaunchKernelGGL((k_frame<L, M, C>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, fp_start, best, bq, big_capacity, big_count, *rider, list)
+#define LS_FRAME_C(L, M) do { if (culled) LS_FRAME(L, M, true); else LS_FRAME(L, M, false); } while (0)
+            if (lt) { if (multi) LS_FRAME_C(true, true); else LS_FRAME_C(true, false); }
+            else { if (multi) LS_FRAME_C(false, true); else LS_FRAME_C(false, false); }
+#undef LS_FRAME_C
+#undef LS_FRAME
+            rider = nullptr;
+            return;
+        }
+        const dim3 grid(blocks);
+#define LS_LAUNCH(C, L, M, K) hipLaunchKernelGGL((k_project<C, L, M, K>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, best, bq, big_capacity, big_count, stats, list)
+#define LS_LAUNCH_K(C, L, M) do { if (culled) LS_LAUNCH(C, L, M, true); else LS_LAUNCH(C, L, M, false); } while (0)
+        if (lt) {
+            if (stats) { if (multi) LS_LAUNCH_K(true, true, true); else LS_LAUNCH_K(true, true, false); }
+            else { if (multi) LS_LAUNCH_K(false, true, true); else LS_LAUNCH_K(false, true, false); }
+        } else {
+            if (stats) { if (multi) LS_LAUNCH_K(true, false, true); else LS_LAUNCH_K(true, false, false); }
+            else { if (multi) LS_LAUNCH_K(false, false, true); else LS_LAUNCH_K(false, false, false); }
+        }
+#undef LS_LAUNCH_K
+#undef LS_LAUNCH
+    };
+
+    // ---- geometries with group bounds: k_cull, then a launch whose waves read the survivors
+    bool culled_done = false;
+    if (cull_list) {
+        GeomBatch batch;
+        uint32_t blocks, entries;
+        if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries)) {
+            const dim3 cgrid(entries / kCullPerBlock);
+            const size_t clds = 2 * (size_t)pp.tb.V * sizeof(float);
+            if (lt) hipLaunchKernelGGL(k_cull<true>, cgrid, dim3(kBlock), clds, s, pp, batch, cull_list, big_count + kCullCountAt);
+            else hipLaunchKernelGGL(k_cull<false>, cgrid, dim3(kBlock), 0, s, pp, batch, cull_list, big_count + kCullCountAt);
+            launch(batch, blocks, cull_list);
+            culled_done = true;
+        }
+    }
+    // ---- the others (small meshes, or everything when culling is off): up to kGeomsPerLaunch per launch
     uint32_t at = 0;
     while (at < n_srcs) {
         GeomBatch batch;
@@ -730,44 +1149,43 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         uint32_t blocks = 0;
         for (; at < n_srcs && batch.n < (uint32_t)kGeomsPerLaunch; ++at) {
             const GeomSource &src = srcs[at];
-            if (!src.ntris) continue;
-            uint32_t tpw = 64u;
-            while (tpw > min_tpw && (src.ntris + tpw - 1u) / tpw < tpw_waves) tpw >>= 1;
+            if (!src.ntris || (culled_done && src.boxes)) continue;
+            const uint32_t tpw = project_tris_per_wave(src.ntris);
             const uint32_t per_block = tpw * (kBlock / 64);
             batch.block_first[batch.n] = blocks;
             batch.tris_per_wave[batch.n] = tpw;
+            batch.list_first[batch.n] = 0;
             batch.g[batch.n] = src;
             blocks += (src.ntris + per_block - 1) / per_block;
             ++batch.n;
         }
         if (!batch.n) break;
         batch.block_first[batch.n] = blocks;
-        const bool multi = batch.n > 1;
-        const bool lt = pp.tb.V <= 2048u;   // channel tables fit in LDS (40 KB at most)
-        if (rider && !stats) {
-            // the previous frame's finish + pack workgroups ride in this launch (the first one of the frame)
-            const dim3 grid(blocks + rider->n_blocks);
-            // where the riders sit in the grid: behind the triangle workgroups by default (they fill the tail)
-            const uint32_t fp_start = fp_at < 0 ? blocks : std::min((uint32_t)fp_at, blocks);
-#define LS_FRAME(L, M) hipLaunchKernelGGL((k_frame<L, M>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, fp_start, best, bq, big_capacity, big_count, *rider)
-            if (lt) { if (multi) LS_FRAME(true, true); else LS_FRAME(true, false); }
-            else { if (multi) LS_FRAME(false, true); else LS_FRAME(false, false); }
-#undef LS_FRAME
-            rider = nullptr;
-            continue;
-        }
-        const dim3 grid(blocks);
-#define LS_LAUNCH(C, L, M) hipLaunchKernelGGL((k_project<C, L, M>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, best, bq, big_capacity, big_count, stats)
-        if (lt) {
-            if (stats) { if (multi) LS_LAUNCH(true, true, true); else LS_LAUNCH(true, true, false); }
-            else { if (multi) LS_LAUNCH(false, true, true); else LS_LAUNCH(false, true, false); }
-        } else {
-            if (stats) { if (multi) LS_LAUNCH(true, false, true); else LS_LAUNCH(true, false, false); }
-            else { if (multi) LS_LAUNCH(false, false, true); else LS_LAUNCH(false, false, false); }
-        }
-#undef LS_LAUNCH
+        launch(batch, blocks, nullptr);
     }
     if (rider) launch_finish_pack(s, pp, *rider, stats);   // nothing was launched for it to ride with
+}
+
+void launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,
+                       uint32_t *aabb6, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, void *sort_temp, size_t sort_temp_bytes,
+                       uint32_t *perm, uint32_t *idx_sorted)
+{
+    if (!ntris || !nverts) return;
+    (void)hipMemsetAsync(aabb6, 0xFF, 12, s);
+    (void)hipMemsetAsync(aabb6 + 3, 0, 12, s);
+    const uint32_t vgrid = std::min<uint32_t>((nverts + kBlock - 1) / kBlock, 256u);
+    hipLaunchKernelGGL(k_mesh_aabb, dim3(vgrid), dim3(kBlock), 0, s, verts, stride, nverts, aabb6);
+    const dim3 tgrid((ntris + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_mesh_morton, tgrid, dim3(kBlock), 0, s, verts, stride, idx, ntris, aabb6, keys_a, vals_a);
+    launch_sort(s, sort_temp, sort_temp_bytes, keys_a, keys_b, vals_a, perm, ntris);
+    hipLaunchKernelGGL(k_permute_indices, tgrid, dim3(kBlock), 0, s, idx, perm, ntris, idx_sorted);
+}
+
+void launch_group_bounds(hipStream_t s, const uint8_t *verts, uint32_t stride, const uint32_t *idx_sorted, uint32_t ntris, float4 *boxes)
+{
+    if (!ntris) return;
+    const uint32_t groups = (ntris + kCullGroup - 1) / kCullGroup;
+    hipLaunchKernelGGL(k_group_bounds, dim3((groups + kBlock - 1) / kBlock), dim3(kBlock), 0, s, verts, stride, idx_sorted, ntris, boxes);
 }
 
 void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats)

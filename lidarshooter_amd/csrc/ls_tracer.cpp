@@ -43,6 +43,12 @@ struct Geometry {
     void *h_stage_v = nullptr, *h_stage_i = nullptr;
     size_t stage_v_cap = 0, stage_i_cap = 0;
     hipEvent_t ev_stage_v = nullptr, ev_stage_i = nullptr;   // recorded behind the last DMA that reads the staging buffer
+    // block culling (projection engine, meshes with 64 triangles per wave): Morton order of the triangles, the
+    // indices in that order, mesh-space bounds per 64 sorted triangles
+    uint32_t *d_perm = nullptr, *d_idx_sorted = nullptr;
+    float4 *d_boxes = nullptr;
+    bool order_stale = true;    // the topology changed since d_perm / d_idx_sorted were made
+    bool bounds_stale = true;   // vertices (may have) changed since d_boxes were made
     const void *raw() const { return shared_raw ? shared_raw : d_raw; }
     const uint32_t *idx() const { return shared_idx ? shared_idx : d_idx; }
     float affine[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -272,6 +278,10 @@ struct ls_tracer {
     size_t h_cap = 0;  // records
     uint32_t *h_n_points = nullptr;
     bool traced = false;
+    int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (on for azimuth shards narrower than half a turn)
+    DevBuf<uint32_t> cull_list;  // three survivor lists (one per frame that can be in flight) of cull_chunks entries
+    uint32_t cull_chunks = 0;
+    uint32_t *d_aabb6 = nullptr; // scratch of launch_mesh_order
     int opt_host_output = 1;     // LS_OPT_HOST_OUTPUT: the pack kernel writes the pinned host buffers itself
     int opt_readback_hits = 1;   // LS_OPT_READBACK_HITS
     int opt_debug_fault = 0;     // LS_OPT_DEBUG_FAULT (one frame)
@@ -385,6 +395,9 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     static const int debug = getenv("LS_PROJECT_DEBUG") ? atoi(getenv("LS_PROJECT_DEBUG")) : 0;
     pp.big_cells = big_cells;
     pp.debug = debug;
+    // LS_PROJECT_SPREAD (0 / 1) overrides: spread when frames do not overlap on other streams (modes 0 and 1)
+    static const int spread_env = getenv("LS_PROJECT_SPREAD") ? atoi(getenv("LS_PROJECT_SPREAD")) : -1;
+    pp.spread = spread_env >= 0 ? spread_env : (tr->opt_pipeline == 2 ? 0 : 1);
     return pp;
 }
 
@@ -760,7 +773,8 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         g.shared_raw = verts;
         g.stride = stride;
         g.has_verts = true;
-        if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; }
+        g.bounds_stale = true;   // the caller's buffer may hold anything now
+        if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; }
         return LS_OK;
     }
     if (!verts && !idx) return LS_OK;   // transform only: nothing is copied, nothing to order
@@ -792,9 +806,11 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         g.stride = stride;
         if (!g.has_verts) tr->layout_dirty = true;
         g.has_verts = true;
+        g.bounds_stale = true;
     }
     if (idx) {
         g.shared_idx = nullptr;
+        g.order_stale = true;
         const size_t bytes = (size_t)g.n_tris * 12;
         if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), bytes ? bytes : 4));
         if (bytes) {
@@ -818,6 +834,11 @@ void free_geometry(Geometry &g)
     if (g.d_idx) (void)hipFree(g.d_idx);
     if (g.h_stage_v) (void)hipHostFree(g.h_stage_v);
     if (g.h_stage_i) (void)hipHostFree(g.h_stage_i);
+    if (g.d_perm) (void)hipFree(g.d_perm);
+    if (g.d_idx_sorted) (void)hipFree(g.d_idx_sorted);
+    if (g.d_boxes) (void)hipFree(g.d_boxes);
+    g.d_perm = g.d_idx_sorted = nullptr;
+    g.d_boxes = nullptr;
     if (g.ev_stage_v) (void)hipEventDestroy(g.ev_stage_v);
     if (g.ev_stage_i) (void)hipEventDestroy(g.ev_stage_i);
     g.d_raw = nullptr;
@@ -845,6 +866,50 @@ int materialize_scene(ls_tracer *tr, bool with_maxabs)
     }
     LS_HIP(hipGetLastError());
     tr->scene_materialized = true;
+    return LS_OK;
+}
+
+// Group culling pays when k_project is bandwidth-bound or most groups go.  Measured on MI355X (128 x 4096 rays): at 10 M
+// triangles the frame drops from 87 to 59 us (three frames in flight); at 1 M the kernel is latency-bound, the cull pass
+// (~10 us) costs what the denser k_project saves (21 -> 15.6 us), so auto leaves it off there; an azimuth shard of an
+// eighth of a turn keeps 4 % of a ground mesh's groups.  auto = the geometry has 2 M triangles or more, or the handle is
+// an azimuth shard narrower than half a turn.
+bool cull_enabled(const ls_tracer *tr, const Geometry &g)
+{
+    if (tr->opt_block_cull != 2) return tr->opt_block_cull != 0;
+    return g.n_tris >= 2000000u || project_params(tr).sector_on != 0;
+}
+
+// Group-culling data of one geometry, brought up to date (stream-ordered on the handle's stream).
+int prepare_blocks(ls_tracer *tr, Geometry &g)
+{
+    const bool want = cull_enabled(tr, g) && g.has_verts && g.has_idx && ls::project_tris_per_wave(g.n_tris) == 64u;
+    if (!want) return LS_OK;
+    if (!g.order_stale && !g.bounds_stale) return LS_OK;
+    // frames in flight on the slot streams read d_idx_sorted / d_perm / d_boxes
+    int rc;
+    if ((rc = flush_pipeline(tr))) return rc;
+    ++tr->main_epoch;
+    const uint32_t nt = g.n_tris, ngroups = (nt + ls::kCullGroup - 1u) / ls::kCullGroup;
+    if (!g.d_perm) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_perm), (size_t)nt * 4));
+    if (!g.d_idx_sorted) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx_sorted), (size_t)nt * 12));
+    if (!g.d_boxes) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_boxes), (size_t)ngroups * 32));
+    if (g.order_stale) {
+        if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
+        if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
+        if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
+        if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
+        if (!tr->d_aabb6) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_aabb6), 32));
+        ls::launch_mesh_order(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.n_verts, g.idx(), nt, tr->d_aabb6,
+                              tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->sort_temp.p, tr->sort_temp.cap, g.d_perm, g.d_idx_sorted);
+        g.order_stale = false;
+        g.bounds_stale = true;
+    }
+    if (g.bounds_stale) {
+        ls::launch_group_bounds(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.d_idx_sorted, nt, g.d_boxes);
+        g.bounds_stale = false;
+    }
+    LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
@@ -941,8 +1006,11 @@ int commit_locked(ls_tracer *tr)
         LS_HIP(hipGetLastError());
         tr->bvh_built = true;
     } else {
-        // projection engine: nothing to build -- the trace kernel streams the meshes as uploaded and
-        // applies the vertex transform on the fly
+        // projection engine: no hierarchy to build -- the trace kernel streams the meshes as uploaded and applies
+        // the vertex transform on the fly.  Big meshes keep a Morton order (per topology) and per-block bounds
+        // (per vertex upload) so that k_cull can drop whole 64-triangle blocks before their indices are read.
+        for (Geometry *ge : order)
+            if ((rc = prepare_blocks(tr, *ge))) return rc;
         mark(tr, 1);
     }
     for (Geometry *ge : order) ge->idx_dirty = false;
@@ -1003,7 +1071,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         unsigned long long *keys = slot == 0 ? tr->best_keys.p : (slot == 1 ? tr->best_keys_b.p : tr->best_keys_c.p);
         void *bigq = slot == 0 ? static_cast<void *>(tr->big_queue.p)
                                : (slot == 1 ? static_cast<void *>(tr->big_queue_b.p) : static_cast<void *>(tr->big_queue_c.p));
-        uint32_t *big_count = tr->d_big_count + 4u * (multi ? slot : tr->pipe_seq % 3u);
+        uint32_t *big_count = tr->d_big_count + ls::kCounterSlotWords * (multi ? slot : tr->pipe_seq % 3u);
         if (slot && !tr->ext_points) {
             d_points = slot == 1 ? tr->points_b.p : tr->points_c.p;
             d_hits = slot == 1 ? tr->hits_b.p : tr->hits_c.p;
@@ -1040,6 +1108,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         mark(tr, 7);
         std::vector<ls::GeomSource> &srcs = tr->project_srcs;
         srcs.clear();
+        bool any_culled = false;
         for (const auto &le : tr->layout) {
             auto it = tr->geoms.find(le.name);
             if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
@@ -1055,7 +1124,28 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             std::memcpy(src.m.a, ge.affine, sizeof(src.m.a));
             std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
             std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
+            // block culling data is current (prepare_blocks ran at the commit) unless an update came in since
+            const bool culled = cull_enabled(tr, ge) && ge.d_boxes && !ge.order_stale && !ge.bounds_stale &&
+                                ls::project_tris_per_wave(ge.n_tris) == 64u;
+            src.perm = culled ? ge.d_perm : nullptr;
+            src.boxes = culled ? ge.d_boxes : nullptr;
+            if (culled) src.idx = ge.d_idx_sorted;
+            any_culled = any_culled || culled;
             srcs.push_back(src);
+        }
+        // survivor list of this frame's k_cull: one of three (as many frames as can be in flight)
+        uint32_t *cull_list = nullptr;
+        if (any_culled) {
+            const uint32_t entries = ls::project_cull_entries(srcs.data(), (uint32_t)srcs.size());
+            if (entries) {
+                if (entries > tr->cull_chunks) {
+                    if ((rc = flush_pipeline(tr))) return rc;
+                    LS_HIP(hipStreamSynchronize(tr->stream));
+                    if ((rc = ensure(tr, tr->cull_list, 3 * (size_t)entries))) return rc;
+                    tr->cull_chunks = (uint32_t)(tr->cull_list.cap / 3);
+                }
+                cull_list = tr->cull_list.p + (size_t)(multi ? slot : tr->pipe_seq % 3u) * tr->cull_chunks;
+            }
         }
         ls::GeomTable gt;
         gt.n = (uint32_t)tr->slot_geom_ids.size();
@@ -1064,7 +1154,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         if (pipelined) {
             // one launch: this frame's k_project workgroups + the previous frame's finish + pack workgroups
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, nullptr,
-                               tr->pipe_pending ? &tr->pipe_fa : nullptr);
+                               tr->pipe_pending ? &tr->pipe_fa : nullptr, cull_list);
             if (++tr->pack_epoch == 0u) {   // the epoch tag wrapped: no stale status word may match
                 LS_HIP(hipMemsetAsync(tr->pack_status.p, 0, tr->pack_status.cap * 8, s));
                 tr->pack_epoch = 1u;
@@ -1074,7 +1164,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             fa.big = bigq;
             fa.big_capacity = tr->big_capacity;
             fa.big_count = big_count;
-            fa.rearm_big_count = tr->d_big_count + 4u * ((tr->pipe_seq + 2u) % 3u);
+            fa.rearm_big_count = tr->d_big_count + ls::kCounterSlotWords * ((tr->pipe_seq + 2u) % 3u);
             fa.status = tr->pack_status.p;
             fa.epoch = tr->pack_epoch;
             fa.publish_epoch = tr->pack_epoch;
@@ -1096,7 +1186,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             if (readback && (rc = flush_pipeline(tr))) return rc;
         } else {
             // one launch per 16 geometries (the descriptors travel as kernel arguments)
-            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats);
+            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list);
             mark(tr, 8);
             ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
             mark(tr, 9);
@@ -1207,7 +1297,7 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_queue_heads), ls::kQueues * 16 * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
-    if (hipMalloc(reinterpret_cast<void **>(&tr->d_big_count), 64) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_big_count), 4 * ls::kCounterSlotWords * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
     for (float chi : tr->vertical)
         if (!(chi >= -90.0f && chi <= 90.0f)) tr->projection_ok = false;  // elevation == channel angle only there
     if (!std::isfinite(tr->h_begin) || !std::isfinite(tr->h_end)) tr->projection_ok = false;
@@ -1303,6 +1393,8 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->d_n_points) (void)hipFree(tr->d_n_points);
     if (tr->d_queue_heads) (void)hipFree(tr->d_queue_heads);
     if (tr->d_big_count) (void)hipFree(tr->d_big_count);
+    release(tr->cull_list);
+    if (tr->d_aabb6) (void)hipFree(tr->d_aabb6);
     release(tr->best_keys);
     release(tr->big_queue);
     release(tr->spill);
@@ -1623,6 +1715,10 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         tr->opt_readback_hits = value;
         return LS_OK;
     case LS_OPT_DEBUG_FAULT: tr->opt_debug_fault = value != 0; return LS_OK;
+    case LS_OPT_BLOCK_CULL:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto");
+        tr->opt_block_cull = value;
+        return LS_OK;
     case LS_OPT_PIPELINE: {
         if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_PIPELINE: 0 off, 1 two frames on one stream, 2 three streams");
         if (value == 2) {
@@ -1642,7 +1738,7 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         const int rc = flush_pipeline(tr);
         if (rc) return rc;
         LS_HIP(hipStreamSynchronize(tr->stream));
-        LS_HIP(hipMemset(tr->d_big_count, 0, 64));   // the modes rotate the queue counters differently
+        LS_HIP(hipMemset(tr->d_big_count, 0, 4 * ls::kCounterSlotWords * sizeof(uint32_t)));   // the modes rotate the queue counters differently
         tr->pipe_seq = 0;
         tr->ms_seq = 0;
         tr->opt_pipeline = value;

@@ -1,0 +1,133 @@
+"""Block culling of the projection engine (LS_OPT_BLOCK_CULL: Morton-ordered mesh, bounds per 64 triangles, k_cull
+drops blocks no ring / no shard column can meet) must not change a single bit: culled == unculled == BVH engine on the
+headline-sized scene under a moving transform, a vertex update, azimuth shards and both frames-in-flight modes."""
+import numpy as np
+import pytest
+
+from conftest import make_tracer
+from test_gpu_parity import _syn_sensor
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(tr):
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    assert rc == 0
+    return tr.denseHits(), pts, hits
+
+
+def _same(a, b):
+    (ta, ga), pa, ha = a
+    (tb, gb), pb, hb = b
+    assert np.array_equal(ga, gb) and np.array_equal(ta, tb)
+    assert np.array_equal(pa, pb) and np.array_equal(ha, hb)
+
+
+def test_cull_equals_unculled_under_transforms_and_shards(oracle, capi, sensors):
+    from lidarshooter_amd import synth
+    v, t = synth.syn_1m()
+    s = _syn_sensor(oracle, sensors, V=128, H=4096)
+    on, off = make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection")
+    off.setOption(capi.LS_OPT_BLOCK_CULL, 0)
+    for tr in (on, off):
+        tr.addGeometry("g", v.shape[0], t.shape[0])
+        tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
+    a, b = _frame(on), _frame(off)
+    _same(a, b)
+    assert 200000 < len(a[1]) < 300000
+    # transform-only updates: the cached mesh-space bounds travel through this frame's matrix
+    for lin, ang in (((3.0, -7.5, 0.4), (0.02, -0.03, 0.9)), ((-20.0, 11.0, -1.5), (0.3, 0.1, -2.2)), ((0.0, 0.0, 30.0), (1.2, 0.0, 0.0))):
+        A = oracle.affine_from_components(np.array(lin, np.float32), np.array(ang, np.float32))
+        for tr in (on, off):
+            tr.updateGeometryTransform("g", A)
+        _same(_frame(on), _frame(off))
+    # a non-rigid matrix (the interface takes any Affine3f, ITracer.hpp:69)
+    A = np.array([1.5, 0.2, 0.0, 1.0, -0.1, 0.7, 0.3, -2.0, 0.0, 0.4, 2.0, 0.5], np.float32)
+    for tr in (on, off):
+        tr.updateGeometryTransform("g", A)
+    _same(_frame(on), _frame(off))
+    # azimuth shards: a narrow sector, a half turn, the wrap-around columns
+    for tr in (on, off):
+        tr.updateGeometryTransform("g", oracle.IDENTITY_AFFINE)
+    for first, n in ((1000, 256), (0, 2048), (3900, 196), (512, 512)):
+        for tr in (on, off):
+            tr.setShard(first, n)
+        _same(_frame(on), _frame(off))
+    on.close()
+    off.close()
+
+
+def test_cull_follows_vertex_updates_and_small_meshes(oracle, capi, sensors, meshes):
+    """A 600 000-triangle grid whose vertices change every frame (bounds recomputed per upload) next to the small
+    ben.stl (no block data: its chunks pass through k_cull), against the BVH engine."""
+    from lidarshooter_amd import synth
+    v, t = synth.grid_mesh(1000, 300)
+    bv, bt = meshes["ben"]
+    s = _syn_sensor(oracle, sensors, V=128, H=2048)
+    pr, bvh = make_tracer(capi, s, "projection"), make_tracer(capi, s, "bvh")
+    for tr in (pr, bvh):
+        tr.addGeometry("grid", v.shape[0], t.shape[0])
+        tr.addGeometry("face", bv.shape[0], bt.shape[0])
+    rng = np.random.default_rng(5)
+    for k in range(4):
+        vk = v.copy()
+        vk[:, 2] += (0.5 * k + 0.2 * np.sin(0.21 * v[:, 0] + k)).astype(np.float32)
+        if k == 3:
+            vk = vk[:, [1, 0, 2]].copy()           # the same topology laid out differently: the old Morton order is stale but valid
+        A = oracle.affine_from_components(rng.uniform(-2, 2, 3).astype(np.float32), rng.uniform(-0.3, 0.3, 3).astype(np.float32))
+        for tr in (pr, bvh):
+            tr.updateGeometry("grid", oracle.IDENTITY_AFFINE, vk, t if k == 0 else None)
+            tr.updateGeometry("face", A, bv, bt)
+        _same(_frame(pr), _frame(bvh))
+    pr.close()
+    bvh.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_cull_with_frames_in_flight(oracle, capi, sensors, mode):
+    """Streamed frames (two on one stream / three on three streams) with block culling and a pose that changes every
+    frame: each frame's cloud equals the synchronous, unculled one for the same pose."""
+    import torch
+    from lidarshooter_amd import synth
+    v, t = synth.syn_1m()
+    s = _syn_sensor(oracle, sensors, V=128, H=4096)
+    dev = torch.device("cuda", 0)
+    dv = torch.from_numpy(v).to(dev)
+    dt = torch.from_numpy(t.view(np.int32)).to(dev)
+    poses = [oracle.affine_from_components(np.array((0.7 * k, -0.4 * k, 0.05 * k), np.float32), np.array((0.0, 0.01 * k, 0.2 * k), np.float32))
+             for k in range(6)]
+    ref_tr = make_tracer(capi, s, "projection")
+    ref_tr.setOption(capi.LS_OPT_BLOCK_CULL, 0)
+    ref_tr.addGeometry("g", v.shape[0], t.shape[0])
+    ref_tr.updateGeometryDeviceShared("g", poses[0], dv.data_ptr(), 12, dt.data_ptr())
+    refs = []
+    for A in poses:
+        ref_tr.updateGeometryTransform("g", A)
+        refs.append(_frame(ref_tr)[1:])
+    ref_tr.close()
+    tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_PIPELINE, mode)
+    tr.addGeometry("g", v.shape[0], t.shape[0])
+    tr.updateGeometryDeviceShared("g", poses[0], dv.data_ptr(), 12, dt.data_ptr())
+    cap = s.V * s.H
+    bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device=dev), torch.zeros(16 * cap, dtype=torch.uint8, device=dev),
+             torch.zeros(4, dtype=torch.int32, device=dev)) for _ in range(3)]
+    n_frames = 18
+    for i in range(n_frames):
+        tr.updateGeometryTransform("g", poses[i % 6])
+        assert tr.commitScene() == 0
+        p, h, n = bufs[i % 3]
+        tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
+        tr.traceSceneAsync(i)
+        if i % 3 == 2:
+            tr.synchronize()
+            for k in (i - 2, i - 1, i):
+                p, h, n = bufs[k % 3]
+                pts, hits = refs[k % 6]
+                cnt = int(n[0].item())
+                assert cnt == pts.shape[0]
+                assert np.array_equal(p.cpu().numpy()[:32 * cnt].reshape(cnt, 32), pts)
+                got = h.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4)
+                assert np.array_equal(got, np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1))
+    tr.close()
