@@ -395,9 +395,7 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     static const int debug = getenv("LS_PROJECT_DEBUG") ? atoi(getenv("LS_PROJECT_DEBUG")) : 0;
     pp.big_cells = big_cells;
     pp.debug = debug;
-    // LS_PROJECT_SPREAD (0 / 1) overrides: spread when frames do not overlap on other streams (modes 0 and 1)
-    static const int spread_env = getenv("LS_PROJECT_SPREAD") ? atoi(getenv("LS_PROJECT_SPREAD")) : -1;
-    pp.spread = spread_env >= 0 ? spread_env : (tr->opt_pipeline == 2 ? 0 : 1);
+    pp.spread = 1;   // trace_locked clears it for frames that overlap on the three slot streams
     return pp;
 }
 
@@ -1057,12 +1055,17 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 32, s));
     if (use_projection(tr)) {
         // sensor-space projection engine: stream the triangles once, test only the covered rays
-        const ls::ProjectParams pp = project_params(tr);
+        ls::ProjectParams pp = project_params(tr);
         unsigned long long *stats = tr->opt_count ? tr->d_visits + 1 : nullptr;  // counts[1] = triangle tests
         const uint32_t n_blocks = (shard_rays(tr) + 255u) / 256u;
         const bool pipelined = tr->opt_pipeline == 1 && !tr->opt_count && !tr->opt_timing;
         const bool multi = tr->opt_pipeline == 2 && !tr->opt_count && !tr->opt_timing;
         if (!pipelined && !multi && (rc = flush_pipeline(tr))) return rc;
+        {   // spread runs balance the cells per wave (shorter kernel: 23.6 -> 21.2 us alone) but touch more cache lines,
+            // which costs more than it gains once three frames overlap (16.9 -> 17.2 us per frame): LS_PROJECT_SPREAD overrides
+            static const int spread_env = getenv("LS_PROJECT_SPREAD") ? atoi(getenv("LS_PROJECT_SPREAD")) : -1;
+            pp.spread = spread_env >= 0 ? spread_env : (multi ? 0 : 1);
+        }
         // which set of keys / queue / outputs and which of the three queue counters this frame uses.
         // Rider mode and frames that are not pipelined: pipe_seq counts the pipelined frames; a frame that is
         // not pipelined re-arms what it used itself and leaves pipe_seq alone, so the rotation stays

@@ -59,7 +59,10 @@ def main():
         wv = write.get(k, (0.0, 0))
         hbm[k] = {"FETCH_SIZE_KiB_per_launch": f[0], "WRITE_SIZE_KiB_per_launch": wv[0], "launches": max(f[1], wv[1]),
                   "hbm_bytes_per_launch": (2.0 * f[0] + wv[0]) * 1024.0}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     json.dump({"note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE reads 1/2)",
+               "kernel_source_sha": bench.kernel_source_sha(),   # bench.py reports `traffic` only while the sources still hash to this
                "kernels": hbm}, open(out + "_hbm.json", "w"), indent=1)
     for r in rows[:12]:
         print(r[0], r[1], r[3], r[4])
