@@ -1,0 +1,73 @@
+/*
+ * lidarshooter_group.h -- one LiDAR frame over the GPUs of a node, from C or C++ (no Python, no PyTorch): the
+ * multi-GPU part of SURVEY.md section 8(e) behind the C ABI of lidarshooter_hip.h.  One process per GPU; the
+ * collective is RCCL (librccl.so.1, loaded at ls_group_create; xGMI between the GPUs of a node).
+ *
+ * The reference has no multi-GPU path ("no NCCL / MPI / Gloo"); this is new surface.  Two ways
+ * to spread a stream of frames over `world` GPUs, every GPU holding the whole scene:
+ *
+ *   LS_GROUP_SHARDED      every rank traces its azimuth sector of EVERY frame (ls_tracer_set_shard) and leaves its
+ *                         hit records in a fixed-capacity slot  [n u32 | pad to 64 B | ls_hit x capacity];  ONE
+ *                         ncclAllGather of the slots per frame is the all-gatherv of hit records (the count travels
+ *                         in the slot header; the 32-byte points are a function of (ray, t) and are rebuilt by
+ *                         ls_expand_gathered_hits on every rank).  Latency of one frame goes down with `world`.
+ *   LS_GROUP_INTERLEAVED  rank g traces the WHOLE raster of the frames f with f mod world == g; nothing is exchanged
+ *                         on the frame path.  Throughput goes up with `world`; a frame's latency stays that of one GPU.
+ *                         (A 128 x 4096 frame over 1 M triangles takes ~20 us on one MI355X and is bound by launch
+ *                         and memory latency, not by work: sharding it cannot win what a collective costs; interleaving can.)
+ *
+ * Frames rotate over three sets of buffers, so the gather + rebuild of frame f overlap the tracing of f+1 and f+2.
+ */
+#ifndef LIDARSHOOTER_GROUP_H
+#define LIDARSHOOTER_GROUP_H
+
+#include "lidarshooter_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ls_group ls_group;
+
+#define LS_GROUP_SHARDED 0
+#define LS_GROUP_INTERLEAVED 1
+#define LS_GROUP_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+#define LS_GROUP_SLOT_HEADER 64
+
+/* ---- slot arithmetic: plain functions, usable (and tested) without a GPU ---------------------------------------- */
+/* contiguous azimuth columns of `rank`: the first H mod world ranks get one column more */
+void ls_group_shard_columns(uint32_t H, uint32_t world, uint32_t rank, uint32_t *first_az, uint32_t *n_az);
+/* records per slot = rays of the largest shard */
+uint32_t ls_group_slot_capacity(uint32_t V, uint32_t H, uint32_t world);
+uint64_t ls_group_slot_bytes(uint32_t capacity);
+/* host twins of what the GPU does with a slot (CPU consumers, tests): fill one / unpack `world` gathered ones in rank
+ * order (= ascending azimuth sector; ray indices inside the records are global).  decode returns the record count. */
+void ls_group_write_slot(void *slot, uint32_t capacity, const ls_hit *hits, uint32_t n);
+uint32_t ls_group_decode_gathered(const void *gathered, uint32_t world, uint32_t capacity, ls_hit *out_hits);
+
+/* ---- the group ---------------------------------------------------------------------------------------------------- */
+/* rank 0 makes the id (ncclGetUniqueId) and ships it to the other ranks by any means (file, pipe, MPI, environment) */
+int ls_group_unique_id(uint8_t id[LS_GROUP_ID_BYTES]);
+/* Collective over all ranks.  `tr` is this rank's tracer (created on its own GPU, geometries may be added before or
+ * after); the group puts it on a stream of its own, sets its shard (SHARDED) and owns its output buffers from now on. */
+int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, ls_tracer *tr, ls_group **out);
+void ls_group_destroy(ls_group *g);
+/* One frame, after the caller's updateGeometry / commitScene on the tracer: nothing in it waits for the device.
+ * SHARDED: every rank calls it for every frame.  INTERLEAVED: every rank calls it for every frame too; it returns 1
+ * without doing anything on the ranks that do not own the frame (0 where the frame was traced). */
+int ls_group_trace(ls_group *g, uint32_t frame_index);
+/* 1 if this rank holds frame_index's cloud (always, when SHARDED) */
+int ls_group_owns_frame(const ls_group *g, uint32_t frame_index);
+/* The whole frame's cloud on this rank: device pointers (points32, hits, count word), complete once the group's
+ * collective stream has drained (ls_group_synchronize) -- buffers are reused three frames later. */
+int ls_group_cloud(ls_group *g, uint32_t frame_index, ls_frame *out);
+/* The same cloud copied to host memory (waits for the frame): points32 takes 32 bytes per point, hits 16 (either may
+ * be NULL); returns the number of points or a negative ls_status.  capacity in points. */
+long ls_group_download_cloud(ls_group *g, uint32_t frame_index, void *points32, void *hits, uint32_t capacity);
+int ls_group_synchronize(ls_group *g);
+const char *ls_group_last_error(const ls_group *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARSHOOTER_GROUP_H */

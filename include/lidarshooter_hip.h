@@ -205,6 +205,10 @@ int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az);
  * sector), d_points32 (rebuilt points), *d_n_points.  Stream-ordered on the handle's stream. */
 int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
                             void *d_hits, uint32_t *d_n_points);
+/* The same on a stream of the caller's (a hipStream_t): the collective's stream, so that the compaction follows the
+ * gather without holding up the tracer's stream (include/lidarshooter_group.h does this). */
+int ls_expand_gathered_hits_on(ls_tracer *tr, void *hip_stream, const void *d_gathered, uint32_t world, uint32_t capacity,
+                               void *d_points32, void *d_hits, uint32_t *d_n_points);
 
 /* The step after the tracer: the sensor-frame cloud into the world frame, on the
  * device.  Replaces CloudTransformer::applyInverseTransform (CloudTransformer.cpp:283-318) +
@@ -280,6 +284,7 @@ int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
 #define LS_INFO_PIPELINE_MODE 2      /* the frames-in-flight mode actually in use (0, 1 or 2)                    */
 #define LS_INFO_DEVICE_STATUS 3      /* sticky device status word (0 = ok); read-and-clear, synchronises          */
 #define LS_INFO_HOST_THREADS 4       /* worker threads of the host copy pool                                     */
+#define LS_INFO_AZIMUTH_COUNT 5      /* H: azimuth columns of the sensor's full raster (whatever the shard)       */
 long ls_get_info(ls_tracer *tr, int what);
 
 /* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded

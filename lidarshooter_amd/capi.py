@@ -19,7 +19,7 @@ INVALID = 0xFFFFFFFF
 
 LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPELINE = 1, 2, 3, 5, 6
 LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL = 7, 8, 9, 10
-LS_INFO_CONCURRENT_STREAMS, LS_INFO_PIPELINE_MODE, LS_INFO_DEVICE_STATUS, LS_INFO_HOST_THREADS = 1, 2, 3, 4
+LS_INFO_CONCURRENT_STREAMS, LS_INFO_PIPELINE_MODE, LS_INFO_DEVICE_STATUS, LS_INFO_HOST_THREADS, LS_INFO_AZIMUTH_COUNT = 1, 2, 3, 4, 5
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
 STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "trace_aux", "pack")
 
@@ -30,7 +30,7 @@ SYMBOLS = (
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
-    "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
+    "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_debug_dense_hits", "ls_debug_trace_bruteforce",
     "ls_debug_scene_size", "ls_debug_download_scene", "ls_debug_download_bvh",
 )
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
     L.ls_tracer_synchronize.argtypes = [vp]
     L.ls_tracer_set_output_buffers.argtypes = [vp, vp, vp, vp, u32]
     L.ls_expand_gathered_hits.argtypes = [vp, vp, u32, u32, vp, vp, vp]
+    L.ls_expand_gathered_hits_on.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
     L.ls_cloud_to_world.argtypes = [vp, f32p, f32p, vp, vp, vp, vp, vp, u32]
     L.ls_tracer_flush.argtypes = [vp]
     L.ls_tracer_set_option.argtypes = [vp, i32, i32]

@@ -1668,6 +1668,7 @@ long ls_get_info(ls_tracer *tr, int what)
         return (long)__atomic_exchange_n(tr->h_status, 0u, __ATOMIC_ACQ_REL);
     }
     case LS_INFO_HOST_THREADS: return HostPool::get().threads();
+    case LS_INFO_AZIMUTH_COUNT: return (long)tr->H;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }
@@ -1790,16 +1791,23 @@ int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[4])
     return LS_OK;
 }
 
-int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
-                            void *d_hits, uint32_t *d_n_points)
+int ls_expand_gathered_hits_on(ls_tracer *tr, void *hip_stream, const void *d_gathered, uint32_t world, uint32_t capacity,
+                               void *d_points32, void *d_hits, uint32_t *d_n_points)
 {
     LS_ENTER(tr);
     if (!d_gathered || !d_points32 || !d_hits || !d_n_points || !world || !capacity)
         return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
-    ls::launch_expand_slots(tr->stream, tables(tr), static_cast<const uint32_t *>(d_gathered), world, capacity,
-                            16u + 4u * capacity, static_cast<uint8_t *>(d_points32), d_hits, d_n_points);
+    ls::launch_expand_slots(hip_stream ? static_cast<hipStream_t>(hip_stream) : tr->stream, tables(tr),
+                            static_cast<const uint32_t *>(d_gathered), world, capacity, 16u + 4u * capacity,
+                            static_cast<uint8_t *>(d_points32), d_hits, d_n_points);
     LS_HIP(hipGetLastError());
     return LS_OK;
+}
+
+int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
+                            void *d_hits, uint32_t *d_n_points)
+{
+    return ls_expand_gathered_hits_on(tr, nullptr, d_gathered, world, capacity, d_points32, d_hits, d_n_points);
 }
 
 int ls_generate_rays(ls_tracer *tr, float *dx, float *dy, float *dz)

@@ -6,10 +6,14 @@
 // on the XT-32 scene and checks the reference's known answer (1781 points).
 //
 //   lsbench --config sensor.json [--mesh name=file.stl]... [--syn V H]  [--grid NX NY]
-//           [--frames K] [--warmup W] [--pipeline 0|1|2] [--engine 0|1|2]
+//           [--frames K] [--warmup W] [--pipeline 0|1|2] [--engine 0|1|2] [--ranks N [--group sharded|interleaved]]
+//   --ranks N    : one process per GPU (forked before anything touches a GPU), frames through include/lidarshooter_group.h:
+//                  azimuth shards + one ncclAllGather of hit-record slots per frame, or whole frames interleaved over the ranks
 //   --syn V H    : replace the sensor's raster by V channels (+15 .. -25 deg) x H azimuths (0 .. 360 deg)
 //   --grid NX NY : add a synthetic ground of NX x NY cells (2 triangles each) over [-50, 50]^2 m
 #include <hip/hip_runtime.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cmath>
@@ -19,6 +23,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/lidarshooter_group.h"
 #include "../../include/lidarshooter_hip.h"
 #include "HostTypes.hpp"
 #include "LidarDevice.hpp"
@@ -50,11 +55,15 @@ int upload(DeviceMesh& m, const void* verts, size_t vbytes, const uint32_t* tris
 
 }  // namespace
 
+namespace {
+std::string config, group_mode = "sharded";
+std::vector<std::pair<std::string, std::string>> mesh_files;
+int synV = 0, synH = 0, gridX = 0, gridY = 0, frames = 200, warmup = 50, pipeline = 0, engine = 0, ranks = 0;
+int run(int rank, int world, const std::string& id_path, int result_fd);
+}  // namespace
+
 int main(int argc, char** argv)
 {
-    std::string config;
-    std::vector<std::pair<std::string, std::string>> mesh_files;
-    int synV = 0, synH = 0, gridX = 0, gridY = 0, frames = 200, warmup = 50, pipeline = 0, engine = 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](int n) { if (i + n >= argc) { std::fprintf(stderr, "%s: missing value\n", a.c_str()); std::exit(2); } };
@@ -66,9 +75,83 @@ int main(int argc, char** argv)
         else if (a == "--warmup") { need(1); warmup = std::atoi(argv[++i]); }
         else if (a == "--pipeline") { need(1); pipeline = std::atoi(argv[++i]); }
         else if (a == "--engine") { need(1); engine = std::atoi(argv[++i]); }
+        else if (a == "--ranks") { need(1); ranks = std::atoi(argv[++i]); }
+        else if (a == "--group") { need(1); group_mode = argv[++i]; }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (config.empty()) { std::fprintf(stderr, "--config is required\n"); return 2; }
+    if (ranks <= 0) return run(0, 0, "", -1);
+    if (group_mode != "sharded" && group_mode != "interleaved") { std::fprintf(stderr, "--group sharded|interleaved\n"); return 2; }
+
+    // ---- one process per rank, forked before anything here has touched a GPU; results come back through pipes
+    char id_path[] = "/tmp/lsbench_id_XXXXXX";
+    const int idfd = mkstemp(id_path);
+    if (idfd >= 0) close(idfd);
+    unlink(id_path);   // rank 0 creates it (renamed into place) once it holds the RCCL id
+    std::vector<pid_t> pids(ranks);
+    std::vector<int> fds(ranks);
+    for (int r = 0; r < ranks; ++r) {
+        int pfd[2];
+        if (pipe(pfd) != 0) { std::perror("pipe"); return 2; }
+        const pid_t pid = fork();
+        if (pid < 0) { std::perror("fork"); return 2; }
+        if (pid == 0) {
+            close(pfd[0]);
+            const int rc = run(r, ranks, id_path, pfd[1]);
+            close(pfd[1]);
+            _exit(rc);
+        }
+        close(pfd[1]);
+        pids[r] = pid;
+        fds[r] = pfd[0];
+    }
+    double worst = 0.0, enq = 0.0;
+    unsigned rays = 0, points = 0;
+    unsigned long long tris = 0;
+    char sha[80] = "";
+    int rc = 0;
+    for (int r = 0; r < ranks; ++r) {
+        std::string text;
+        char buf[512];
+        for (ssize_t n; (n = read(fds[r], buf, sizeof(buf))) > 0;) text.append(buf, static_cast<size_t>(n));
+        close(fds[r]);
+        int status = 0;
+        waitpid(pids[r], &status, 0);
+        if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) { std::fprintf(stderr, "rank %d failed\n", r); rc = 2; continue; }
+        double el = 0, eq = 0;
+        unsigned ry = 0, pt = 0, owns_last = 0;
+        unsigned long long tt = 0;
+        char h[80] = "";
+        if (std::sscanf(text.c_str(), "%lf %lf %u %llu %u %u %79s", &el, &eq, &ry, &tt, &pt, &owns_last, h) < 6) { rc = 2; continue; }
+        worst = std::max(worst, el);
+        enq = std::max(enq, eq);
+        rays = ry;
+        tris = tt;
+        if (owns_last) { points = pt; std::snprintf(sha, sizeof(sha), "%s", h); }
+    }
+    unlink(id_path);
+    if (rc) return rc;
+    const unsigned whole = group_mode == "sharded" ? rays : rays;   // rays of the whole frame either way (reported by the ranks)
+    std::printf("{\"harness\": \"lsbench\", \"ranks\": %d, \"group\": \"%s\", \"rays_per_frame\": %u, \"triangles\": %llu, \"frames\": %d, "
+                "\"us_per_frame\": %.3f, \"frames_per_s\": %.1f, \"mrays_per_s\": %.1f, \"host_enqueue_us_per_frame\": %.3f, "
+                "\"points_last_frame\": %u, \"points_sha256\": \"%s\"}\n",
+                ranks, group_mode.c_str(), whole, tris, frames, worst / frames * 1e6, frames / worst,
+                static_cast<double>(whole) * frames / worst / 1e6, enq / frames * 1e6, points, sha);
+    return 0;
+}
+
+namespace {
+
+// one rank (world == 0: the plain single-process harness)
+int run(int rank, int world, const std::string& id_path, int result_fd)
+{
+    int device = 0;
+    if (world > 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { std::fprintf(stderr, "no HIP device\n"); return 2; }
+        device = ndev >= world ? rank : 0;
+        HIP_OK(hipSetDevice(device));
+    }
 
     // ---- sensor: LidarDevice.cpp:482-633 through the host mirror; --syn swaps the raster, keeps the pose
     lidarshooter::LidarDevice::Ptr dev;
@@ -86,7 +169,7 @@ int main(int argc, char** argv)
         sd.h_count = static_cast<uint32_t>(synH);
     }
     ls_tracer* tr = nullptr;
-    if (ls_tracer_create(&sd, 0, &tr) != LS_OK) { std::fprintf(stderr, "ls_tracer_create failed (no MI355X?)\n"); return 2; }
+    if (ls_tracer_create(&sd, device, &tr) != LS_OK) { std::fprintf(stderr, "ls_tracer_create failed (no MI355X?)\n"); return 2; }
     ls_tracer_set_option(tr, LS_OPT_ENGINE, engine);
 
     // ---- meshes: STL files (pcl::io::loadPolygonFileSTL semantics) and / or a synthetic ground, resident in HBM
@@ -142,6 +225,69 @@ int main(int argc, char** argv)
         total_tris += m.n_tris;
     }
 
+    static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    if (world > 0) {
+        // ---- frames through the group: every rank restates every mesh's pose, commits, and hands the frame to the group
+        const uint32_t whole_rays = ls_total_rays(tr);
+        ls_tracer_set_option(tr, LS_OPT_PIPELINE, pipeline);
+        for (const auto& m : meshes)
+            if (ls_update_geometry_device_shared(tr, m.name.c_str(), kIdentity, m.d_verts, m.stride, static_cast<const uint32_t*>(m.d_tris)) < 0) return 2;
+        uint8_t id[LS_GROUP_ID_BYTES] = {0};
+        const bool sharded = group_mode == "sharded";
+        if (sharded) {   // the RCCL id: rank 0 makes it, the others read it from the file
+            if (rank == 0) {
+                if (ls_group_unique_id(id) != LS_OK) { std::fprintf(stderr, "ls_group_unique_id failed (librccl?)\n"); return 2; }
+                const std::string tmp = id_path + ".tmp";
+                FILE* f = std::fopen(tmp.c_str(), "wb");
+                if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id)) return 2;
+                std::fclose(f);
+                std::rename(tmp.c_str(), id_path.c_str());
+            } else {
+                FILE* f = nullptr;
+                for (int tries = 0; tries < 3000 && !(f = std::fopen(id_path.c_str(), "rb")); ++tries) usleep(10000);
+                if (!f || std::fread(id, 1, sizeof(id), f) != sizeof(id)) { std::fprintf(stderr, "rank %d: no RCCL id\n", rank); return 2; }
+                std::fclose(f);
+            }
+        }
+        ls_group* g = nullptr;
+        if (ls_group_create(id, static_cast<uint32_t>(world), static_cast<uint32_t>(rank), sharded ? LS_GROUP_SHARDED : LS_GROUP_INTERLEAVED, tr, &g) != LS_OK) {
+            std::fprintf(stderr, "rank %d: ls_group_create failed\n", rank);
+            return 2;
+        }
+        auto gframe = [&](uint32_t i) -> int {
+            for (const auto& m : meshes)
+                if (ls_update_geometry_transform(tr, m.name.c_str(), kIdentity) < 0) return -2;
+            if (ls_commit_scene(tr) < -1) return -2;
+            return ls_group_trace(g, i) < -1 ? -2 : 0;
+        };
+        for (int i = 0; i < warmup; ++i)
+            if (gframe(static_cast<uint32_t>(i))) { std::fprintf(stderr, "frame: %s\n", ls_group_last_error(g)); return 2; }
+        ls_group_synchronize(g);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < frames; ++i)
+            if (gframe(static_cast<uint32_t>(i))) { std::fprintf(stderr, "frame: %s\n", ls_group_last_error(g)); return 2; }
+        const double enqueue_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ls_group_synchronize(g);
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const uint32_t last = static_cast<uint32_t>(frames - 1);
+        const bool owns_last = sharded ? rank == 0 : ls_group_owns_frame(g, last) != 0;
+        long n = 0;
+        std::string sha = "-";
+        if (owns_last) {
+            std::vector<uint8_t> pts(static_cast<size_t>(whole_rays) * 32);
+            n = ls_group_download_cloud(g, last, pts.data(), nullptr, whole_rays);
+            if (n < 0) { std::fprintf(stderr, "download: %s\n", ls_group_last_error(g)); return 2; }
+            sha = lidarshooter::sha256Hex(pts.data(), static_cast<size_t>(n) * 32);
+        }
+        char line[256];
+        const int len = std::snprintf(line, sizeof(line), "%.9f %.9f %u %llu %ld %d %s\n", elapsed, enqueue_s, whole_rays,
+                                      static_cast<unsigned long long>(total_tris), n, owns_last ? 1 : 0, sha.c_str());
+        if (result_fd >= 0 && write(result_fd, line, static_cast<size_t>(len)) != len) return 2;
+        ls_group_destroy(g);
+        ls_tracer_destroy(tr);
+        return 0;
+    }
+
     // ---- outputs: three caller-owned sets (frames in flight rotate over them)
     const uint32_t rays = ls_total_rays(tr);
     struct Out { void *points = nullptr, *hits = nullptr; uint32_t* n = nullptr; } out[3];
@@ -151,7 +297,6 @@ int main(int argc, char** argv)
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&o.n), 4));
     }
     ls_tracer_set_option(tr, LS_OPT_PIPELINE, pipeline);
-    static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     // the meshes are handed over once (in place, in HBM); after that every frame restates every mesh's pose
     // (MeshProjector.cpp:448-461 calls updateGeometry for every mesh, every frame): the unchanged-mesh update
     for (const auto& m : meshes)
@@ -195,3 +340,5 @@ int main(int argc, char** argv)
     ls_tracer_destroy(tr);
     return 0;
 }
+
+}  // namespace

@@ -40,3 +40,15 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "liblsoracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_group_header_symbols_are_exported():
+    # include/lidarshooter_group.h: the C multi-GPU surface (loads without a GPU and without RCCL: dlopen at create)
+    from lidarshooter_amd import groupapi
+    hdr = open(os.path.join(ROOT, "include", "lidarshooter_group.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(ls_group_[a-z0-9_]+)\s*\(", hdr)))
+    assert syms == sorted(groupapi.SYMBOLS)
+    lib = ctypes.CDLL(groupapi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), s

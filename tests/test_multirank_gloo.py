@@ -1,7 +1,9 @@
 """The N > 1 path on CPU: world_size-2 (and 3) gloo process groups run the same shard arithmetic,
 slot layout and single all-gather that bench.py runs over RCCL; the per-rank results come from the
 CPU oracle restricted to the rank's azimuth sector (no GPU here).  The gathered, decoded cloud
-must equal the oracle's full-frame cloud."""
+must equal the oracle's full-frame cloud.  Both implementations of the slot protocol are driven: the Python one
+(lidarshooter_amd/shards.py, what bench.py uses) and the C one (include/lidarshooter_group.h, what lsbench --ranks
+and any C++ caller use) -- and a slot written by one must decode with the other."""
 import os
 import socket
 
@@ -22,10 +24,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, impl="python"):
     import sys
     sys.path.insert(0, ROOT)
     from lidarshooter_amd import shards
+    if impl == "c":                       # the C slot protocol (liblidarshooter_group.so), same call shapes
+        from lidarshooter_amd import groupapi
+        proto_w = groupapi
+        proto_r = shards if rank % 2 else groupapi   # odd ranks decode with the other implementation
+    else:
+        proto_w = proto_r = shards
     from oracle import oracle as O
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     s = O.load_sensor(os.path.join(DATA, "config", "hesai-pandar-XT-32-lidar_0000.json"))
@@ -34,18 +42,21 @@ def _worker(rank, world, port, out_dir):
     ml = [(0, *ground, O.IDENTITY_AFFINE), (1, *ben, O.IDENTITY_AFFINE)]
     full = O.trace_frame(s, ml)
     # this rank's sector: keep the hits whose azimuth column is in [first, first+n)
-    first, n = shards.shard_columns(s.H, world, rank)
+    first, n = proto_w.shard_columns(s.H, world, rank)
+    assert (first, n) == shards.shard_columns(s.H, world, rank)
     col = full["hits"][:, 0] % s.H
     mine = (col >= first) & (col < first + n)
-    cap = shards.slot_capacity(s.V, s.H, world)
-    slot = np.zeros(shards.slot_bytes(cap), np.uint8)
-    shards.write_slot(slot, cap, full["hits"][mine])
+    cap = proto_w.slot_capacity(s.V, s.H, world)
+    assert cap == shards.slot_capacity(s.V, s.H, world) and proto_w.slot_bytes(cap) == shards.slot_bytes(cap)
+    slot = np.full(proto_w.slot_bytes(cap), 0xAB, np.uint8)
+    slot[:shards.HEADER] = 0
+    proto_w.write_slot(slot, cap, full["hits"][mine])
     t_slot = torch.from_numpy(slot)
     gathered = torch.zeros(world * slot.shape[0], dtype=torch.uint8)
     work = shards.all_gather_slots(t_slot, gathered, async_op=True)     # the asynchronous form bench.py uses
     work.wait()
-    hts = shards.decode_gathered(gathered.numpy(), world, cap)
-    hits = hts.view(np.uint32).reshape(-1, 4)
+    hts = proto_r.decode_gathered(gathered.numpy(), world, cap)
+    hits = np.ascontiguousarray(hts).view(np.uint32).reshape(-1, 4)
     order = np.argsort(hits[:, 0], kind="stable")
     # points are rebuilt on the receiving side from (ray, t): xyz = t * dir(ray)
     t = hits[order][:, 3].view(np.float32)
@@ -62,10 +73,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_gather_equals_full_frame(tmp_path, world):
+@pytest.mark.parametrize("world,impl", [(2, "python"), (3, "python"), (2, "c"), (3, "c")])
+def test_sharded_gather_equals_full_frame(tmp_path, world, impl):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), impl), nprocs=world, join=True)
     for r in range(world):
         ok, same, n = open(tmp_path / f"rank{r}.txt").read().split()
         assert ok == "1" and same == "1" and n == "1781"
@@ -82,3 +93,26 @@ def test_shard_columns_partition():
             assert cols == list(range(H))
     assert shards.slot_capacity(128, 4096, 8) == 128 * 512
     assert shards.slot_bytes(10) == 64 + 160
+
+
+def test_c_slot_arithmetic_equals_python():
+    # include/lidarshooter_group.h against lidarshooter_amd/shards.py, without a GPU
+    from lidarshooter_amd import groupapi, shards
+    for H in (150, 4096, 7, 2):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert groupapi.shard_columns(H, world, r) == shards.shard_columns(H, world, r)
+            assert groupapi.slot_capacity(32, H, world) == shards.slot_capacity(32, H, world)
+    assert groupapi.slot_bytes(10) == shards.slot_bytes(10) and groupapi.SLOT_HEADER == shards.HEADER
+    rng = np.random.default_rng(1)
+    cap, world = 40, 3
+    recs = [rng.integers(0, 2**32, size=(n, 4), dtype=np.uint32) for n in (0, 40, 17)]
+    g_c = np.zeros(world * shards.slot_bytes(cap), np.uint8)
+    g_p = g_c.copy()
+    for r, h in enumerate(recs):
+        groupapi.write_slot(g_c[r * shards.slot_bytes(cap):(r + 1) * shards.slot_bytes(cap)], cap, h)
+        shards.write_slot(g_p[r * shards.slot_bytes(cap):(r + 1) * shards.slot_bytes(cap)], cap, h)
+    assert np.array_equal(g_c, g_p)
+    want = np.concatenate(recs)
+    assert np.array_equal(groupapi.decode_gathered(g_p, world, cap), want)
+    assert np.array_equal(shards.decode_gathered(g_c, world, cap).view(np.uint32).reshape(-1, 4), want)
