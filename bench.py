@@ -66,6 +66,11 @@ def parse_args():
                          "a transform-only update: the library must then assume new vertices and redo its per-block bounds")
     ap.add_argument("--no-cull", action="store_true", help="LS_OPT_BLOCK_CULL off")
     ap.add_argument("--cull", action="store_true", help="LS_OPT_BLOCK_CULL on (default: the library's auto rule)")
+    ap.add_argument("--multi", default="interleaved", choices=["interleaved", "sharded"],
+                    help="N > 1: which way of spreading the frame stream over the GPUs is reported as `value` (the other one is "
+                         "measured too and reported under also_measured): interleaved = whole frames per rank, no collective "
+                         "(weak scaling: K frames per rank); sharded = azimuth sectors of every frame + one all-gather of "
+                         "hit-record slots per frame (strong scaling: K frames in all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the ITracer-adapter (host buffers, PointCloud2) legs")
     ap.add_argument("--cpu-frames", type=int, default=6)
@@ -282,16 +287,39 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    if world == 1 or args.workload == "cfg5":
+        out = measure(args, rank, world, device, dev_index, rehearsal, None)
+    else:
+        # N > 1, one scene: two ways to spread a stream of frames over the GPUs, both measured, args.multi is `value`
+        other = "sharded" if args.multi == "interleaved" else "interleaved"
+        out = measure(args, rank, world, device, dev_index, rehearsal, args.multi)
+        alt = measure(args, rank, world, device, dev_index, rehearsal, other)
+        if rank == 0:
+            out["also_measured"] = {k: alt.get(k) for k in ("value", "unit", "ms_per_step", "frames_per_s", "scaling", "gathered_points_rank0",
+                                                             "host_enqueue_ms_per_step", "timing")}
+            out["also_measured"]["parallelism"] = alt["config"]["parallelism"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure(args, rank, world, device, dev_index, rehearsal, multi):
+    """One measurement.  multi: None (single GPU, or cfg5's replicas), "sharded" (azimuth sectors + one all-gather of
+    hit-record slots per frame: a frame's latency is what is split) or "interleaved" (rank g traces the whole raster of
+    frames f with f mod N == g, nothing is exchanged on the frame path: the stream's throughput is what is multiplied)."""
     sensor, meshes = build_workload(args.workload, rank)
+    pipeline_arg = args.pipeline
     if args.pipeline == 0:
         args.pipeline = 2 if sum(t.shape[0] for _, _, t in meshes) >= 200000 else 1
-    replicas = args.workload == "cfg5"               # every rank traces its own full sensor: no shards, no collective
+    replicas = args.workload == "cfg5"               # every rank traces its own full sensor (own pose): no shards, no collective
+    independent = replicas or multi == "interleaved" # every rank traces whole frames of its own: nothing is exchanged
     if replicas:  # the AffineMesh pose rule played over config/trajectory.json, scaled to keep ben inside the scene
         poses = hostapi.trajectory_play(os.path.join(DATA, "config", "trajectory.json"), 0.1)
         affines = [_affine(p[:3] * np.float32(0.05), p[3:]) for p in poses]
     V, H = int(sensor["vertical"].shape[0]), int(sensor["h_count"])
-    first_az, n_az = (0, H) if replicas else shards.shard_columns(H, world, rank)
-    cap = V * H if replicas else shards.slot_capacity(V, H, world)  # records per slot
+    first_az, n_az = (0, H) if independent else shards.shard_columns(H, world, rank)
+    cap = V * H if independent else shards.slot_capacity(V, H, world)  # records per slot
 
     tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"],
                      device=dev_index)
@@ -305,7 +333,7 @@ def main():
     # a dedicated (non-default) stream shared by the tracer's kernels and, through torch, by RCCL's
     # stream dependencies: the all-gather of frame i is ordered after frame i's pack kernel
     stream = torch.cuda.Stream(device)
-    if world > 1:            # a single GPU has no collective to order: the tracer keeps its own stream
+    if world > 1 and not independent:   # no collective to order otherwise: the tracer keeps its own stream
         tr.setStream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
 
@@ -317,8 +345,8 @@ def main():
         assert tr.addGeometry(name, v.shape[0], t.shape[0]) >= 0
         d_meshes.append((name, dv, dt))
     ident = capi.IDENTITY_AFFINE
-    single = world == 1 or replicas
-    pipeline = single_gpu_pipeline = (world == 1 or replicas) and not args.no_pipeline and engine == "projection"
+    single = world == 1 or independent
+    pipeline = single_gpu_pipeline = single and not args.no_pipeline and engine == "projection"
     if single:
         # single GPU: [n_points u32 | pad to 64 B | points 32*cap | hits 16*cap] in caller-owned buffers, two of
         # them: with two frames in flight (LS_OPT_PIPELINE) consecutive frames write alternate buffers
@@ -605,7 +633,7 @@ def main():
                                                                                 vbytes / 1e6, vbytes / 55e3)}
         at.close()
 
-    total_rays = V * H * (world if replicas else 1)
+    total_rays = V * H * (world if independent else 1)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays * args.steps / elapsed / 1e6
     trace_ms = tm["trace"]
@@ -658,7 +686,7 @@ def main():
                    "cfg5": "Mrays/s (one 128ch x 4096az sensor per GPU over a shared 10M-tri scene + animated instance)",
                    "xt32": "Mrays/s (XT-32 over ground+ben)"}[args.workload],
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if independent else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"syn128x1m": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)",
                                 "syn128x10m": "SYN-128 x SYN-10M (9,998,244 tris)",
@@ -676,7 +704,11 @@ def main():
                                   f"hit-record slots per frame (overlapped with the next "
                                   f"{'two frames; two frames in flight per rank' if lagged else 'frame'}), cloud rebuilt on every rank"
                    if not single else ("single GPU" if world == 1 else
-                                       f"{world} independent replicas (one sensor pose per GPU), no collective")},
+                                       (f"{world} independent replicas (one sensor pose per GPU), no collective" if replicas else
+                                        f"frames interleaved over {world} GPUs: every rank traces the whole raster of its own frames "
+                                        f"(K per rank in the timed region, {world}K in all), scene replica per GPU, nothing exchanged "
+                                        f"on the frame path (a 20 us frame is bound by launch and memory latency: splitting it costs "
+                                        f"more in the collective than it saves)"))},
         "frames_per_s": args.steps / elapsed,
         "timing": {"windows": len(wins), "frames_per_window": args.steps, "window_ms_min_median_max":
                    [window_ms[0], window_ms[len(window_ms) // 2], window_ms[-1]], "reported": "median window",
@@ -715,11 +747,11 @@ def main():
         out["trace_only_mrays_per_s"] = shard_rays / trace_only_s / 1e6
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not replicas:
         out["cpu_baseline"] = cpu_baseline(sensor, meshes, args.cpu_frames, total_rays)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     tr.close()
-    if world > 1:
-        dist.destroy_process_group()
+    args.pipeline = pipeline_arg
+    torch.cuda.set_stream(torch.cuda.default_stream(device))
+    gc.enable()
+    return out
 
 
 if __name__ == "__main__":
