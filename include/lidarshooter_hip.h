@@ -263,7 +263,8 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_BLOCK_CULL 10    /* projection engine, meshes of 524 288 triangles or more: keep the mesh in Morton order with a
                                  *    bound per 4 triangles and drop, before their indices are read, the groups that no ring
                                  *    of the raster and no column of the shard can meet.  0 off, 1 on, 2 (default) auto: on for
-                                 *    azimuth shards narrower than half a turn.  Identical results.                       */
+                                 *    geometries of 2 000 000 triangles or more (where the kernel is bandwidth-bound).
+                                 *    Identical results.                                                                  */
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */

@@ -867,15 +867,15 @@ int materialize_scene(ls_tracer *tr, bool with_maxabs)
     return LS_OK;
 }
 
-// Group culling pays when k_project is bandwidth-bound or most groups go.  Measured on MI355X (128 x 4096 rays): at 10 M
-// triangles the frame drops from 87 to 59 us (three frames in flight); at 1 M the kernel is latency-bound, the cull pass
-// (~10 us) costs what the denser k_project saves (21 -> 15.6 us), so auto leaves it off there; an azimuth shard of an
-// eighth of a turn keeps 4 % of a ground mesh's groups.  auto = the geometry has 2 M triangles or more, or the handle is
-// an azimuth shard narrower than half a turn.
+// Group culling pays when k_project is bandwidth-bound.  Measured on MI355X (128 x 4096 rays, rocprofv3): at 10 M
+// triangles the frame drops from 87 to 59 us (three frames in flight); at 1 M k_project itself drops from 21 to 15.6 us
+// (43 % of the groups survive, its lanes are 2.3 x denser) but the cull pass in front of it takes ~10 us of pure
+// latency (table staging, bound loads, one contended atomic per workgroup), and an 8-way azimuth shard's 8.5 + 9.7 us
+// lose against 12.8 us without it.  auto = geometries of 2 M triangles or more.
 bool cull_enabled(const ls_tracer *tr, const Geometry &g)
 {
     if (tr->opt_block_cull != 2) return tr->opt_block_cull != 0;
-    return g.n_tris >= 2000000u || project_params(tr).sector_on != 0;
+    return g.n_tris >= 2000000u;
 }
 
 // Group-culling data of one geometry, brought up to date (stream-ordered on the handle's stream).

@@ -39,6 +39,36 @@ def pmc(dirname, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
+def overlap_excerpt(src, out):
+    """A short excerpt of the kernel trace (start / end timestamps, hardware queue) around a moment at which frames on
+    different queues overlap: the evidence that the reported step time is a throughput with several frames in flight,
+    while `roofline.kernel_ms` is one kernel on its own."""
+    rows = []
+    for f in glob.glob(os.path.join(src, "stats", "*_kernel_trace.csv")):
+        for row in csv.DictReader(open(f)):
+            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), short(row["Kernel_Name"]),
+                         row.get("Queue_Id", ""), row.get("Stream_Id", "")))
+    rows.sort()
+    proj = [i for i, r in enumerate(rows) if r[2].startswith("k_project<false")]
+    best = None
+    for n, i in enumerate(proj[len(proj) // 2:]):          # steady state: second half of the run
+        live = [j for j in range(max(0, i - 12), i + 1) if rows[j][0] <= rows[i][0] < rows[j][1]]
+        if len({rows[j][3] for j in live}) >= 2 and sum(1 for j in live if rows[j][2].startswith("k_project<false")) >= 2:
+            best = i
+            break
+    if best is None:
+        return
+    lo, hi = max(0, best - 6), min(len(rows), best + 10)
+    t0 = rows[lo][0]
+    with open(out + "_overlap_excerpt.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "queue", "stream", "start_us", "end_us", "duration_us", "kernels_in_flight_at_start"])
+        for j in range(lo, hi):
+            st, en, name, q, sid = rows[j]
+            live = sum(1 for k in range(max(0, j - 12), j + 1) if rows[k][0] <= st < rows[k][1])
+            w.writerow([name, q, sid, f"{(st - t0) / 1e3:.2f}", f"{(en - t0) / 1e3:.2f}", f"{(en - st) / 1e3:.2f}", live])
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
@@ -64,6 +94,7 @@ def main():
     json.dump({"note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE reads 1/2)",
                "kernel_source_sha": bench.kernel_source_sha(),   # bench.py reports `traffic` only while the sources still hash to this
                "kernels": hbm}, open(out + "_hbm.json", "w"), indent=1)
+    overlap_excerpt(src, out)
     for r in rows[:12]:
         print(r[0], r[1], r[3], r[4])
     for k, v in hbm.items():

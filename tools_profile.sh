@@ -2,12 +2,12 @@
 # Profiling recipe used for profiles/: kernel trace + stats, then HBM counters in separate passes.
 # Usage (on the GPU box, from the repo root):  bash tools_profile.sh <tag> [bench args...]
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 10 --no-cpu-baseline $*"
+ARGS="--steps 50 --warmup 10 --no-cpu-baseline --no-dropin $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_stats.json" 2> "$OUT/stats.err" || echo "stats pass failed"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o "$TAG" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err" || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o "$TAG" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_write.json" 2> "$OUT/write.err" || echo "write pass failed"
