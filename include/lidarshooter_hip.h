@@ -34,7 +34,7 @@ typedef enum ls_status {
     LS_ERR_INVALID_ARGUMENT = -2,
     LS_ERR_UNKNOWN_GEOMETRY = -3, /* name not registered (EmbreeTracer.cpp:224-225 returns -1 for remove) */
     LS_ERR_DUPLICATE_GEOMETRY = -4,
-    LS_ERR_UNSUPPORTED_TYPE = -5, /* only triangles (EmbreeTracer.cpp:200-201 returns 0/false there) */
+    LS_ERR_UNSUPPORTED_TYPE = -5, /* neither triangles nor quads (EmbreeTracer.cpp:200-201 returns 0/false there) */
     LS_ERR_HIP = -6,              /* a HIP runtime call failed; message in ls_last_error */
     LS_ERR_NO_DEVICE = -7,        /* no usable gfx950 device: the product never falls back to the CPU */
     LS_ERR_NOT_COMMITTED = -8,
@@ -45,7 +45,8 @@ typedef enum ls_status {
 /* Geometry element types; values follow Embree's RTCGeometryType so the adapter can pass the
  * enum it receives through ITracer::addGeometry (ITracer.hpp:50) unchanged. */
 #define LS_GEOMETRY_TYPE_TRIANGLE 0 /* RTC_GEOMETRY_TYPE_TRIANGLE */
-#define LS_GEOMETRY_TYPE_QUAD 1     /* RTC_GEOMETRY_TYPE_QUAD: rejected */
+#define LS_GEOMETRY_TYPE_QUAD 1     /* RTC_GEOMETRY_TYPE_QUAD (EmbreeTracer.cpp:179-198): 4 indices per element; traced as
+                                     * Embree does, as the triangle pair (v0,v1,v3), (v2,v3,v1); ls_hit.prim = quad index */
 
 /* Sensor description = what LidarDevice holds after loadConfiguration()
  * (LidarDevice.cpp:482-633, :758-822).  The adapter fills it from its LidarDevice; the repo's own
@@ -125,7 +126,7 @@ int ls_remove_geometry(ls_tracer *tr, const char *name);
  * MeshTransformer.cpp:142-205).  affine3x4: row-major [linear | translation].  verts: n_vertices
  * records of vert_stride bytes whose first 12 bytes are x,y,z float32 (pcl cloud.data with
  * point_step, MeshTransformer.cpp:176-181).  tri_idx: 3*n_elements vertex indices (polygons[i].vertices,
- * MeshTransformer.cpp:512-518); NULL keeps the indices of the previous update.  Host pointers; the
+ * MeshTransformer.cpp:512-518; 4*n_elements for a quad geometry, :521-552); NULL keeps the indices of the previous update.  Host pointers; the
  * caller may reuse them as soon as the call returns (MeshProjector.cpp:448-461 does).  By default the copy
  * goes straight from the caller's pageable memory at PCIe rate and the call returns when the memory has been
  * read; with LS_UPLOAD_MODE=0 in the environment the library's worker threads stage it through pinned memory
@@ -260,6 +261,9 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
                                  *    adapter only needs the 32-byte points.                                   */
 #define LS_OPT_DEBUG_FAULT 9    /* test hook: 1 makes the next pipelined frame publish a wrong epoch, so that the
                                  *    chained prefix gives up and the device status word is raised (one frame).  */
+#define LS_OPT_BVH_REFIT 11     /* BVH engine: 1 (default) a commit after which only vertices / poses differ refits the
+                                 *    hierarchy (OptixTracer.cpp:532-535 OPERATION_UPDATE): no key pass, no sort; 0: always
+                                 *    a full build.  Identical results.                                                   */
 #define LS_OPT_BLOCK_CULL 10    /* projection engine, meshes of 524 288 triangles or more: keep the mesh in Morton order with a
                                  *    bound per 4 triangles and drop, before their indices are read, the groups that no ring
                                  *    of the raster and no column of the shard can meet.  0 off, 1 on, 2 (default) auto: on for
@@ -286,6 +290,7 @@ int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
 #define LS_INFO_DEVICE_STATUS 3      /* sticky device status word (0 = ok); read-and-clear, synchronises          */
 #define LS_INFO_HOST_THREADS 4       /* worker threads of the host copy pool                                     */
 #define LS_INFO_AZIMUTH_COUNT 5      /* H: azimuth columns of the sensor's full raster (whatever the shard)       */
+#define LS_INFO_LAST_COMMIT_REFIT 6  /* BVH engine: 1 if the last commitScene refitted instead of rebuilding      */
 long ls_get_info(ls_tracer *tr, int what);
 
 /* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded

@@ -79,6 +79,7 @@ public:
         if (rc == LS_ERR_UNSUPPORTED_TYPE) return 0;   // EmbreeTracer.cpp:200-201 `return false`
         if (rc < 0) return rc;
         MeshState state;
+        state.verticesPerElement = _geometryType == RTC_GEOMETRY_TYPE_QUAD ? 4u : 3u;
         state.numVertices = static_cast<std::size_t>(_numVertices);
         state.numElements = static_cast<std::size_t>(_numElements);
         _meshes[_meshName] = std::move(state);
@@ -185,7 +186,7 @@ public:
 
 private:
     struct MeshState {
-        std::size_t numVertices = 0, numElements = 0;
+        std::size_t numVertices = 0, numElements = 0, verticesPerElement = 3;   // 4: RTC_GEOMETRY_TYPE_QUAD
         bool haveVertices = false, haveElements = false;
         // identity of the data handed over last time
         const void* polygonStorage = nullptr;
@@ -273,14 +274,13 @@ private:
         const std::uint64_t polygonProbe = probePolygons(*_mesh);
         if (!st.haveElements || st.polygonStorage != static_cast<const void*>(_mesh->polygons.data()) ||
             st.polygonCount != _mesh->polygons.size() || st.polygonProbe != polygonProbe) {
-            st.flat.resize(st.numElements * 3);
+            const std::size_t per = st.verticesPerElement;   // MeshTransformer.cpp:499-538: 3 for triangles, 4 for quads
+            st.flat.resize(st.numElements * per);
             std::size_t k = 0;
             for (const auto& polygon : _mesh->polygons) {
-                if (polygon.vertices.size() != 3)
-                    throw TraceException(__FILE__, "Geometry does not match element vertex count", 1);
-                st.flat[k++] = static_cast<std::uint32_t>(polygon.vertices[0]);
-                st.flat[k++] = static_cast<std::uint32_t>(polygon.vertices[1]);
-                st.flat[k++] = static_cast<std::uint32_t>(polygon.vertices[2]);
+                if (polygon.vertices.size() != per)
+                    throw TraceException(__FILE__, "Geometry does not match element vertex count", per == 3 ? 1 : 2);
+                for (std::size_t c = 0; c < per; ++c) st.flat[k++] = static_cast<std::uint32_t>(polygon.vertices[c]);
             }
             indices = st.flat.data();
         }

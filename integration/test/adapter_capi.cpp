@@ -103,8 +103,18 @@ int lsa_probe_sensor(const char* sensor_config, unsigned* vh2, float* tables4, u
 }
 
 // a mesh as pcl::io::loadPolygonFileSTL leaves it: pcl::PointXYZ records (16 bytes: x, y, z, pad), triangles
+int lsa_mesh_from_arrays_ex(lsa_ctx* c, const char* name, const float* xyz, unsigned n_vertices, const unsigned* elements,
+                            unsigned n_elements, unsigned point_step, unsigned vertices_per_element);
+
 int lsa_mesh_from_arrays(lsa_ctx* c, const char* name, const float* xyz, unsigned n_vertices, const unsigned* triangles,
                          unsigned n_triangles, unsigned point_step)
+{
+    return lsa_mesh_from_arrays_ex(c, name, xyz, n_vertices, triangles, n_triangles, point_step, 3);
+}
+
+// vertices_per_element 4: a quad mesh (pcl::Vertices with four indices each)
+int lsa_mesh_from_arrays_ex(lsa_ctx* c, const char* name, const float* xyz, unsigned n_vertices, const unsigned* triangles,
+                            unsigned n_triangles, unsigned point_step, unsigned vertices_per_element)
 {
     if (point_step < 12) return -2;
     TrackedMesh tm;
@@ -117,9 +127,11 @@ int lsa_mesh_from_arrays(lsa_ctx* c, const char* name, const float* xyz, unsigne
     cloud.data.assign(static_cast<std::size_t>(n_vertices) * point_step, 0);
     for (unsigned i = 0; i < n_vertices; ++i) std::memcpy(cloud.data.data() + static_cast<std::size_t>(i) * point_step, xyz + 3 * i, 12);
     tm.mesh->polygons.resize(n_triangles);
-    for (unsigned i = 0; i < n_triangles; ++i)
-        tm.mesh->polygons[i].vertices = {static_cast<pcl::index_t>(triangles[3 * i]), static_cast<pcl::index_t>(triangles[3 * i + 1]),
-                                         static_cast<pcl::index_t>(triangles[3 * i + 2])};
+    for (unsigned i = 0; i < n_triangles; ++i) {
+        tm.mesh->polygons[i].vertices.resize(vertices_per_element);
+        for (unsigned k = 0; k < vertices_per_element; ++k)
+            tm.mesh->polygons[i].vertices[k] = static_cast<pcl::index_t>(triangles[vertices_per_element * i + k]);
+    }
     c->meshes[name] = tm;
     return 0;
 }

@@ -31,6 +31,7 @@ def load() -> C.CDLL:
     L.lsa_destroy.restype = None
     L.lsa_probe_sensor.argtypes = [C.c_char_p, u32p, f32p, C.c_uint, f32p, f32p, f32p, f32p]
     L.lsa_mesh_from_arrays.argtypes = [vp, C.c_char_p, f32p, C.c_uint, u32p, C.c_uint, C.c_uint]
+    L.lsa_mesh_from_arrays_ex.argtypes = [vp, C.c_char_p, f32p, C.c_uint, u32p, C.c_uint, C.c_uint, C.c_uint]
     L.lsa_mesh_from_stl.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.lsa_mesh_vertices.argtypes = [vp, C.c_char_p]
     L.lsa_mesh_vertices.restype = C.c_uint
@@ -110,9 +111,9 @@ class AdapterTracer:
 
     def meshFromArrays(self, name: str, verts, tris, point_step: int = 16):
         v = np.ascontiguousarray(verts, np.float32)
-        t = np.ascontiguousarray(tris, np.uint32)
-        return self._check(self.L.lsa_mesh_from_arrays(self.c, name.encode(), _f32p(v), v.shape[0],
-                                                       t.ctypes.data_as(C.POINTER(C.c_uint)), t.shape[0], point_step),
+        t = np.ascontiguousarray(tris, np.uint32)   # [n,3] triangles or [n,4] quads
+        return self._check(self.L.lsa_mesh_from_arrays_ex(self.c, name.encode(), _f32p(v), v.shape[0],
+                                                          t.ctypes.data_as(C.POINTER(C.c_uint)), t.shape[0], point_step, t.shape[1]),
                            "lsa_mesh_from_arrays")
 
     def setVertices(self, name: str, verts, seq: int = 0):

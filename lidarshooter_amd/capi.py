@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("LS_LIB_PATH") or os.path.join(_HERE, "liblidarshooter
 INVALID = 0xFFFFFFFF
 
 LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPELINE = 1, 2, 3, 5, 6
-LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL = 7, 8, 9, 10
+LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL, LS_OPT_BVH_REFIT = 7, 8, 9, 10, 11
+LS_INFO_LAST_COMMIT_REFIT = 6
 LS_INFO_CONCURRENT_STREAMS, LS_INFO_PIPELINE_MODE, LS_INFO_DEVICE_STATUS, LS_INFO_HOST_THREADS, LS_INFO_AZIMUTH_COUNT = 1, 2, 3, 4, 5
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
 STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "trace_aux", "pack")
@@ -204,7 +205,7 @@ class Tracer:
             verts = np.ascontiguousarray(verts, np.float32)
             stride = 12
         tp = None
-        if tris is not None:
+        if tris is not None:   # uint32[n,3] triangles, or [n,4] quads for a geometry added with geometry_type=1
             tris = np.ascontiguousarray(tris, np.uint32)
             tp = tris.ctypes.data
         return self._check(self.L.ls_update_geometry(self.h, name.encode(), _f32p(A), verts.ctypes.data, stride, tp),

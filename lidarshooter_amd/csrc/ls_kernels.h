@@ -57,6 +57,7 @@ struct GeomTable {
     uint32_t n;
     const uint32_t *tri_first;  // device, [n+1] ascending global triangle id offsets
     const uint32_t *geom_ids;   // device, [n]
+    const uint32_t *prim_shift; // device, [n]: 1 for quad geometries (two triangles per element, primID = triangle / 2), else 0
 };
 
 // Ray queues of the persistent trace kernel: the shard's azimuth columns are cut into kQueues
@@ -134,6 +135,8 @@ static_assert(64 % LS_CULL_GROUP == 0, "a wave takes a whole number of groups");
 void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t n, const float *affine12,
                       const float *rinv9, const float *t3, float *out_xyz, uint32_t *d_maxabs_bits);
 void launch_rebase(hipStream_t s, const uint32_t *idx, uint32_t n_idx, uint32_t vbase, uint32_t *out);
+// RTC_GEOMETRY_TYPE_QUAD (EmbreeTracer.cpp:179-198): quad (v0,v1,v2,v3) -> triangles (v0,v1,v3), (v2,v3,v1), Embree's split
+void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t n_quads, uint32_t *tri_idx);
 void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint32_t ntris,
                    const uint32_t *d_maxabs_bits, uint32_t *keys, uint32_t *vals);
 size_t sort_temp_bytes(uint32_t n);

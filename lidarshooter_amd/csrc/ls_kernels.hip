@@ -57,6 +57,16 @@ __global__ __launch_bounds__(kBlock) void k_transform(const uint8_t *__restrict_
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_quads_to_triangles(const uint32_t *__restrict__ q, uint32_t n, uint32_t *__restrict__ t)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v0 = q[4 * (size_t)i], v1 = q[4 * (size_t)i + 1], v2 = q[4 * (size_t)i + 2], v3 = q[4 * (size_t)i + 3];
+    uint32_t *o = t + 6 * (size_t)i;
+    o[0] = v0; o[1] = v1; o[2] = v3;
+    o[3] = v2; o[4] = v3; o[5] = v1;
+}
+
 __global__ __launch_bounds__(kBlock) void k_rebase(const uint32_t *__restrict__ idx, uint32_t n, uint32_t vbase,
                                                    uint32_t *__restrict__ out)
 {
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         const uint32_t mid = (lo + hi) >> 1;
         if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
     }
-    hits[dst] = make_uint4(v * tb.H + h, gt.geom_ids[lo], gid - gt.tri_first[lo], __float_as_uint(t));
+    hits[dst] = make_uint4(v * tb.H + h, gt.geom_ids[lo], (gid - gt.tri_first[lo]) >> gt.prim_shift[lo], __float_as_uint(t));
 }
 
 // Debug view of the projection engine's result: dense per-ray (t, global triangle id) arrays from
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_from_hits(SensorTables tb, con
     }
     const uint32_t q = v * tb.naz + (h - tb.az0);
     t[q] = __uint_as_float(rec.w);
-    gid[q] = gt.tri_first[lo] + rec.z;
+    gid[q] = gt.tri_first[lo] + (rec.z << gt.prim_shift[lo]);   // a quad's first triangle stands for the quad
 }
 
 // Sensor frame -> world frame for the x,y,z of 32-byte points: p_world = R * (A * p) + t
@@ -775,6 +785,12 @@ void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, c
     else
         hipLaunchKernelGGL((k_trace<false, 0>), dim3(grid), dim3(kBlock), 0, s, tb, rq, nodes, records, nleaves,
                            leaf_size, ntris, t_out, gid_out, spill, visit_counts);
+}
+
+void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t n_quads, uint32_t *tri_idx)
+{
+    if (!n_quads) return;
+    hipLaunchKernelGGL(k_quads_to_triangles, dim3(blocks_for(n_quads)), dim3(kBlock), 0, s, quad_idx, n_quads, tri_idx);
 }
 
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts)

@@ -32,6 +32,9 @@ struct Geometry {
     std::string name;
     int id = -1;
     uint32_t n_verts = 0, n_tris = 0;
+    bool quad = false;          // RTC_GEOMETRY_TYPE_QUAD: n_elems quads, traced as n_tris = 2 n_elems triangles
+    uint32_t n_elems = 0;       // elements as registered by addGeometry (= n_tris for triangle geometries)
+    uint32_t *d_quad_idx = nullptr;   // 4*n_elems indices as handed over (converted into d_idx)
     void *d_raw = nullptr;      // vertex records as uploaded (n_verts * stride bytes)
     size_t raw_cap = 0;
     uint32_t stride = 0;
@@ -278,6 +281,10 @@ struct ls_tracer {
     size_t h_cap = 0;  // records
     uint32_t *h_n_points = nullptr;
     bool traced = false;
+    int opt_bvh_refit = 1;       // LS_OPT_BVH_REFIT
+    bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
+    uint32_t bvh_order_tris = 0;
+    bool last_commit_refit = false;
     int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (on for azimuth shards narrower than half a turn)
     DevBuf<uint32_t> cull_list;  // three survivor lists (one per frame that can be in flight) of cull_chunks entries
     uint32_t cull_chunks = 0;
@@ -772,7 +779,17 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         g.stride = stride;
         g.has_verts = true;
         g.bounds_stale = true;   // the caller's buffer may hold anything now
-        if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; }
+        if (idx && g.quad) {
+            // quads are traced as triangle pairs: the caller's indices are converted into a library-owned array
+            if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), (size_t)g.n_tris * 12 + 4));
+            const int rc = order_after_projects(tr);
+            if (rc) return rc;
+            ++tr->main_epoch;
+            ls::launch_quads_to_triangles(tr->stream, idx, g.n_elems, g.d_idx);
+            g.shared_idx = nullptr;
+            if (!g.has_idx) tr->layout_dirty = true;
+            g.has_idx = true; g.idx_dirty = true; g.order_stale = true;
+        } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; }
         return LS_OK;
     }
     if (!verts && !idx) return LS_OK;   // transform only: nothing is copied, nothing to order
@@ -809,15 +826,18 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
     if (idx) {
         g.shared_idx = nullptr;
         g.order_stale = true;
-        const size_t bytes = (size_t)g.n_tris * 12;
-        if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), bytes ? bytes : 4));
+        const size_t bytes = g.quad ? (size_t)g.n_elems * 16 : (size_t)g.n_tris * 12;
+        if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), (size_t)g.n_tris * 12 + 4));
+        if (g.quad && !g.d_quad_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_quad_idx), bytes ? bytes : 4));
+        uint32_t *dst = g.quad ? g.d_quad_idx : g.d_idx;
         if (bytes) {
             if (from_host) {
-                const int rc = stage_upload(tr, g.h_stage_i, g.stage_i_cap, g.ev_stage_i, g.d_idx, idx, bytes);
+                const int rc = stage_upload(tr, g.h_stage_i, g.stage_i_cap, g.ev_stage_i, dst, idx, bytes);
                 if (rc) return rc;
             } else {
-                LS_HIP(hipMemcpyAsync(g.d_idx, idx, bytes, kind, tr->stream));
+                LS_HIP(hipMemcpyAsync(dst, idx, bytes, kind, tr->stream));
             }
+            if (g.quad) ls::launch_quads_to_triangles(tr->stream, g.d_quad_idx, g.n_elems, g.d_idx);   // Embree's split of a quad
         }
         if (!g.has_idx) tr->layout_dirty = true;
         g.has_idx = true;
@@ -830,6 +850,8 @@ void free_geometry(Geometry &g)
 {
     if (g.d_raw) (void)hipFree(g.d_raw);
     if (g.d_idx) (void)hipFree(g.d_idx);
+    if (g.d_quad_idx) (void)hipFree(g.d_quad_idx);
+    g.d_quad_idx = nullptr;
     if (g.h_stage_v) (void)hipHostFree(g.h_stage_v);
     if (g.h_stage_i) (void)hipHostFree(g.h_stage_i);
     if (g.d_perm) (void)hipFree(g.d_perm);
@@ -898,6 +920,7 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
         if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
         if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
         if (!tr->d_aabb6) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_aabb6), 32));
+        tr->bvh_order_valid = false;   // keys_a / keys_b / vals_a are the scratch of this pass
         ls::launch_mesh_order(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.n_verts, g.idx(), nt, tr->d_aabb6,
                               tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->sort_temp.p, tr->sort_temp.cap, g.d_perm, g.d_idx_sorted);
         g.order_stale = false;
@@ -957,6 +980,7 @@ int commit_locked(ls_tracer *tr)
         LS_HIP(hipStreamSynchronize(tr->stream));
         std::vector<uint32_t> table(tfirst);
         for (int id : ids) table.push_back((uint32_t)id);
+        for (const Geometry *ge : order) table.push_back(ge->quad ? 1u : 0u);   // primID = triangle >> shift
         if ((rc = ensure(tr, tr->geom_table, table.size()))) return rc;
         LS_HIP(hipMemcpyAsync(tr->geom_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, tr->stream));
         LS_HIP(hipStreamSynchronize(tr->stream));  // `table` is a stack temporary
@@ -980,7 +1004,15 @@ int commit_locked(ls_tracer *tr)
     const bool want_bvh = !use_projection(tr);
     mark(tr, 0);
     if (want_bvh) {
-        // BVH engine: transform every geometry into the sensor frame, then a full LBVH rebuild
+        // BVH engine: transform every geometry into the sensor frame, then the LBVH: a full build (Morton keys, radix
+        // sort, leaves, range tree, hierarchy), or -- when only vertices / poses changed since the last build, the case
+        // OptixTracer handles with OPTIX_BUILD_OPERATION_UPDATE (OptixTracer.cpp:532-535) -- a REFIT: the triangles keep
+        // their Morton order and the radix tree its topology (both come from the sorted keys, which stay), records and
+        // every box are recomputed from the new vertices (leaf boxes, aligned-range tree, both child boxes of every
+        // node by range query).  Always a valid BVH; the sort and the key pass (half of the build) are not run.
+        bool any_idx_dirty = false;
+        for (const Geometry *ge : order) any_idx_dirty = any_idx_dirty || ge->idx_dirty;
+        const bool refit = tr->opt_bvh_refit && !relayout && !any_idx_dirty && tr->bvh_order_valid && tr->bvh_order_tris == nt;
         if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
         if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
         if ((rc = ensure(tr, tr->vals_a, nt))) return rc;
@@ -991,10 +1023,13 @@ int commit_locked(ls_tracer *tr)
         if ((rc = ensure(tr, tr->range_boxes, 2 * (size_t)tr->range_entries + 2))) return rc;
         if ((rc = materialize_scene(tr, true))) return rc;
         mark(tr, 1);
-        ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
+        if (!refit) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
         mark(tr, 2);
-        ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
+        if (!refit) ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
         mark(tr, 3);
+        tr->bvh_order_valid = true;
+        tr->bvh_order_tris = nt;
+        tr->last_commit_refit = refit;
         ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->range_boxes.p);
         mark(tr, 4);
         ls::launch_range_tree(s, tr->rt, tr->range_boxes.p);
@@ -1154,6 +1189,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         gt.n = (uint32_t)tr->slot_geom_ids.size();
         gt.tri_first = tr->geom_table.p;
         gt.geom_ids = tr->geom_table.p + gt.n + 1;
+        gt.prim_shift = gt.geom_ids + gt.n;
         if (pipelined) {
             // one launch: this frame's k_project workgroups + the previous frame's finish + pack workgroups
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, nullptr,
@@ -1227,6 +1263,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         gt.n = (uint32_t)tr->slot_geom_ids.size();
         gt.tri_first = tr->geom_table.p;
         gt.geom_ids = tr->geom_table.p + gt.n + 1;
+        gt.prim_shift = gt.geom_ids + gt.n;
         ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n, compact);
         tr->traced_projection = false;
         mark(tr, 10);
@@ -1421,7 +1458,9 @@ int ls_add_geometry(ls_tracer *tr, const char *name, int geometry_type, int n_ve
 {
     LS_ENTER(tr);
     if (!name || n_vertices < 0 || n_elements < 0) return fail(tr, LS_ERR_INVALID_ARGUMENT, "bad argument");
-    if (geometry_type != LS_GEOMETRY_TYPE_TRIANGLE) return fail(tr, LS_ERR_UNSUPPORTED_TYPE, "only triangle geometries are supported");
+    if (geometry_type != LS_GEOMETRY_TYPE_TRIANGLE && geometry_type != LS_GEOMETRY_TYPE_QUAD)
+        return fail(tr, LS_ERR_UNSUPPORTED_TYPE, "only triangle and quad geometries are supported");   // EmbreeTracer.cpp:200-201
+    if (geometry_type == LS_GEOMETRY_TYPE_QUAD && n_elements > 0x3FFFFFFF) return fail(tr, LS_ERR_OUT_OF_RANGE, "too many quads");
     if (tr->geoms.count(name)) return fail(tr, LS_ERR_DUPLICATE_GEOMETRY, "geometry key already exists");
     // lowest free id, like rtcAttachGeometry (EmbreeTracer.cpp:205)
     std::vector<int> used;
@@ -1436,7 +1475,9 @@ int ls_add_geometry(ls_tracer *tr, const char *name, int geometry_type, int n_ve
     g.name = name;
     g.id = id;
     g.n_verts = (uint32_t)n_vertices;
-    g.n_tris = (uint32_t)n_elements;
+    g.quad = geometry_type == LS_GEOMETRY_TYPE_QUAD;
+    g.n_elems = (uint32_t)n_elements;
+    g.n_tris = g.quad ? 2u * (uint32_t)n_elements : (uint32_t)n_elements;
     tr->geoms.emplace(name, g);
     tr->geometry_count += 1;
     tr->layout_dirty = true;
@@ -1558,7 +1599,7 @@ long ls_element_count(ls_tracer *tr, const char *name)
     LS_ENTER(tr);
     auto it = tr->geoms.find(name ? name : "");
     if (it == tr->geoms.end()) return fail(tr, LS_ERR_UNKNOWN_GEOMETRY, "geometry key does not exist");
-    return (long)it->second.n_tris;
+    return (long)it->second.n_elems;
 }
 
 uint32_t ls_total_rays(ls_tracer *tr) { return tr ? shard_rays(tr) : 0u; }
@@ -1669,6 +1710,7 @@ long ls_get_info(ls_tracer *tr, int what)
     }
     case LS_INFO_HOST_THREADS: return HostPool::get().threads();
     case LS_INFO_AZIMUTH_COUNT: return (long)tr->H;
+    case LS_INFO_LAST_COMMIT_REFIT: return tr->last_commit_refit ? 1 : 0;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }
@@ -1719,6 +1761,7 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         tr->opt_readback_hits = value;
         return LS_OK;
     case LS_OPT_DEBUG_FAULT: tr->opt_debug_fault = value != 0; return LS_OK;
+    case LS_OPT_BVH_REFIT: tr->opt_bvh_refit = value != 0; return LS_OK;
     case LS_OPT_BLOCK_CULL:
         if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto");
         tr->opt_block_cull = value;
@@ -1838,6 +1881,7 @@ int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid)
         gt.n = (uint32_t)tr->slot_geom_ids.size();
         gt.tri_first = tr->geom_table.p;
         gt.geom_ids = tr->geom_table.p + gt.n + 1;
+        gt.prim_shift = gt.geom_ids + gt.n;
         ls::launch_dense_from_hits(tr->stream, tables(tr), tr->last_d_hits, tr->last_d_n, gt, tr->hit_t.p, tr->hit_gid.p);
         LS_HIP(hipGetLastError());
     }

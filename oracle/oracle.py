@@ -297,25 +297,42 @@ class Scene:
     tris: np.ndarray           # uint32[Nt,3], indices into verts
     geom_first: np.ndarray     # uint32[G] first global triangle id per geometry slot
     geom_ids: np.ndarray       # uint32[G] geomID of each slot (ascending)
+    geom_quad: np.ndarray = None   # bool[G]: RTC_GEOMETRY_TYPE_QUAD slot (two triangles per element, primID = triangle // 2)
+
+
+def quads_to_triangles(quads: np.ndarray) -> np.ndarray:
+    """Embree 3's quad = the triangle pair (v0,v1,v3), (v2,v3,v1) (its API documentation of RTC_GEOMETRY_TYPE_QUAD; the
+    reference hands quads to Embree as they are, EmbreeTracer.cpp:179-198): uint32[n,4] -> uint32[2n,3]."""
+    q = np.asarray(quads, np.uint32)
+    t = np.empty((2 * q.shape[0], 3), np.uint32)
+    t[0::2] = q[:, [0, 1, 3]]
+    t[1::2] = q[:, [2, 3, 1]]
+    return t
 
 
 def assemble_scene(sensor: Sensor, meshes) -> Scene:
-    """meshes: iterable of (geomID, verts[Nv,3], tris[Nt,3], affine[12]); sorted by geomID here."""
+    """meshes: iterable of (geomID, verts[Nv,3], elements, affine[12]); elements uint32[Nt,3] (triangles) or [Nq,4]
+    (quads); sorted by geomID here."""
     meshes = sorted(meshes, key=lambda m: m[0])
-    vs, ts, first, ids, vo, to = [], [], [], [], 0, 0
+    vs, ts, first, ids, quad, vo, to = [], [], [], [], [], 0, 0
     for gid, v, t, A in meshes:
         tv = transform_vertices(v, A, sensor)
         vs.append(tv)
-        ts.append(np.asarray(t, np.uint32) + np.uint32(vo))
+        t = np.asarray(t, np.uint32)
+        is_quad = t.ndim == 2 and t.shape[1] == 4
+        if is_quad:
+            t = quads_to_triangles(t)
+        ts.append(t + np.uint32(vo))
         first.append(to)
         ids.append(gid)
+        quad.append(is_quad)
         vo += tv.shape[0]
         to += len(t)
     if not vs:
         return Scene(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32), np.zeros(0, np.uint32),
-                     np.zeros(0, np.uint32))
+                     np.zeros(0, np.uint32), np.zeros(0, bool))
     return Scene(np.concatenate(vs), np.concatenate(ts).astype(np.uint32), np.array(first, np.uint32),
-                 np.array(ids, np.uint32))
+                 np.array(ids, np.uint32), np.array(quad, bool))
 
 
 def trace_bruteforce(dirs: np.ndarray, scene: Scene, nthreads: int = 8):
@@ -374,7 +391,12 @@ def pack_points(t, gid, dirs, H, scene: Scene):
     k = lib().lso_pack_points(_p(t, C.c_float), _p(gid, C.c_uint32), _p(dirs, C.c_float), n, H,
                               _p(gf, C.c_uint32), _p(gi, C.c_uint32), gf.shape[0], _p(pts, C.c_uint8),
                               _p(hits, C.c_uint32))
-    return pts[:k].copy(), hits[:k].copy()
+    pts, hits = pts[:k].copy(), hits[:k].copy()
+    if scene.geom_quad is not None and scene.geom_quad.any() and k:   # primID of a quad geometry = triangle // 2
+        slot_of = {int(g): i for i, g in enumerate(scene.geom_ids)}
+        is_quad = np.array([scene.geom_quad[slot_of[int(g)]] for g in hits[:, 1]], bool)
+        hits[is_quad, 2] //= 2
+    return pts, hits
 
 
 def fat_traverse_stats(nodes: np.ndarray, tris: np.ndarray, leaf_size: int, dirs: np.ndarray, per_ray=None):

@@ -222,3 +222,25 @@ def test_adapter_syn128_over_grid(adapterapi, oracle, tmp_path):
     assert spf > 0
     assert np.array_equal(_points(tr.cloud()), want) and tr.cloud()["seq"] == 5
     tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_quad_mesh(adapterapi, oracle, sensors):
+    # addGeometry(name, RTC_GEOMETRY_TYPE_QUAD, ...) with a pcl::PolygonMesh of four-index polygons (MeshTransformer.cpp:521-538)
+    from test_gpu_dropin import _quad_grid
+    s = sensors["0000"]
+    v, q = _quad_grid(40, 30)
+    tr = adapterapi.AdapterTracer(CFG["0000"])
+    tr.meshFromArrays("relief", v, q, point_step=16)
+    assert tr.addGeometry("relief", geometry_type=1) == 0
+    tr.updateGeometry("relief")
+    assert tr.commitScene() == 0 and tr.traceScene(3) == 0
+    want = oracle.trace_frame(s, [(0, v, q, oracle.IDENTITY_AFFINE)])["points"]
+    c = tr.cloud()
+    assert c["width"] == want.shape[0] > 500 and np.array_equal(_points(c), want)
+    # a triangle mesh registered as quads is refused like the reference does (BadGeometryException there)
+    tr.meshFromArrays("wrong", v, oracle.quads_to_triangles(q), point_step=16)
+    assert tr.addGeometry("wrong", geometry_type=1) == 1
+    with pytest.raises(Exception, match="element vertex count"):
+        tr.updateGeometry("wrong")
+    tr.close()

@@ -184,3 +184,100 @@ def test_stuck_chained_prefix_is_reported(oracle, capi, sensors, meshes):
     rc, pts, hits = tr.traceScene(9)
     assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
     tr.close()
+
+
+def _quad_grid(nx, ny, half=30.0, seed=3):
+    """A relief of nx x ny quads (not planar: the two triangles of a quad differ) + the same surface as triangles."""
+    xs, ys = np.linspace(-half, half, nx + 1), np.linspace(-half, half, ny + 1)
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    rng = np.random.default_rng(seed)
+    Z = 0.4 * np.sin(0.3 * X) * np.cos(0.2 * Y) + rng.uniform(-0.05, 0.05, X.shape)
+    v = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
+    j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    a = (j * (nx + 1) + i).reshape(-1)
+    q = np.stack([a, a + 1, a + nx + 2, a + nx + 1], -1).astype(np.uint32)     # v0 v1 v2 v3 around the cell
+    return v, q
+
+
+def test_quad_geometry(oracle, capi, sensors, meshes, engine):
+    """RTC_GEOMETRY_TYPE_QUAD (EmbreeTracer.cpp:179-198, MeshTransformer.cpp:521-538): four indices per element, traced
+    as Embree's triangle pair (v0,v1,v3), (v2,v3,v1); primID is the quad's index.  A quad relief next to the triangle
+    mesh ben.stl, device and host index paths."""
+    import torch
+    s = sensors["0001"]
+    v, q = _quad_grid(60, 40)
+    bv, bt = meshes["ben"]
+    tr = make_tracer(capi, s, engine)
+    assert tr.addGeometry("relief", v.shape[0], q.shape[0], geometry_type=1) == 0
+    assert tr.addGeometry("face", bv.shape[0], bt.shape[0]) == 1
+    assert tr.getElementCount("relief") == q.shape[0] and tr.getVertexCount("relief") == v.shape[0]
+    tr.updateGeometry("relief", oracle.IDENTITY_AFFINE, v, q)
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    ref = oracle.trace_frame(s, [(0, v, q, oracle.IDENTITY_AFFINE), (1, bv, bt, oracle.IDENTITY_AFFINE)])
+    assert rc == 0 and len(pts) > 1000
+    assert np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    on_quads = hits["geom"] == 0
+    assert on_quads.sum() > 500 and int(hits["prim"][on_quads].max()) < q.shape[0]
+    # the same quads as a plain triangle mesh give the same points and t, primID = 2 * quad (+1)
+    tri = make_tracer(capi, s, engine)
+    t2 = oracle.quads_to_triangles(q)
+    tri.addGeometry("relief", v.shape[0], t2.shape[0])
+    tri.addGeometry("face", bv.shape[0], bt.shape[0])
+    tri.updateGeometry("relief", oracle.IDENTITY_AFFINE, v, t2)
+    tri.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+    assert tri.commitScene() == 0
+    _, pts3, hits3 = tri.traceScene(0)
+    assert np.array_equal(pts3, pts) and np.array_equal(hits3["prim"][on_quads] // 2, hits["prim"][on_quads])
+    tri.close()
+    # device-resident indices (converted into the library's triangle array), then a moved pose
+    dev = torch.device("cuda", 0)
+    dv = torch.from_numpy(v).to(dev)
+    dq = torch.from_numpy(q.view(np.int32)).to(dev)
+    A = oracle.affine_from_components(np.array((1.0, -2.0, 0.3), np.float32), np.array((0.02, 0.0, 0.4), np.float32))
+    tr.updateGeometryDeviceShared("relief", A, dv.data_ptr(), 12, dq.data_ptr())
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(1)
+    ref = oracle.trace_frame(s, [(0, v, q, A), (1, bv, bt, oracle.IDENTITY_AFFINE)])
+    assert np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    tr.close()
+
+
+def test_bvh_refit(oracle, capi, sensors, meshes):
+    """BVH engine: a commit after which only poses / vertices differ refits (OptixTracer.cpp:532-535 OPERATION_UPDATE):
+    same Morton order and tree topology, all boxes recomputed; a topology change rebuilds.  Results equal the oracle either
+    way, also when the refitted mesh has moved far from where it was sorted."""
+    from lidarshooter_amd import synth
+    s = sensors["0000"]
+    gv, gt = synth.grid_mesh(120, 80, half=45.0, seed=2)
+    bv, bt = meshes["ben"]
+    tr = make_tracer(capi, s, "bvh")
+    tr.addGeometry("ground", gv.shape[0], gt.shape[0])
+    tr.addGeometry("face", bv.shape[0], bt.shape[0])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gv, gt)
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == 0
+    poses = [((0, 0, 0), (0, 0, 0)), ((2.0, -1.0, 0.2), (0.0, 0.1, 0.8)), ((-25.0, 30.0, 1.0), (0.3, 0.0, -2.0)), ((40.0, 40.0, 5.0), (0.0, 0.0, 3.0))]
+    for k, (lin, ang) in enumerate(poses):
+        A = oracle.affine_from_components(np.array(lin, np.float32), np.array(ang, np.float32))
+        gk = gv.copy()
+        gk[:, 2] += np.float32(0.3 * k)                      # the ground's vertices change too (same indices)
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gk, None)
+        tr.updateGeometryTransform("face", A)
+        assert tr.commitScene() == 0
+        assert tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == (1 if k else 1)   # the first loop commit already follows a build
+        rc, pts, hits = tr.traceScene(k)
+        ref = oracle.trace_frame(s, [(0, gk, gt, oracle.IDENTITY_AFFINE), (1, bv, bt, A)])
+        assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    # new indices for one mesh: a full build
+    tr.updateGeometry("face", A, bv, bt[::-1].copy())
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == 0
+    rc, pts, hits = tr.traceScene(9)
+    ref = oracle.trace_frame(s, [(0, gk, gt, oracle.IDENTITY_AFFINE), (1, bv, bt[::-1].copy(), A)])
+    assert np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    # refit switched off
+    tr.setOption(capi.LS_OPT_BVH_REFIT, 0)
+    tr.updateGeometryTransform("face", oracle.IDENTITY_AFFINE)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == 0
+    tr.close()

@@ -83,7 +83,7 @@ def test_geometry_bookkeeping(capi, sensors, meshes):
     g2 = _add(tr, "face", meshes["ben"])
     assert g2 == gid + 1 and tr.getGeometryCount() == 2
     assert tr.addGeometry("face", 3, 1) < 0                                   # duplicate key
-    assert tr.addGeometry("quad", 4, 1, geometry_type=1) < 0                  # unsupported type
+    assert tr.addGeometry("grid", 4, 1, geometry_type=2) < 0                  # unsupported type (RTC_GEOMETRY_TYPE_GRID)
     assert tr.removeGeometry("mesh") == gid
     assert tr.getGeometryCount() == 1
     assert tr.removeGeometry("mesh") == -1                                    # EmbreeTracer.cpp:224-225
