@@ -34,29 +34,33 @@ int HipTracer::addGeometry(const std::string& _meshName, RTCGeometryType _geomet
 {
     const int rc = ls_add_geometry(_handle, _meshName.c_str(), static_cast<int>(_geometryType), _numVertices, _numElements);
     if (rc == LS_ERR_UNSUPPORTED_TYPE) return 0;  // EmbreeTracer.cpp:200-201 `return false`
+    if (rc >= 0) _verticesPerElement[_meshName] = _geometryType == RTC_GEOMETRY_TYPE_QUAD ? 4u : 3u;
     return rc;
 }
 
-int HipTracer::removeGeometry(const std::string& _meshName) { return ls_remove_geometry(_handle, _meshName.c_str()); }
-
-std::vector<std::uint32_t> HipTracer::flattenPolygons(const PolygonMesh& _mesh) const
+int HipTracer::removeGeometry(const std::string& _meshName)
 {
-    // MeshTransformer.cpp:486-520 copyElementsIntoBuffer
-    if (!_mesh.polygons.empty() && _mesh.polygons[0].vertices.size() != 3)
-        throw TraceException(__FILE__, "Geometry does not match element vertex count", 1);
-    std::vector<std::uint32_t> idx(_mesh.polygons.size() * 3);
+    _verticesPerElement.erase(_meshName);
+    return ls_remove_geometry(_handle, _meshName.c_str());
+}
+
+std::vector<std::uint32_t> HipTracer::flattenPolygons(const std::string& _meshName, const PolygonMesh& _mesh) const
+{
+    // MeshTransformer.cpp:486-538 copyElementsIntoBuffer: three indices per triangle, four per quad
+    const auto it = _verticesPerElement.find(_meshName);
+    const std::size_t per = it == _verticesPerElement.end() ? 3u : it->second;
+    if (!_mesh.polygons.empty() && _mesh.polygons[0].vertices.size() != per)
+        throw TraceException(__FILE__, "Geometry does not match element vertex count", per == 3 ? 1 : 2);
+    std::vector<std::uint32_t> idx(_mesh.polygons.size() * per);
     std::size_t k = 0;
-    for (const auto& poly : _mesh.polygons) {
-        idx[k++] = poly.vertices[0];
-        idx[k++] = poly.vertices[1];
-        idx[k++] = poly.vertices[2];
-    }
+    for (const auto& poly : _mesh.polygons)
+        for (std::size_t c = 0; c < per; ++c) idx[k++] = poly.vertices[c];
     return idx;
 }
 
 int HipTracer::updateGeometry(const std::string& _meshName, const Affine3f& _transform, const PolygonMesh& _mesh)
 {
-    const std::vector<std::uint32_t> idx = flattenPolygons(_mesh);
+    const std::vector<std::uint32_t> idx = flattenPolygons(_meshName, _mesh);
     const int rc = ls_update_geometry(_handle, _meshName.c_str(), _transform.data(), _mesh.cloud.data.data(),
                                       _mesh.cloud.point_step, idx.data());
     if (rc == LS_ERR_UNKNOWN_GEOMETRY) throw TraceException(__FILE__, "Geometry key does not exist in geometry types map", 8);
@@ -65,7 +69,7 @@ int HipTracer::updateGeometry(const std::string& _meshName, const Affine3f& _tra
 
 int HipTracer::updateGeometry(const std::string& _meshName, const Vector3f& _translation, const Vector3f& _rotation, const PolygonMesh& _mesh)
 {
-    const std::vector<std::uint32_t> idx = flattenPolygons(_mesh);
+    const std::vector<std::uint32_t> idx = flattenPolygons(_meshName, _mesh);
     const int rc = ls_update_geometry_components(_handle, _meshName.c_str(), _translation.data(), _rotation.data(),
                                                  _mesh.cloud.data.data(), _mesh.cloud.point_step, idx.data());
     if (rc == LS_ERR_UNKNOWN_GEOMETRY) throw TraceException(__FILE__, "Geometry key does not exist in geometry types map", 8);

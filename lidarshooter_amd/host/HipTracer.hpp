@@ -5,9 +5,11 @@
 #pragma once
 
 #include <array>
+#include <map>
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/lidarshooter_hip.h"
 #include "HostTypes.hpp"
@@ -56,7 +58,8 @@ public:
 
 private:
     HipTracer(LidarDevice::Ptr _sensorConfig, std::shared_ptr<PointCloud2> _traceStorage, int _hipDevice);
-    std::vector<std::uint32_t> flattenPolygons(const PolygonMesh& _mesh) const;
+    std::vector<std::uint32_t> flattenPolygons(const std::string& _meshName, const PolygonMesh& _mesh) const;
+    std::map<std::string, std::size_t> _verticesPerElement;   // 3, or 4 for RTC_GEOMETRY_TYPE_QUAD
 
     LidarDevice::Ptr _config;
     std::shared_ptr<PointCloud2> _traceCloud;

@@ -473,7 +473,7 @@ def test_host_mirror_hiptracer(oracle, sensors, meshes):
     assert tr.getVertexCount("mesh") == 98 and tr.getElementCount("mesh") == 162
     assert tr.getGeometryId("mesh") == gid
     assert tr.getVertexCount("unknown") == -100            # TraceException (EmbreeTracer.cpp:369-439)
-    assert tr.addGeometry("q", 4, 1, geometry_type=1) == 0  # EmbreeTracer.cpp:200-201 returns false
+    assert tr.addGeometry("q", 4, 1, geometry_type=2) == 0  # an unsupported type: EmbreeTracer.cpp:200-201 returns false
     assert tr.updateGeometry("mesh", oracle.IDENTITY_AFFINE, ground) == 0
     assert tr.commitScene() == 0
     assert tr.traceScene(0) == 0
