@@ -17,7 +17,7 @@
 //   * vertices are uploaded every frame by default (MeshProjector::affineMeshCallback rewrites the cloud in
 //     place, MeshProjector.cpp:306-307, so the bytes have to be read anyway); setMeshPolicy(SkipUnchanged)
 //     or LIDARSHOOTER_HIP_SKIP_UNCHANGED=1 makes an update whose cloud still carries the same
-//     (buffer, size, header.seq, header.stamp, 256-vertex probe) a transform-only update: no copy at all
+//     (buffer, size, header.seq, header.stamp, 64-vertex probe) a transform-only update: no copy at all
 //     -- what a joystick-driven pose change is (AffineMesh.cpp:108-128);
 //   * the vertex transform (MeshTransformer.cpp:142-205), ray generation, closest hit and 32-byte point
 //     packing (XYZIRBytes.cpp:24-40) run on the GPU; the points land in pinned host memory (16 bytes each:
@@ -227,7 +227,7 @@ private:
     static std::uint64_t probePolygons(const pcl::PolygonMesh& mesh)
     {
         std::uint64_t h = 1469598103934665603ull;
-        const std::size_t n = mesh.polygons.size(), step = n > 64 ? n / 64 : 1;
+        const std::size_t n = mesh.polygons.size(), step = n > 16 ? n / 16 : 1;   // every pcl::Vertices is its own heap block: a cache miss each
         for (std::size_t i = 0; i < n; i += step) {
             const auto& p = mesh.polygons[i].vertices;
             h = mix(h, p.size());
@@ -243,7 +243,7 @@ private:
     static std::uint64_t probeVertices(const std::uint8_t* data, std::size_t count, std::size_t pointStep)
     {
         std::uint64_t h = 1469598103934665603ull;
-        const std::size_t step = count > 256 ? count / 256 : 1;
+        const std::size_t step = count > 64 ? count / 64 : 1;
         for (std::size_t i = 0; i < count; i += step) {
             std::uint64_t w[2] = {0, 0};
             std::memcpy(w, data + i * pointStep, 12);
