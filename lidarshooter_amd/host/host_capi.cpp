@@ -159,6 +159,36 @@ const void* lsh_tracer_hits(lsh_tracer* t, unsigned* n)
 }
 void* lsh_tracer_handle(lsh_tracer* t) { return t->p->handle(); }
 
+// The per-frame call sequence of MeshProjector::traceAffineMesh (MeshProjector.cpp:446-464) on the C ABI, `n_frames`
+// times without the interpreter in between (bench.py's timed loop; lsbench.cpp is the same loop as a program):
+// for every mesh ls_update_geometry_transform (the mesh is resident and unchanged, its pose is restated; mesh m takes
+// affines[(frame % n_affines[m]) * 12 ...] of its own list), ls_commit_scene, the frame's output set (they rotate over
+// n_out caller-owned sets), ls_trace_scene_async.  Returns 0 or the first negative status.
+int lsh_stream_frames(void* tracer, const char* const* names, const float* const* affines, const unsigned* n_affines, unsigned n_meshes,
+                      void* const* out_points, void* const* out_hits, void* const* out_counts, unsigned n_out, unsigned capacity,
+                      unsigned first_frame, unsigned n_frames)
+{
+    ls_tracer* tr = static_cast<ls_tracer*>(tracer);
+    ls_frame f;
+    for (unsigned k = 0; k < n_frames; ++k) {
+        const unsigned frame = first_frame + k;
+        for (unsigned m = 0; m < n_meshes; ++m) {
+            const int rc = ls_update_geometry_transform(tr, names[m], affines[m] + 12u * (n_affines[m] ? frame % n_affines[m] : 0u));
+            if (rc < 0) return rc;
+        }
+        int rc = ls_commit_scene(tr);
+        if (rc < -1) return rc;
+        if (n_out) {
+            const unsigned o = frame % n_out;
+            rc = ls_tracer_set_output_buffers(tr, out_points[o], out_hits[o], static_cast<uint32_t*>(out_counts[o]), capacity);
+            if (rc < 0) return rc;
+        }
+        rc = ls_trace_scene_async(tr, frame, &f);
+        if (rc < -1) return rc;
+    }
+    return 0;
+}
+
 // Trajectory player: writes up to `cap` poses (6 floats each: linear xyz, angular xyz); returns the count
 int lsh_trajectory_play(const char* path, float period, float* out6, int cap)
 {

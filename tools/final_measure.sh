@@ -1,0 +1,27 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one go (GPU box, repo root):  bash tools/final_measure.sh r02
+TAG=${1:-r02}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$REPO"
+mkdir -p gpurun_out/final
+python bench.py > gpurun_out/final/${TAG}_projection_bench.json 2> gpurun_out/final/bench.err
+python bench.py --engine bvh --no-dropin > gpurun_out/final/${TAG}_bvh_bench.json 2>> gpurun_out/final/bench.err
+python bench.py --no-cpu-baseline --no-dropin --pipeline 1 > gpurun_out/final/bench_${TAG}_projection_mode1.json 2>> gpurun_out/final/bench.err
+python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m > gpurun_out/final/bench_${TAG}_projection_10m.json 2>> gpurun_out/final/bench.err
+python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m --no-cull > gpurun_out/final/bench_${TAG}_projection_10m_nocull.json 2>> gpurun_out/final/bench.err
+python bench.py --no-cpu-baseline --no-dropin --workload cfg5 > gpurun_out/final/bench_${TAG}_projection_cfg5.json 2>> gpurun_out/final/bench.err
+python bench.py --no-cpu-baseline --workload xt32 > gpurun_out/final/bench_${TAG}_projection_xt32.json 2>> gpurun_out/final/bench.err
+for p in 0 1 2; do
+  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --grid 1000 500 --frames 2000 --warmup 200 --pipeline $p
+done > gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
+lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --mesh ground=tests/golden/data/mesh/ground.stl --mesh face=tests/golden/data/mesh/ben.stl --frames 5000 --warmup 200 --pipeline 1 >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
+for g in sharded interleaved; do
+  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --grid 1000 500 --frames 1000 --warmup 100 --ranks 1 --group $g
+done >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
+python tools/dropin_bench.py 50 > gpurun_out/final/dropin_${TAG}.json 2>> gpurun_out/final/bench.err
+bash tools_profile.sh ${TAG} > gpurun_out/final/profile.log 2>&1
+python tools/prof_summary.py gpurun_out/prof_${TAG} gpurun_out/final/${TAG}_projection > gpurun_out/final/prof_summary.log 2>&1
+cp gpurun_out/prof_${TAG}/bench_stats.json gpurun_out/final/${TAG}_projection_bench_under_rocprof.json
+BENCH_ARGS="--engine bvh --no-dropin" bash tools_pmc.sh ${TAG}_bvh "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/final/pmc_bvh.log 2>&1
+ls gpurun_out/final
+tail -3 gpurun_out/final/bench.err
