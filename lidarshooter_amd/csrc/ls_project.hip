@@ -306,30 +306,22 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)big_count[kCullCountAt + gi]);
         if (block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
     }
-    ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
-    if (LDS_TABLES) {
-        const uint32_t V = pp.tb.V;
-        for (uint32_t i = threadIdx.x; i < V; i += kBlock) {
-            s_chan[i] = pp.chan_tan_up[i];
-            s_chan[V + i] = pp.chan_tan_dn[i];
-            s_chan[2 * V + i] = pp.tb.sin_theta[i];
-            s_chan[3 * V + i] = pp.tb.cos_theta[i];
-            s_chan[4 * V + i] = __uint_as_float(pp.chan_perm[i]);
-        }
-        ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V)};
-        __syncthreads();
-    }
+    // ---- which triangle this lane takes, and its loads, BEFORE the channel tables are staged: index load -> vertex
+    //      gather is a chain of two memory round trips, the staging (global -> LDS, then a workgroup barrier) a third
+    //      that does not depend on them -- issued first, the chain runs under the staging instead of after it
+    //      (rocprofv3: the waves of this kernel spend half their lifetime in s_waitcnt; eight vector loads per wave)
     uint32_t k = 0xFFFFFFFFu;
+    bool live_wave = true;
     if (CULLED) {
         const uint32_t rank = block * (kBlock / 64) + w;   // this wave among the geometry's waves
         if (COUNT && rank == 0 && lane == 0) atomicAdd(&stats[1], (unsigned long long)n_live);   // counts[2]: surviving groups
-        if (rank * kPerWave >= n_live) return;             // the survivors' last, partly filled workgroup (no barrier follows)
+        live_wave = rank * kPerWave < n_live;              // the survivors' last workgroup is partly filled
         // a wave's groups are taken at a stride of the number of live waves: the survivors list is in mesh order, and the
         // cells a group expands to vary by orders of magnitude with its distance from the sensor -- consecutive groups
         // would make a few waves next to the sensor walk ten times the cells of the others (and the kernel wait for them)
         const uint32_t live_waves = (n_live + kPerWave - 1u) / kPerWave;
         const uint32_t e = pp.spread ? (lane / kCullGroup) * live_waves + rank : rank * kPerWave + lane / kCullGroup;
-        if (e < n_live) k = cull_list[batch.list_first[gi] + e] * kCullGroup + (lane % kCullGroup);
+        if (live_wave && e < n_live) k = cull_list[batch.list_first[gi] + e] * kCullGroup + (lane % kCullGroup);
     } else {
         // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
         // join the cell tests): its footprints are large, and the cells are what takes the time
@@ -343,23 +335,43 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             k = (block * (kBlock / 64) + w) * tris_per_wave + lane;
         }
     }
-    uint32_t cells = 0, slot = 0;
+    float raw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // the three corners as uploaded (mesh space)
     if (k < src.ntris) {
         const uint32_t a = src.idx[3 * (size_t)k + 0], b = src.idx[3 * (size_t)k + 1], c = src.idx[3 * (size_t)k + 2];
+        const float *pa = reinterpret_cast<const float *>(src.verts + (size_t)a * src.stride);
+        const float *pb = reinterpret_cast<const float *>(src.verts + (size_t)b * src.stride);
+        const float *pc = reinterpret_cast<const float *>(src.verts + (size_t)c * src.stride);
+        raw[0] = pa[0]; raw[1] = pa[1]; raw[2] = pa[2];
+        raw[3] = pb[0]; raw[4] = pb[1]; raw[5] = pb[2];
+        raw[6] = pc[0]; raw[7] = pc[1]; raw[8] = pc[2];
+    }
+    ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
+    if (LDS_TABLES) {
+        const uint32_t V = pp.tb.V;
+        for (uint32_t i = threadIdx.x; i < V; i += kBlock) {
+            s_chan[i] = pp.chan_tan_up[i];
+            s_chan[V + i] = pp.chan_tan_dn[i];
+            s_chan[2 * V + i] = pp.tb.sin_theta[i];
+            s_chan[3 * V + i] = pp.tb.cos_theta[i];
+            s_chan[4 * V + i] = __uint_as_float(pp.chan_perm[i]);
+        }
+        ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V)};
+        __syncthreads();
+    }
+    if (!live_wave) return;   // (no barrier follows)
+    uint32_t cells = 0, slot = 0;
+    if (k < src.ntris) {
         V3 v0, v1, v2;
         if (src.xform == 1) {
-            v0 = xform_vertex(src.m, src.verts + (size_t)a * src.stride);
-            v1 = xform_vertex(src.m, src.verts + (size_t)b * src.stride);
-            v2 = xform_vertex(src.m, src.verts + (size_t)c * src.stride);
+            v0 = xform_vertex(src.m, reinterpret_cast<const uint8_t *>(raw));
+            v1 = xform_vertex(src.m, reinterpret_cast<const uint8_t *>(raw + 3));
+            v2 = xform_vertex(src.m, reinterpret_cast<const uint8_t *>(raw + 6));
         } else if (src.xform == 2) {  // mesh transform is exactly the identity: sensor pose only
-            v0 = xform_vertex_sensor_only(src.m, src.verts + (size_t)a * src.stride);
-            v1 = xform_vertex_sensor_only(src.m, src.verts + (size_t)b * src.stride);
-            v2 = xform_vertex_sensor_only(src.m, src.verts + (size_t)c * src.stride);
+            v0 = xform_vertex_sensor_only(src.m, reinterpret_cast<const uint8_t *>(raw));
+            v1 = xform_vertex_sensor_only(src.m, reinterpret_cast<const uint8_t *>(raw + 3));
+            v2 = xform_vertex_sensor_only(src.m, reinterpret_cast<const uint8_t *>(raw + 6));
         } else {
-            const float *pa = reinterpret_cast<const float *>(src.verts + (size_t)a * src.stride);
-            const float *pb = reinterpret_cast<const float *>(src.verts + (size_t)b * src.stride);
-            const float *pc = reinterpret_cast<const float *>(src.verts + (size_t)c * src.stride);
-            v0 = {pa[0], pa[1], pa[2]}; v1 = {pb[0], pb[1], pb[2]}; v2 = {pc[0], pc[1], pc[2]};
+            v0 = {raw[0], raw[1], raw[2]}; v1 = {raw[3], raw[4], raw[5]}; v2 = {raw[6], raw[7], raw[8]};
         }
         if (pp.debug == 1) { if (v0.x + v1.y + v2.z == 12345.678f) best[0] = 0; return; }
         // multi-GPU shards: a triangle wholly on the outer side of one of the two vertical planes that bound
