@@ -1,23 +1,23 @@
-// stub of src/ITracer.cpp: constructor semantics of ITracer.cpp:3-28 (cloud allocated when none is given,
-// width/height zeroed, geometry count 0) and the trivial accessors
+// Stand-in for src/ITracer.cpp: what the base class does at construction (ITracer.cpp:3-28 in the reference: a cloud
+// is made when none is handed in, its width / height start at zero, no geometries yet) and its trivial accessors.
 #include "ITracer.hpp"
 
 namespace lidarshooter
 {
 
-ITracer::ITracer(LidarDevice::Ptr _sensorConfig, sensor_msgs::PointCloud2::Ptr _traceStorage, std::shared_ptr<spdlog::logger> __logger)
-    : _logger(__logger ? __logger : spdlog::stdout_color_mt(LIDARSHOOTER_APPLICATION_NAME)), _config(_sensorConfig), _geometryCount(0),
-      _traceCloud(_traceStorage ? _traceStorage : sensor_msgs::PointCloud2::Ptr(new sensor_msgs::PointCloud2()))
+ITracer::ITracer(LidarDevice::Ptr sensor, CloudPtr storage, LoggerPtr logger) : sensor_(sensor), cloud_(storage)
 {
-    _traceCloud->width = 0;
-    _traceCloud->height = 0;
+    _logger = logger ? logger : spdlog::stdout_color_mt(LIDARSHOOTER_APPLICATION_NAME);
+    if (!cloud_) cloud_ = std::make_shared<sensor_msgs::PointCloud2>();
+    cloud_->height = 0;
+    cloud_->width = 0;
 }
 
-long ITracer::getGeometryCount() const { return _geometryCount; }
-sensor_msgs::PointCloud2::Ptr ITracer::getTraceCloud() { return _traceCloud; }
-void ITracer::setTraceCloud(sensor_msgs::PointCloud2::Ptr _traceStorage) { _traceCloud = _traceStorage; }
-LidarDevice::Ptr ITracer::getSensorConfig() { return _config; }
-void ITracer::setSensorConfig(LidarDevice::Ptr __config) { _config = __config; }
-void ITracer::setGeometryCount(long _count) { _geometryCount = _count; }
+long ITracer::getGeometryCount() const { return geometries_; }
+void ITracer::setGeometryCount(long n) { geometries_ = n; }
+ITracer::CloudPtr ITracer::getTraceCloud() { return cloud_; }
+void ITracer::setTraceCloud(CloudPtr storage) { cloud_ = storage; }
+LidarDevice::Ptr ITracer::getSensorConfig() { return sensor_; }
+void ITracer::setSensorConfig(LidarDevice::Ptr sensor) { sensor_ = sensor; }
 
 }  // namespace lidarshooter

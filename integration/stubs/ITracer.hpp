@@ -1,5 +1,6 @@
-// stub with the shape of lidarshooter's src/ITracer.hpp:29-152 -- the abstract tracer the adapter derives from.
-// Declarations only mirror what a backend must override or may call; see the reference for the real file.
+// Stand-in for lidarshooter's src/ITracer.hpp (see the reference, lines 29-152, for the real header): only the
+// SHAPE a tracer backend derives from -- six pure virtuals, the count / cloud / config accessors -- so that
+// integration/HipTracer.hpp can be compiled and exercised in an image without ROS.  Test infrastructure.
 #pragma once
 
 #include <cstdint>
@@ -21,34 +22,46 @@ namespace lidarshooter
 class ITracer
 {
 public:
-    using Ptr = std::shared_ptr<ITracer>;
-    using ConstPtr = std::shared_ptr<ITracer const>;
+    typedef std::shared_ptr<ITracer> Ptr;
+    typedef std::shared_ptr<const ITracer> ConstPtr;
+    typedef sensor_msgs::PointCloud2::Ptr CloudPtr;
+    typedef std::shared_ptr<spdlog::logger> LoggerPtr;
 
-    ITracer(LidarDevice::Ptr _sensorConfig, sensor_msgs::PointCloud2::Ptr _traceStorage = nullptr, std::shared_ptr<spdlog::logger> _logger = nullptr);
-    virtual ITracer::Ptr getPtr() = 0;
+    ITracer(LidarDevice::Ptr sensor, CloudPtr storage = nullptr, LoggerPtr logger = nullptr);
     virtual ~ITracer() = default;
+    virtual Ptr getPtr() = 0;
 
-    virtual int addGeometry(const std::string& _meshName, enum RTCGeometryType _geometryType, int _numVertices, int _numElements) = 0;
-    virtual int removeGeometry(const std::string& _meshName) = 0;
-    virtual int updateGeometry(const std::string& _meshName, Eigen::Affine3f _transform, pcl::PolygonMesh::Ptr& _mesh) = 0;
-    virtual int updateGeometry(const std::string& _meshName, Eigen::Vector3f _translation, Eigen::Vector3f _rotation, pcl::PolygonMesh::Ptr& _mesh) = 0;
+    // geometry registry
+    virtual int addGeometry(const std::string& mesh,
+                            enum RTCGeometryType elementType,
+                            int vertexCount,
+                            int elementCount) = 0;
+    virtual int removeGeometry(const std::string& mesh) = 0;
+    // per frame: every mesh with its pose, then commit, then trace
+    virtual int updateGeometry(const std::string& mesh,
+                               Eigen::Affine3f pose,
+                               pcl::PolygonMesh::Ptr& data) = 0;
+    virtual int updateGeometry(const std::string& mesh,
+                               Eigen::Vector3f shift,
+                               Eigen::Vector3f eulerXYZ,
+                               pcl::PolygonMesh::Ptr& data) = 0;
     virtual int commitScene() = 0;
-    virtual int traceScene(std::uint32_t _frameIndex) = 0;
-    virtual long getGeometryCount() const;
+    virtual int traceScene(std::uint32_t frame) = 0;
 
-    sensor_msgs::PointCloud2::Ptr getTraceCloud();
-    void setTraceCloud(sensor_msgs::PointCloud2::Ptr _traceStorage);
+    virtual long getGeometryCount() const;
+    CloudPtr getTraceCloud();
+    void setTraceCloud(CloudPtr storage);
     LidarDevice::Ptr getSensorConfig();
-    void setSensorConfig(LidarDevice::Ptr __config);
+    void setSensorConfig(LidarDevice::Ptr sensor);
 
 protected:
-    void setGeometryCount(long _count);
-    std::shared_ptr<spdlog::logger> _logger;
+    void setGeometryCount(long n);
+    LoggerPtr _logger;
 
 private:
-    LidarDevice::Ptr _config;
-    long _geometryCount;
-    sensor_msgs::PointCloud2::Ptr _traceCloud;
+    LidarDevice::Ptr sensor_;
+    long geometries_ = 0;
+    CloudPtr cloud_;
 };
 
 }  // namespace lidarshooter

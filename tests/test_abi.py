@@ -52,3 +52,35 @@ def test_group_header_symbols_are_exported():
     lib = ctypes.CDLL(groupapi.LIB_PATH)
     for s in syms:
         assert hasattr(lib, s), s
+
+
+def test_host_side_helpers_without_a_gpu(capi, oracle):
+    """The C ABI's host-only helpers (no HIP call inside): ls_affine_from_components == the oracle's restatement of
+    MeshTransformer.cpp:467-477, ls_expand_points rebuilds the 32-byte records of XYZIRBytes.cpp:24-40 from the compact
+    ones, ls_parallel_copy copies."""
+    import numpy as np
+    L = capi.load()
+    f32p = ctypes.POINTER(ctypes.c_float)
+    rng = np.random.default_rng(7)
+    for _ in range(20):
+        lin = rng.uniform(-50, 50, 3).astype(np.float32)
+        ang = rng.uniform(-3.2, 3.2, 3).astype(np.float32)
+        out = np.zeros(12, np.float32)
+        L.ls_affine_from_components(lin.ctypes.data_as(f32p), ang.ctypes.data_as(f32p), out.ctypes.data_as(f32p))
+        assert np.array_equal(out.view(np.uint32), oracle.affine_from_components(lin, ang).view(np.uint32))
+    n = 100003                                     # several work items of the copy pool, a ragged tail
+    compact = np.zeros((n, 4), np.float32)
+    compact[:, :3] = rng.normal(size=(n, 3)).astype(np.float32)
+    ring = rng.integers(0, 128, n).astype(np.int32)
+    compact[:, 3] = ring.view(np.float32)
+    out = np.full((n, 32), 0xCD, np.uint8)
+    assert L.ls_expand_points(out.ctypes.data, compact.ctypes.data, n) == 0
+    want = np.zeros((n, 8), np.float32)
+    want[:, :3] = compact[:, :3]
+    want[:, 4] = 64.0                              # EmbreeTracer.cpp:343
+    want[:, 5] = ring.view(np.float32)
+    assert np.array_equal(out.view(np.uint32).reshape(n, 8), want.view(np.uint32))
+    src = rng.integers(0, 256, 5_000_001, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    assert L.ls_parallel_copy(dst.ctypes.data, src.ctypes.data, src.size) == 0 and np.array_equal(src, dst)
+    assert L.ls_expand_points(None, None, 0) == 0 and L.ls_parallel_copy(None, None, 0) == 0
