@@ -165,3 +165,39 @@ def test_config5_as_composed_vs_oracle(oracle, capi, sensors, meshes):
         assert np.array_equal(np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1), ref["hits"])
         assert (hits["geom"] == 1).sum() > 0 and 200000 < len(pts) < 320000   # ben is in view, the ground fills the lower channels
     tr.close()
+
+
+def test_cull_stress_poses(oracle, capi, sensors):
+    """Group culling forced on, a 600 000-triangle relief under poses that stress its bound: the mesh stood on edge (its
+    least-squares planes become walls: slopes are clamped, plain boxes), passing through the sensor's vertical axis and
+    through the sensor itself (extent / distance >= 1/4: no first-order bound, groups are kept), scaled up and down by
+    1000, mirrored, and sheared -- culled == unculled, bit for bit."""
+    from lidarshooter_amd import synth
+    v, t = synth.grid_mesh(1000, 300, half=40.0, seed=9, relief=1.5, noise=0.05)
+    s = _syn_sensor(oracle, sensors, V=128, H=2048)
+    on, off = make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection")
+    on.setOption(capi.LS_OPT_BLOCK_CULL, 1)
+    off.setOption(capi.LS_OPT_BLOCK_CULL, 0)
+    for tr in (on, off):
+        tr.addGeometry("g", v.shape[0], t.shape[0])
+        tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
+    tx, ty, tz = [float(x) for x in s.t]
+    poses = [
+        oracle.affine_from_components(np.array((0, 0, 0), np.float32), np.array((np.pi / 2, 0, 0), np.float32)),        # on edge
+        oracle.affine_from_components(np.array((tx, ty, tz - 2.0), np.float32), np.array((0, 0, 0.3), np.float32)),     # under the sensor, axis pierces it
+        oracle.affine_from_components(np.array((tx, ty, tz), np.float32), np.array((0.4, 0.2, 0), np.float32)),         # through the sensor origin
+        oracle.affine_from_components(np.array((tx + 10, ty, tz + 30), np.float32), np.array((0, np.pi / 2, 1.0), np.float32)),
+        np.array([1000, 0, 0, 0, 0, 1000, 0, 0, 0, 0, 1000, -20000], np.float32),                                      # huge
+        np.array([1e-3, 0, 0, tx + 0.5, 0, 1e-3, 0, ty, 0, 0, 1e-3, tz - 0.2], np.float32),                             # tiny, next to the sensor
+        np.array([-1, 0, 0, 5, 0, 1, 0.8, 0, 0, 0, 1, 0], np.float32),                                                  # mirrored + sheared
+    ]
+    n_hits = []
+    for A in poses:
+        for tr in (on, off):
+            tr.updateGeometryTransform("g", A)
+        a, b = _frame(on), _frame(off)
+        _same(a, b)
+        n_hits.append(len(a[1]))
+    assert max(n_hits) > 50000 and len(set(n_hits)) > 3
+    on.close()
+    off.close()
