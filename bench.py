@@ -575,8 +575,11 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
     #      stream bracketing that kernel only (recorded without synchronising, read after the loop)
     tr.setOption(capi.LS_OPT_TIMING, 2)
     tr.timings()
-    for i in range(args.steps):
-        frame(i)
+    if stream_frames is not None:
+        stream_frames(0, args.steps)             # back to back, like the timed windows (the GPU stays busy)
+    else:
+        for i in range(args.steps):
+            frame(i)
     sync()
     tm = tr.timings()
     tr.setOption(capi.LS_OPT_TIMING, 0)
@@ -760,9 +763,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": trace_ms, "kernel_launches_timed": tm["frames"],
-            "kernel_timing": "ISOLATED kernel: hipEvents on the tracer's stream around the kernel with ONE frame in flight (frames do not "
-                             "overlap while it is timed), in a second pass of the same K frames; compare with "
-                             "ms_per_step_one_frame_in_flight, not with ms_per_step (frames overlap there)",
+            "kernel_timing": "ISOLATED kernel: its own begin / end timestamps (hipEvents attached to the dispatch with hipExtLaunchKernel, what rocprofv3 reports per dispatch; events recorded around a launch add ~3 us of barrier packets) with ONE frame in flight (frames do not overlap while it is timed), in a second pass of the same K frames; compare with ms_per_step_one_frame_in_flight, not with ms_per_step (frames overlap there), and with profiles/*_kernel_isolated.json (the same figure from the rocprofv3 trace of this command)",
             "ms_per_step_one_frame_in_flight": one_ms,
             "algorithmic_bytes_per_launch": b_launch, "kernel_source_sha": sha,
             # the same roofline on the frame as timed: all kernels' algorithmic bytes over the reported step time

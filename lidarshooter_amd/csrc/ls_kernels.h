@@ -192,7 +192,8 @@ struct FinishPackArgs {
 // geometries' k_project launch take 64 / kCullGroup of them each.  Geometries without bounds go in a launch of their own.
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
                     void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats,
-                    const FinishPackArgs *rider = nullptr, uint32_t *cull_list = nullptr);
+                    const FinishPackArgs *rider = nullptr, uint32_t *cull_list = nullptr, hipEvent_t ev_start = nullptr,
+                    hipEvent_t ev_stop = nullptr);   // ev_*: ride on the k_project dispatch (its own begin / end timestamps)
 uint32_t project_tris_per_wave(uint32_t ntris);   // 64 for big meshes, fewer for small ones (more waves than ntris / 64)
 uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs);   // survivor-list words for the geometries with bounds (0: none, or too many for one launch)
 // one-off per topology: Morton order of the triangles (centroids in mesh space) -> perm (sorted position -> triangle),

@@ -20,6 +20,9 @@
 // (OptixTracer.cpp:317-328, OptixTracerModules.cu:26-86).
 #include <algorithm>
 #include <cstdlib>
+#include <hip/hip_ext.h>
+#include <cstdio>
+#include <vector>
 #include "ls_kernels.h"
 #include "ls_device.h"
 
@@ -280,6 +283,24 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Build option -DLS_WAVE_TIMELINE (tools/exp_build.sh, tools/exp_timeline.py; never in the shipped library): every wave
+// of the 400th k_project launch records its start / end (s_memrealtime) and the cycle count at four marks; the host
+// writes the records to $LS_TIMELINE_OUT at the 600th launch.  This is where DESIGN.md's per-phase numbers come from.
+#ifdef LS_WAVE_TIMELINE
+__device__ unsigned long long g_timeline[8 * 32768];
+__device__ uint32_t g_tl_on;
+__device__ __forceinline__ unsigned long long tl_mark()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define TL_MARK(x) const unsigned long long x = tl_mark()
+#else
+#define TL_MARK(x)
+#endif
+
 template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
 __device__ __forceinline__ void project_body(const ProjectParams &pp, const GeomBatch &batch, uint32_t block_idx, ProjectLds &lds,
                                              float *s_chan /* LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm */,
@@ -291,6 +312,10 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     auto &s_meta = lds.meta;
     auto &s_pref = lds.pref;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+#ifdef LS_WAVE_TIMELINE
+    const unsigned long long tl_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    TL_MARK(tl_0);
     // one launch covers up to kGeomsPerLaunch geometries: the workgroup finds its own (uniform)
     uint32_t gi = 0;
     if (MULTI)
@@ -359,6 +384,11 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         __syncthreads();
     }
     if (!live_wave) return;   // (no barrier follows)
+    TL_MARK(tl_1);   // tables staged
+#ifdef LS_WAVE_TIMELINE
+    { float acc = 0.f; for (int i = 0; i < 9; ++i) acc += raw[i]; if (acc == 12345.6789f) best[1] = 0; }   // the loads have landed
+#endif
+    TL_MARK(tl_2);
     uint32_t cells = 0, slot = 0;
     if (k < src.ntris) {
         V3 v0, v1, v2;
@@ -424,6 +454,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             }
         }
     }
+    TL_MARK(tl_3);   // footprints done
     // wave-level inclusive scan of the cell counts
     const uint32_t incl = wave_inclusive_scan(cells);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -453,6 +484,19 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         wave_lds_fence();
     }
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
+#ifdef LS_WAVE_TIMELINE
+    TL_MARK(tl_4);
+    if (g_tl_on && lane == 0) {
+        const uint32_t id = block_idx * (kBlock / 64) + w;
+        if (id < 32768u) {
+            unsigned long long *r = g_timeline + 8 * (size_t)id;
+            uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            r[0] = tl_w0; r[1] = __builtin_amdgcn_s_memrealtime(); r[2] = tl_0; r[3] = tl_1; r[4] = tl_2; r[5] = tl_3; r[6] = tl_4;
+            r[7] = ((unsigned long long)total << 32) | ((unsigned long long)(xcc & 0xF) << 28) | (hwid & 0x0FFFFFFFu);
+        }
+    }
+#endif
 }
 
 template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
@@ -1101,9 +1145,24 @@ uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs)
 
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
                     void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats, const FinishPackArgs *rider,
-                    uint32_t *cull_list)
+                    uint32_t *cull_list, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (!(pp.tb.V * pp.tb.naz)) return;
+#ifdef LS_WAVE_TIMELINE
+    {
+        static int n_launch = 0;
+        ++n_launch;
+        const uint32_t on = n_launch == 400 ? 1u : 0u;
+        if (n_launch == 400 || n_launch == 401) (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tl_on), &on, 4, 0, hipMemcpyHostToDevice, s);
+        if (n_launch == 600 && getenv("LS_TIMELINE_OUT")) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h(8 * 32768);
+            (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_timeline), h.size() * 8);
+            FILE *f = fopen(getenv("LS_TIMELINE_OUT"), "wb");
+            if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+    }
+#endif
     static const int fp_at = getenv("LS_PROJECT_FP_AT") ? atoi(getenv("LS_PROJECT_FP_AT")) : -1;
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
@@ -1126,7 +1185,14 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
             return;
         }
         const dim3 grid(blocks);
-#define LS_LAUNCH(C, L, M, K) hipLaunchKernelGGL((k_project<C, L, M, K>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, best, bq, big_capacity, big_count, stats, list)
+        // ev_start / ev_stop (LS_OPT_TIMING = 2): the events ride on the dispatch packet itself and carry the kernel's own
+        // begin / end timestamps (what rocprofv3 reports); events recorded around a launch add ~3 us of barrier packets
+        const bool timed = ev_start || ev_stop;
+        hipEvent_t e0 = ev_start;
+        ev_start = nullptr;   // the first k_project launch of the frame starts the clock, the last one stops it
+#define LS_LAUNCH(C, L, M, K) do { \
+            if (timed) hipExtLaunchKernelGGL((k_project<C, L, M, K>), grid, dim3(kBlock), (L) ? (uint32_t)lds : 0u, s, e0, ev_stop, 0u, pp, batch, best, bq, big_capacity, big_count, stats, list); \
+            else hipLaunchKernelGGL((k_project<C, L, M, K>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, best, bq, big_capacity, big_count, stats, list); } while (0)
 #define LS_LAUNCH_K(C, L, M) do { if (culled) LS_LAUNCH(C, L, M, true); else LS_LAUNCH(C, L, M, false); } while (0)
         if (lt) {
             if (stats) { if (multi) LS_LAUNCH_K(true, true, true); else LS_LAUNCH_K(true, true, false); }
@@ -1147,7 +1213,11 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries)) {
             const dim3 cgrid(entries / kCullPerBlock);
             const size_t clds = 2 * (size_t)pp.tb.V * sizeof(float);
-            if (lt) hipLaunchKernelGGL(k_cull<true>, cgrid, dim3(kBlock), clds, s, pp, batch, cull_list, big_count + kCullCountAt);
+            if (ev_start) {   // the cull pass belongs to the timed stage: the clock starts with it
+                if (lt) hipExtLaunchKernelGGL(k_cull<true>, cgrid, dim3(kBlock), (uint32_t)clds, s, ev_start, nullptr, 0u, pp, batch, cull_list, big_count + kCullCountAt);
+                else hipExtLaunchKernelGGL(k_cull<false>, cgrid, dim3(kBlock), 0u, s, ev_start, nullptr, 0u, pp, batch, cull_list, big_count + kCullCountAt);
+                ev_start = nullptr;
+            } else if (lt) hipLaunchKernelGGL(k_cull<true>, cgrid, dim3(kBlock), clds, s, pp, batch, cull_list, big_count + kCullCountAt);
             else hipLaunchKernelGGL(k_cull<false>, cgrid, dim3(kBlock), 0, s, pp, batch, cull_list, big_count + kCullCountAt);
             launch(batch, blocks, cull_list);
             culled_done = true;

@@ -46,8 +46,8 @@ struct Geometry {
     void *h_stage_v = nullptr, *h_stage_i = nullptr;
     size_t stage_v_cap = 0, stage_i_cap = 0;
     hipEvent_t ev_stage_v = nullptr, ev_stage_i = nullptr;   // recorded behind the last DMA that reads the staging buffer
-    // block culling (projection engine, meshes with 64 triangles per wave): Morton order of the triangles, the
-    // indices in that order, mesh-space bounds per 64 sorted triangles
+    // group culling (projection engine, meshes with 64 triangles per wave): Morton order of the triangles, the
+    // indices in that order, a mesh-space bound (sheared box) per kCullGroup sorted triangles
     uint32_t *d_perm = nullptr, *d_idx_sorted = nullptr;
     float4 *d_boxes = nullptr;
     bool order_stale = true;    // the topology changed since d_perm / d_idx_sorted were made
@@ -285,7 +285,7 @@ struct ls_tracer {
     bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
     uint32_t bvh_order_tris = 0;
     bool last_commit_refit = false;
-    int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (on for azimuth shards narrower than half a turn)
+    int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (geometries of 2 M triangles or more, cull_enabled)
     DevBuf<uint32_t> cull_list;  // three survivor lists (one per frame that can be in flight) of cull_chunks entries
     uint32_t cull_chunks = 0;
     uint32_t *d_aabb6 = nullptr; // scratch of launch_mesh_order
@@ -592,8 +592,11 @@ constexpr size_t kMaxTimingRecords = 4096;
 // Marks 0..6 bracket the six commit stages, 7..9 bracket trace and pack.  A commit opens a new
 // record; a trace without a preceding commit opens its own.
 // marks: 0..6 bracket the six commit stages; 7..10 bracket trace, trace_aux and pack
-void mark(ls_tracer *tr, int i)
+// `ride` (optional): the event is not recorded on the stream here; the caller attaches it to a kernel dispatch
+// (hipExtLaunchKernel), where it carries the kernel's own begin or end timestamp
+void mark(ls_tracer *tr, int i, hipEvent_t *ride = nullptr)
 {
+    if (ride) *ride = nullptr;
     if (!tr->opt_timing) return;
     if (tr->opt_timing == 2 && i != 7 && i != 8) return;
     const bool opens = (i == 0) || (i == 7 && !tr->trec_open);
@@ -611,7 +614,8 @@ void mark(ls_tracer *tr, int i)
     if (!tr->trec_open || tr->trec_used == 0) return;
     ls_tracer::TimingRecord &r = tr->trec[tr->trec_used - 1];
     if (!r.ev[i] && hipEventCreate(&r.ev[i]) != hipSuccess) return;
-    r.set[i] = hipEventRecord(r.ev[i], tr->stream) == hipSuccess;
+    if (ride) { *ride = r.ev[i]; r.set[i] = true; }
+    else r.set[i] = hipEventRecord(r.ev[i], tr->stream) == hipSuccess;
     if (i == 10 || (tr->opt_timing == 2 && i == 8)) tr->trec_open = false;
 }
 
@@ -1143,7 +1147,10 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         }
         uint32_t *counts = tr->row_counts.p + (size_t)(multi ? slot : tr->frame_parity) * n_blocks;
         uint32_t *next_counts = tr->row_counts.p + (size_t)(multi ? 3u : 1u - tr->frame_parity) * n_blocks;
-        mark(tr, 7);
+        // LS_OPT_TIMING = 2 (the dominant kernel alone): the two events ride on the k_project dispatch
+        hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+        const bool ride = tr->opt_timing == 2;
+        mark(tr, 7, ride ? &ev_k0 : nullptr);
         std::vector<ls::GeomSource> &srcs = tr->project_srcs;
         srcs.clear();
         bool any_culled = false;
@@ -1225,8 +1232,10 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             if (readback && (rc = flush_pipeline(tr))) return rc;
         } else {
             // one launch per 16 geometries (the descriptors travel as kernel arguments)
-            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list);
-            mark(tr, 8);
+            if (ride) mark(tr, 8, &ev_k1);
+            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list,
+                               ev_k0, ev_k1);
+            if (!ride) mark(tr, 8);
             ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
             mark(tr, 9);
             ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n, compact);

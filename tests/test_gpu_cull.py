@@ -1,6 +1,7 @@
-"""Block culling of the projection engine (LS_OPT_BLOCK_CULL: Morton-ordered mesh, bounds per 64 triangles, k_cull
-drops blocks no ring / no shard column can meet) must not change a single bit: culled == unculled == BVH engine on the
-headline-sized scene under a moving transform, a vertex update, azimuth shards and both frames-in-flight modes."""
+"""Culling in the projection engine (LS_OPT_BLOCK_CULL: Morton-ordered mesh; a bound per 4 triangles and k_cull, which
+drops groups no ring / no shard column can meet -- forced on here, auto takes it from 2 M triangles) must not change a
+single bit: culled == unculled == BVH
+engine on the headline-sized scene under moving transforms, vertex updates, azimuth shards and both frames-in-flight modes."""
 import numpy as np
 import pytest
 
@@ -28,13 +29,16 @@ def test_cull_equals_unculled_under_transforms_and_shards(oracle, capi, sensors)
     from lidarshooter_amd import synth
     v, t = synth.syn_1m()
     s = _syn_sensor(oracle, sensors, V=128, H=4096)
-    on, off = make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection")
+    # on: group culling forced; auto: the size rule (from 2 M triangles: not here); off
+    on, auto, off = make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection")
+    on.setOption(capi.LS_OPT_BLOCK_CULL, 1)
     off.setOption(capi.LS_OPT_BLOCK_CULL, 0)
-    for tr in (on, off):
+    for tr in (on, auto, off):
         tr.addGeometry("g", v.shape[0], t.shape[0])
         tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
     a, b = _frame(on), _frame(off)
     _same(a, b)
+    _same(_frame(auto), b)
     assert 200000 < len(a[1]) < 300000
     # transform-only updates: the cached mesh-space bounds travel through this frame's matrix
     for lin, ang in (((3.0, -7.5, 0.4), (0.02, -0.03, 0.9)), ((-20.0, 11.0, -1.5), (0.3, 0.1, -2.2)), ((0.0, 0.0, 30.0), (1.2, 0.0, 0.0))):
@@ -51,10 +55,36 @@ def test_cull_equals_unculled_under_transforms_and_shards(oracle, capi, sensors)
     for tr in (on, off):
         tr.updateGeometryTransform("g", oracle.IDENTITY_AFFINE)
     for first, n in ((1000, 256), (0, 2048), (3900, 196), (512, 512)):
-        for tr in (on, off):
+        for tr in (on, auto, off):
             tr.setShard(first, n)
-        _same(_frame(on), _frame(off))
+        ref = _frame(off)
+        _same(_frame(on), ref)
+        _same(_frame(auto), ref)
+    # shards of a moved mesh, rigid or not
+    seen = 0
+    for A in (oracle.affine_from_components(np.array((12.0, -30.0, 0.8), np.float32), np.array((0.05, -0.02, 2.4), np.float32)),
+              np.array([1.5, 0.2, 0.0, 1.0, -0.1, 0.7, 0.3, -2.0, 0.0, 0.4, 2.0, 0.5], np.float32)):
+        for tr in (on, auto, off):
+            tr.updateGeometryTransform("g", A)
+        for first, n in ((0, 512), (1536, 512), (3584, 512), (2000, 100)):
+            for tr in (on, auto, off):
+                tr.setShard(first, n)
+            ref = _frame(off)
+            seen += len(ref[1])
+            _same(_frame(on), ref)
+            _same(_frame(auto), ref)
+    assert seen > 10000
+    # a vertex upload makes the bounds stale: the next commit rebuilds them
+    v2 = v.copy()
+    v2[:, 0] += 3.0
+    for tr in (on, auto, off):
+        tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v2, None)
+        tr.setShard(512, 512)
+    ref = _frame(off)
+    _same(_frame(on), ref)
+    _same(_frame(auto), ref)
     on.close()
+    auto.close()
     off.close()
 
 
@@ -66,6 +96,7 @@ def test_cull_follows_vertex_updates_and_small_meshes(oracle, capi, sensors, mes
     bv, bt = meshes["ben"]
     s = _syn_sensor(oracle, sensors, V=128, H=2048)
     pr, bvh = make_tracer(capi, s, "projection"), make_tracer(capi, s, "bvh")
+    pr.setOption(capi.LS_OPT_BLOCK_CULL, 1)
     for tr in (pr, bvh):
         tr.addGeometry("grid", v.shape[0], t.shape[0])
         tr.addGeometry("face", bv.shape[0], bt.shape[0])
@@ -107,6 +138,7 @@ def test_cull_with_frames_in_flight(oracle, capi, sensors, mode):
         refs.append(_frame(ref_tr)[1:])
     ref_tr.close()
     tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_BLOCK_CULL, 1)
     tr.setOption(capi.LS_OPT_PIPELINE, mode)
     tr.addGeometry("g", v.shape[0], t.shape[0])
     tr.updateGeometryDeviceShared("g", poses[0], dv.data_ptr(), 12, dt.data_ptr())

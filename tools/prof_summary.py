@@ -69,6 +69,39 @@ def overlap_excerpt(src, out):
             w.writerow([name, q, sid, f"{(st - t0) / 1e3:.2f}", f"{(en - t0) / 1e3:.2f}", f"{(en - st) / 1e3:.2f}", live])
 
 
+def isolated_split(src, out):
+    """Per kernel: the dispatches of the trace that ran ALONE (no other dispatch's [start, end) meets theirs) against those
+    that shared the chip with another one (three frames in flight on three streams).  bench.py's `roofline.kernel_ms`
+    is the first kind -- timed with one frame in flight -- so this is the figure of the same command it must agree with;
+    the averages in *_kernel_stats.csv mix both kinds."""
+    rows = []
+    for f in glob.glob(os.path.join(src, "stats", "*_kernel_trace.csv")):
+        for row in csv.DictReader(open(f)):
+            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), short(row["Kernel_Name"])))
+    rows.sort()
+    res = defaultdict(lambda: {"isolated": [], "overlapped": []})
+    max_end_before = 0
+    for i, (st, en, name) in enumerate(rows):
+        alone = st >= max_end_before and (i + 1 == len(rows) or rows[i + 1][0] >= en)
+        res[name]["isolated" if alone else "overlapped"].append((en - st) / 1e3)
+        max_end_before = max(max_end_before, en)
+    summary = {}
+    for name, d in res.items():
+        if not name.startswith("k_"):
+            continue
+        summary[name] = {k + "_calls": len(v) for k, v in d.items()}
+        for k, v in d.items():
+            if v:
+                v.sort()
+                summary[name][k + "_avg_us"] = round(sum(v) / len(v), 3)
+                summary[name][k + "_median_us"] = round(v[len(v) // 2], 3)
+    json.dump({"note": "from the rocprofv3 --kernel-trace of `bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-dropin`: "
+                       "dispatches that ran alone vs dispatches that overlapped another one (durations in microseconds)",
+               "kernels": summary}, open(out + "_kernel_isolated.json", "w"), indent=1)
+    for k in sorted(summary):
+        print("isolated/overlapped", k, summary[k])
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
@@ -95,6 +128,7 @@ def main():
                "kernel_source_sha": bench.kernel_source_sha(),   # bench.py reports `traffic` only while the sources still hash to this
                "kernels": hbm}, open(out + "_hbm.json", "w"), indent=1)
     overlap_excerpt(src, out)
+    isolated_split(src, out)
     for r in rows[:12]:
         print(r[0], r[1], r[3], r[4])
     for k, v in hbm.items():
