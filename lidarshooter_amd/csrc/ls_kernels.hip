@@ -482,26 +482,40 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     const uint32_t nq = tb.V * tb.naz;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
 
-    uint32_t acc = 0;
-    for (uint32_t r = threadIdx.x; r < blockIdx.x; r += kBlock) acc += block_counts[r];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-
+    // every load of the kernel is issued up front -- the ray's key (or t / gid), its table entries, the first geometry
+    // slot, then the counts of the blocks before this one -- so that the kernel is one memory round trip deep, not four
+    // (it is a few microseconds long: round trips are what it consists of)
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     uint32_t gid = kInvalid;
     float t = -1.0f;
+    unsigned long long key = ~0ull;
     if (q < nq) {
         if (FROM_KEYS) {
-            const unsigned long long key = keys[q];
-            keys[q] = ~0ull;
-            if (key != ~0ull) { gid = (uint32_t)key; t = __uint_as_float((uint32_t)(key >> 32)); }
+            key = keys[q];
             // no dense per-ray arrays on this path: ls_debug_dense_hits rebuilds them from the records
         } else {
             gid = gid_io[q];
             t = t_io[q];
         }
     }
+    const uint32_t qq = q < nq ? q : 0u;
+    const uint32_t v = qq / tb.naz, h = tb.az0 + (qq - v * tb.naz);
+    const float st = tb.sin_theta[v], ctv = tb.cos_theta[v];
+    const float2 cs = tb.cs_phi[h];
+    uint32_t first0 = 0, geom0 = 0, shift0 = 0;   // slot 0: the only one of a one-mesh scene
+    if (gt.n) { first0 = gt.tri_first[0]; geom0 = gt.geom_ids[0]; shift0 = gt.prim_shift[0]; }
+
+    uint32_t acc = 0;
+    for (uint32_t r = threadIdx.x; r < blockIdx.x; r += kBlock) acc += block_counts[r];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+
     if (FROM_KEYS) {
+        if (key != ~0ull) {
+            keys[q] = ~0ull;   // re-arm (a key nobody touched is armed already)
+            gid = (uint32_t)key;
+            t = __uint_as_float((uint32_t)(key >> 32));
+        }
         if (threadIdx.x == 0) next_block_counts[blockIdx.x] = 0u;
         if (q == 0) big_count[0] = 0u;                                             // queue length
         if (q < (uint32_t)kGeomsPerLaunch) big_count[kCullCountAt + q] = 0u;        // group-cull survivor counts
@@ -517,15 +531,12 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     const uint32_t dst = base + rank;
 
-    const uint32_t v = q / tb.naz, h = tb.az0 + (q - v * tb.naz);
-    const float st = tb.sin_theta[v];
-    const float2 cs = tb.cs_phi[h];
     // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
     if (compact) {
         // host-visible compact form (LS_OPT_HOST_OUTPUT = 2): 16 bytes cross PCIe, ls_expand_points rebuilds the record
-        points[dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * tb.cos_theta[v], __int_as_float((int)v));
+        points[dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * ctv, __int_as_float((int)v));
     } else {
-        points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * tb.cos_theta[v], 0.0f);
+        points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * ctv, 0.0f);
         points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
     }
     // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
@@ -534,7 +545,8 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         const uint32_t mid = (lo + hi) >> 1;
         if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
     }
-    hits[dst] = make_uint4(v * tb.H + h, gt.geom_ids[lo], (gid - gt.tri_first[lo]) >> gt.prim_shift[lo], __float_as_uint(t));
+    const uint32_t first = lo ? gt.tri_first[lo] : first0, geom = lo ? gt.geom_ids[lo] : geom0, shift = lo ? gt.prim_shift[lo] : shift0;
+    hits[dst] = make_uint4(v * tb.H + h, geom, (gid - first) >> shift, __float_as_uint(t));
 }
 
 // Debug view of the projection engine's result: dense per-ray (t, global triangle id) arrays from
