@@ -65,6 +65,7 @@ def parse_args():
                     help="hand the (unchanged) device mesh over again every frame (ls_update_geometry_device_shared) instead of "
                          "a transform-only update: the library must then assume new vertices and redo its per-block bounds")
     ap.add_argument("--no-cull", action="store_true", help="LS_OPT_BLOCK_CULL off")
+    ap.add_argument("--classic-bvh", action="store_true", help="BVH engine: LS_OPT_BVH_INSTANCED off (one hierarchy in the sensor frame, refitted every frame)")
     ap.add_argument("--cull", action="store_true", help="LS_OPT_BLOCK_CULL on (default: the library's auto rule)")
     ap.add_argument("--multi", default="interleaved", choices=["interleaved", "sharded"],
                     help="N > 1: which way of spreading the frame stream over the GPUs is reported as `value` (the other one is "
@@ -326,6 +327,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
     if args.leaf:
         tr.setOption(capi.LS_OPT_LEAF_SIZE, args.leaf)
     tr.setOption(capi.LS_OPT_ENGINE, {"auto": 0, "bvh": 1, "projection": 2}[args.engine])
+    if args.classic_bvh:
+        tr.setOption(capi.LS_OPT_BVH_INSTANCED, 0)
     if args.no_cull or args.cull:
         tr.setOption(capi.LS_OPT_BLOCK_CULL, 1 if args.cull else 0)
     engine = "bvh" if args.engine == "bvh" else "projection"
@@ -680,7 +683,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
     trace_ms = tm["trace"]
     if engine == "bvh":
         # k_trace: 64 B per node fetch + 48 B per triangle test + 8 B per ray written
-        kernel = "k_trace"
+        kernel = "k_trace_inst" if tr.info(capi.LS_INFO_BVH_INSTANCED) else "k_trace"
         b_launch = RAY_OUT_BYTES * shard_rays + NODE_BYTES * n_node + TRI_BYTES * n_tri
         b_frame = None
         units = {"rays_per_launch": shard_rays, "bytes_per_ray": b_launch / shard_rays,
@@ -737,7 +740,9 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
                    "frame": ("updateGeometry(device mesh handed over in place, every frame) + commitScene + traceScene" if args.reregister else
                              "updateGeometry(mesh resident in HBM and unchanged: its pose is restated, ls_update_geometry_transform) "
                              "+ commitScene + traceScene")
-                            + (" (full BVH rebuild every frame)" if engine == "bvh" else "")
+                            + ((" (BVH engine, instanced: per-geometry hierarchies in mesh space, nothing is built when only poses change)"
+                                if tr.info(capi.LS_INFO_BVH_INSTANCED) else " (BVH engine, classic: the hierarchy is refitted every frame)")
+                               if engine == "bvh" else "")
                             + (("; two frames in flight (finish + pack of frame i ride in the launch of frame i+1)"
                                 if args.pipeline == 1 else "; three frames in flight (whole frames rotate over three streams)")
                                if pipeline else ""),

@@ -264,6 +264,13 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_BVH_REFIT 11     /* BVH engine: 1 (default) a commit after which only vertices / poses differ refits the
                                  *    hierarchy (OptixTracer.cpp:532-535 OPERATION_UPDATE): no key pass, no sort; 0: always
                                  *    a full build.  Identical results.                                                   */
+#define LS_OPT_BVH_INSTANCED 12 /* BVH engine: 1 (default) one hierarchy per geometry, built once in MESH space; every frame
+                                 *    carries the rays into each geometry's mesh space and tests a leaf's triangles exactly as
+                                 *    the other paths do (corners through the frame's transform, same bits) -- a commit after
+                                 *    which only poses differ, the sensor's or a mesh's, builds and refits nothing.  Scenes of
+                                 *    more than 16 geometries or with a (nearly) singular mesh matrix take the classic path
+                                 *    (0: always): one hierarchy in the sensor frame, refitted per LS_OPT_BVH_REFIT.
+                                 *    Identical results.  Takes effect at the next commit.                                */
 #define LS_OPT_BLOCK_CULL 10    /* projection engine, meshes of 524 288 triangles or more: keep the mesh in Morton order with a
                                  *    bound per 4 triangles and drop, before their indices are read, the groups that no ring
                                  *    of the raster and no column of the shard can meet.  0 off, 1 on, 2 (default) auto: on for
@@ -291,6 +298,8 @@ int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
 #define LS_INFO_HOST_THREADS 4       /* worker threads of the host copy pool                                     */
 #define LS_INFO_AZIMUTH_COUNT 5      /* H: azimuth columns of the sensor's full raster (whatever the shard)       */
 #define LS_INFO_LAST_COMMIT_REFIT 6  /* BVH engine: 1 if the last commitScene refitted instead of rebuilding      */
+#define LS_INFO_BVH_INSTANCED 7      /* BVH engine: 0 classic hierarchy; 1 instanced and the last commit built nothing;
+                                      *    2 instanced and the last commit (re)built some geometry's hierarchy        */
 long ls_get_info(ls_tracer *tr, int what);
 
 /* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded

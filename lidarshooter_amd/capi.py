@@ -20,6 +20,8 @@ INVALID = 0xFFFFFFFF
 LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPELINE = 1, 2, 3, 5, 6
 LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL, LS_OPT_BVH_REFIT = 7, 8, 9, 10, 11
 LS_INFO_LAST_COMMIT_REFIT = 6
+LS_OPT_BVH_INSTANCED = 12
+LS_INFO_BVH_INSTANCED = 7
 LS_INFO_CONCURRENT_STREAMS, LS_INFO_PIPELINE_MODE, LS_INFO_DEVICE_STATUS, LS_INFO_HOST_THREADS, LS_INFO_AZIMUTH_COUNT = 1, 2, 3, 4, 5
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
 STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "trace", "trace_aux", "pack")

@@ -142,8 +142,10 @@ void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint
 size_t sort_temp_bytes(uint32_t n);
 void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out,
                  uint32_t *vals_in, uint32_t *vals_out, uint32_t n);
+// mesh_records: the records hold the three corners as given (v0, sorted id | v1, 0 | v2, 0) instead of v0 / e1 / e2 / NgC
+// of the transformed triangle -- the per-geometry hierarchies of the instanced mode, built once in mesh space
 void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,
-                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes);
+                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes, bool mesh_records = false);
 void launch_range_tree(hipStream_t s, const RangeTree &rt, float4 *boxes);
 void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleaves, uint32_t leaf_size,
                       const RangeTree &rt, const float4 *boxes, FatNode *nodes);
@@ -155,6 +157,29 @@ void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, c
                   const FatNode *nodes, const TriRecord *records, uint32_t nleaves, uint32_t leaf_size,
                   uint32_t ntris, float *t_out, uint32_t *gid_out, uint32_t *spill,
                   unsigned long long *visit_counts /* nullptr = do not count */);
+// Instanced mode of the BVH engine (LS_OPT_BVH_INSTANCED): one hierarchy per geometry, built ONCE in mesh space; a frame
+// carries every ray into each geometry's mesh space (origin o, linear part minv of the inverse of mesh -> sensor, so
+// that the ray parameter t is the sensor-space one), walks that hierarchy with boxes widened by eps, and tests a leaf's
+// triangles exactly as the other paths do: corners through the frame's transform `m`, then the Embree test against the
+// sensor-space table direction.  A pose change -- the sensor's or a mesh's -- costs no build and no refit.
+struct InstGeom {
+    uint32_t node_first, rec_first;   // this geometry's nodes / records inside the shared arrays
+    uint32_t n_leaves;                // 0: nothing to trace
+    uint32_t n_tris;                  // its last leaf may be short
+    uint32_t gid_first;               // global triangle id of its triangle 0
+    int xform;                        // 1: full transform, 2: A is the identity (as GeomSource::xform)
+    float o[3];                       // ray origin (the sensor) in mesh space
+    float eps;                        // widening of every box (covers the rounding of o and of minv * d)
+    float minv[9];                    // sensor-space direction -> mesh-space direction (row-major)
+    Affine m;                         // mesh -> sensor, as everywhere else
+};
+struct InstBatch {
+    uint32_t n;
+    InstGeom g[kGeomsPerLaunch];
+};
+void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq, const InstBatch &batch,
+                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, float *t_out, uint32_t *gid_out,
+                            uint32_t *spill, unsigned long long *visit_counts /* nullptr = do not count */);
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts);
 // compact != 0: points are written as 16-byte records (x, y, z, ring) instead of the 32-byte PointCloud2 layout
 void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,

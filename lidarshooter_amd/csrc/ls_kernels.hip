@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kBlock) void k_morton(const float *__restrict__ ver
 // Leaf k = records [k*g, k*g+g); its box (padded, see below) is entry k of range-tree level 0.
 // Bytes per triangle: 4 (sorted id) + 12 (indices) + 36 (vertices) read, 48 written, + 32/g.
 // ------------------------------------------------------------------------------------------
+template <bool MESH_RECORDS>
 __global__ __launch_bounds__(kBlock) void k_leaves(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
                                                    const uint32_t *__restrict__ sorted_vals, uint32_t ntris,
                                                    uint32_t g, TriRecord *__restrict__ records,
@@ -135,9 +136,15 @@ __global__ __launch_bounds__(kBlock) void k_leaves(const float *__restrict__ ver
         const V3 Ng = cross_fma(e2, e1);
         const float NgC = dot_fma(Ng, v0);
         float4 *r = reinterpret_cast<float4 *>(records + p);
-        r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
-        r[1] = make_float4(e1.x, e1.y, e1.z, NgC);
-        r[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        if (MESH_RECORDS) {   // the corners as given: the trace kernel carries them into the sensor frame of its frame
+            r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
+            r[1] = make_float4(v1.x, v1.y, v1.z, 0.0f);
+            r[2] = make_float4(v2.x, v2.y, v2.z, 0.0f);
+        } else {
+            r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
+            r[1] = make_float4(e1.x, e1.y, e1.z, NgC);
+            r[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        }
         // The triangle test accepts rays that miss the exact triangle by rounding error, so boxes
         // are fattened by 2^-16 of the largest |coordinate|: BVH result == exhaustive result.
         const float m = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v1.x))),
@@ -446,6 +453,184 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Instanced mode: the same persistent waves and ray refill as k_trace, over one hierarchy PER GEOMETRY built once in
+// mesh space (InstBatch, ls_kernels.h).  A lane walks the geometries one after the other: ray origin o and direction
+// minv * d in that geometry's mesh space (the parameter t stays the sensor-space one, so the closest hit so far prunes
+// across geometries), slab tests against boxes widened by eps -- (lo - eps - o) * inv and (hi + eps - o) * inv as one
+// fused multiply-add each --, the nearer child first (a mesh-space hierarchy has no front-to-back order by
+// construction), and at a leaf the exact test of every other path: the three corners through this frame's transform
+// (xform_vertex: the bits of k_transform / k_project), e1, e2, NgC, Embree's test against the table direction.
+// ------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueues rq, InstBatch batch, const FatNode *__restrict__ nodes,
+                                                       const TriRecord *__restrict__ records, uint32_t g, float *__restrict__ t_out,
+                                                       uint32_t *__restrict__ gid_out, uint32_t *__restrict__ spill,
+                                                       unsigned long long *__restrict__ visit_counts)
+{
+    __shared__ uint32_t s_stack[kStackLds][kBlock];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t *my_spill = spill + ((size_t)blockIdx.x * kBlock + tid) * kStackSpill;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t qsel = xcc & (kQueues - 1);
+    uint32_t tried = 0;
+    bool drained = false;
+
+    bool has = false;
+    V3 d = {0.f, 0.f, 1.f};
+    float ix = 1.f, iy = 1.f, iz = 1.f, best = INFINITY;
+    float cxl = 0.f, cxh = 0.f, cyl = 0.f, cyh = 0.f, czl = 0.f, czh = 0.f;   // -(o +- eps) * inv per axis
+    uint32_t bid = kInvalid, q = 0, cur = kInvalid, sp = 0, gi = 0;
+    uint32_t cn = 0, ctri = 0, trips = 0;
+    const float4 *rec4 = reinterpret_cast<const float4 *>(records);
+
+    // the ray of this lane in geometry `gi`'s mesh space; cur = its root (kInvalid: nothing there)
+    auto enter = [&](uint32_t k) {
+        const InstGeom &ig = batch.g[k];
+        cur = kInvalid;
+        if (!ig.n_leaves) return;
+        const float dx = (ig.minv[0] * d.x + ig.minv[1] * d.y) + ig.minv[2] * d.z;
+        const float dy = (ig.minv[3] * d.x + ig.minv[4] * d.y) + ig.minv[5] * d.z;
+        const float dz = (ig.minv[6] * d.x + ig.minv[7] * d.y) + ig.minv[8] * d.z;
+        ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
+        cxl = -(ig.o[0] + ig.eps) * ix; cxh = -(ig.o[0] - ig.eps) * ix;
+        cyl = -(ig.o[1] + ig.eps) * iy; cyh = -(ig.o[1] - ig.eps) * iy;
+        czl = -(ig.o[2] + ig.eps) * iz; czh = -(ig.o[2] - ig.eps) * iz;
+        cur = ig.n_leaves > 1u ? 0u : kLeafBit;
+    };
+    // next thing to do for a lane whose current subtree is finished: the stack, else the next geometry, else done
+    auto advance = [&]() {
+        cur = kInvalid;
+        if (sp) { --sp; cur = sp < (uint32_t)kStackLds ? s_stack[sp][tid] : my_spill[sp - kStackLds]; return; }
+        while (cur == kInvalid && ++gi < batch.n) enter(gi);
+    };
+
+    while (true) {
+        unsigned long long act = __ballot(has);
+        if (!drained && (uint32_t)__popcll(act) <= 64u - rq.refill_min) {
+            const unsigned long long idle = ~act;
+            const uint32_t nidle = (uint32_t)__popcll(idle);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            while (tried < (uint32_t)kQueues) {
+                const uint32_t first = (uint32_t)(((unsigned long long)qsel * tb.naz) / kQueues);
+                const uint32_t width = (uint32_t)(((unsigned long long)(qsel + 1u) * tb.naz) / kQueues) - first;
+                const uint32_t len = width * tb.V;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&rq.heads[qsel * 16u], nidle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base < len) {
+                    const uint32_t sidx = base + rank;
+                    if (!has && sidx < len) {
+                        const uint32_t j = sidx / width, c = sidx - j * width;
+                        const uint32_t v = (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        const uint32_t hl = first + c, h = tb.az0 + hl;
+                        // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
+                        const float st = tb.sin_theta[v];
+                        d = {st * tb.cos_phi[h], st * tb.sin_phi[h], tb.cos_theta[v]};
+                        q = v * tb.naz + hl;
+                        best = INFINITY; bid = kInvalid; sp = 0; has = true;
+                        gi = 0;
+                        enter(0);
+                        while (cur == kInvalid && ++gi < batch.n) enter(gi);
+                    }
+                    break;
+                }
+                ++tried;
+                qsel = (qsel + 1u) & (kQueues - 1);
+            }
+            if (tried >= (uint32_t)kQueues) drained = true;
+            act = __ballot(has);
+        }
+        if (act == 0ull) break;
+        if (COUNT) ++trips;
+        // one traversal step of this lane in geometry `ig`: a node (both child boxes), then the leaves it leads to
+        auto step = [&](const InstGeom &ig) {
+            if (cur != kInvalid && !(cur & kLeafBit)) {
+                const float4 *nd = nodes[ig.node_first + cur].q;
+                const float4 A = nd[0], B = nd[1], C = nd[2], D = nd[3];
+                if (COUNT) ++cn;
+                float x1 = fmaf(A.x, ix, cxl), x2 = fmaf(B.x, ix, cxh), y1 = fmaf(A.y, iy, cyl), y2 = fmaf(B.y, iy, cyh),
+                      z1 = fmaf(A.z, iz, czl), z2 = fmaf(B.z, iz, czh);
+                const float tnL = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
+                const float tfL = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), best));
+                x1 = fmaf(C.x, ix, cxl); x2 = fmaf(D.x, ix, cxh); y1 = fmaf(C.y, iy, cyl); y2 = fmaf(D.y, iy, cyh);
+                z1 = fmaf(C.z, iz, czl); z2 = fmaf(D.z, iz, czh);
+                const float tnR = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
+                const float tfR = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), best));
+                // (the far bound gets two ulps: the products above round once each)
+                const bool hl_ = tnL <= tfL * 1.0000003f, hr_ = tnR <= tfR * 1.0000003f;
+                const uint32_t left = __float_as_uint(A.w), right = __float_as_uint(B.w);
+                if (hl_ && hr_) {
+                    const bool left_first = tnL <= tnR;
+                    const uint32_t far_child = left_first ? right : left;
+                    cur = left_first ? left : right;
+                    if (sp < (uint32_t)kStackLds) s_stack[sp][tid] = far_child;
+                    else if (sp < (uint32_t)(kStackLds + kStackSpill)) my_spill[sp - kStackLds] = far_child;
+                    ++sp;
+                } else if (hl_) {
+                    cur = left;
+                } else if (hr_) {
+                    cur = right;
+                } else {
+                    advance();
+                }
+            }
+            // (a leaf reached above belongs to `ig`; after advance() moved on to another geometry the loop ends and the
+            // next trip continues there)
+            const uint32_t at_entry = gi;
+            while (cur != kInvalid && (cur & kLeafBit) && gi == at_entry) {
+                const uint32_t first = (cur & ~kLeafBit) * g;
+                const uint32_t last = min(first + g, ig.n_tris);
+                for (uint32_t s = first; s < last; ++s) {
+                    const size_t at = 3 * ((size_t)ig.rec_first + s);
+                    const float4 r0 = rec4[at], r1 = rec4[at + 1], r2 = rec4[at + 2];
+                    const uint32_t local = __float_as_uint(r0.w);
+                    if (COUNT) ++ctri;
+                    V3 v0, v1, v2;
+                    if (ig.xform == 2) {
+                        v0 = xform_vertex_sensor_only(ig.m, reinterpret_cast<const uint8_t *>(&r0));
+                        v1 = xform_vertex_sensor_only(ig.m, reinterpret_cast<const uint8_t *>(&r1));
+                        v2 = xform_vertex_sensor_only(ig.m, reinterpret_cast<const uint8_t *>(&r2));
+                    } else {
+                        v0 = xform_vertex(ig.m, reinterpret_cast<const uint8_t *>(&r0));
+                        v1 = xform_vertex(ig.m, reinterpret_cast<const uint8_t *>(&r1));
+                        v2 = xform_vertex(ig.m, reinterpret_cast<const uint8_t *>(&r2));
+                    }
+                    const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
+                    const float NgC = dot_fma(cross_fma(e2, e1), v0);
+                    float t;
+                    if (tri_test(d, v0, e1, e2, NgC, t)) {
+                        const uint32_t id = ig.gid_first + local;
+                        if (t < best || (t == best && id < bid)) { best = t; bid = id; }
+                    }
+                }
+                advance();
+            }
+        };
+        if (has) {
+            // one geometry (the usual scene): its descriptor is wave-uniform and lives in scalar registers
+            if (batch.n == 1u) step(batch.g[0]);
+            else step(batch.g[gi]);
+            if (cur == kInvalid) {
+                t_out[q] = (bid == kInvalid) ? -1.0f : best;
+                gid_out[q] = bid;
+                has = false;
+            }
+        }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { cn += __shfl_xor(cn, off); ctri += __shfl_xor(ctri, off); }
+        if (lane == 0) {
+            atomicAdd(&visit_counts[0], (unsigned long long)cn);
+            atomicAdd(&visit_counts[1], (unsigned long long)ctri);
+            atomicAdd(&visit_counts[2], (unsigned long long)trips);
+            atomicMax(&visit_counts[3], (unsigned long long)trips);
+        }
+    }
+}
+
 // hits per block of 256 consecutive rays (feeds the ordered pack)
 __global__ __launch_bounds__(kBlock) void k_rowcount(const uint32_t *__restrict__ gid, uint32_t n,
                                                      uint32_t *__restrict__ block_counts)
@@ -741,11 +926,15 @@ void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in
 }
 
 void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,
-                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes)
+                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes, bool mesh_records)
 {
     if (!ntris) return;
-    hipLaunchKernelGGL(k_leaves, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris,
-                       leaf_size, records, boxes);
+    if (mesh_records)
+        hipLaunchKernelGGL(k_leaves<true>, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris,
+                           leaf_size, records, boxes);
+    else
+        hipLaunchKernelGGL(k_leaves<false>, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris,
+                           leaf_size, records, boxes);
 }
 
 void launch_range_tree(hipStream_t s, const RangeTree &rt, float4 *boxes)
@@ -797,6 +986,21 @@ void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, c
     else
         hipLaunchKernelGGL((k_trace<false, 0>), dim3(grid), dim3(kBlock), 0, s, tb, rq, nodes, records, nleaves,
                            leaf_size, ntris, t_out, gid_out, spill, visit_counts);
+}
+
+void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq, const InstBatch &batch,
+                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, float *t_out, uint32_t *gid_out,
+                            uint32_t *spill, unsigned long long *visit_counts)
+{
+    const uint32_t nq = tb.V * tb.naz;
+    if (!nq || !batch.n) return;
+    const uint32_t grid = min(grid_blocks, (nq + kBlock - 1) / kBlock);
+    if (visit_counts)
+        hipLaunchKernelGGL(k_trace_inst<true>, dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, records, leaf_size, t_out, gid_out,
+                           spill, visit_counts);
+    else
+        hipLaunchKernelGGL(k_trace_inst<false>, dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, records, leaf_size, t_out, gid_out,
+                           spill, visit_counts);
 }
 
 void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t n_quads, uint32_t *tri_idx)

@@ -52,6 +52,8 @@ struct Geometry {
     float4 *d_boxes = nullptr;
     bool order_stale = true;    // the topology changed since d_perm / d_idx_sorted were made
     bool bounds_stale = true;   // vertices (may have) changed since d_boxes were made
+    bool blas_dirty = true;     // BVH engine, instanced mode: vertices or topology changed since this geometry's hierarchy was built
+    float mesh_maxabs = 0.0f;   // largest |coordinate| of the mesh as uploaded (read back when that hierarchy is built)
     const void *raw() const { return shared_raw ? shared_raw : d_raw; }
     const uint32_t *idx() const { return shared_idx ? shared_idx : d_idx; }
     float affine[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -282,6 +284,16 @@ struct ls_tracer {
     uint32_t *h_n_points = nullptr;
     bool traced = false;
     int opt_bvh_refit = 1;       // LS_OPT_BVH_REFIT
+    int opt_bvh_instanced = 1;   // LS_OPT_BVH_INSTANCED: per-geometry hierarchies in mesh space, no build / refit for pose changes
+    bool bvh_inst = false;       // the committed BVH is the instanced one
+    bool inst_valid = false;     // records / nodes / inst_layout hold instanced hierarchies for the current layout and leaf size
+    bool last_commit_built = false;
+    struct InstSlot { uint32_t node_first, rec_first, n_leaves, range_first; ls::RangeTree rt; };
+    std::vector<InstSlot> inst_layout;   // per layout entry
+    uint32_t inst_leaf_size = 0;
+    DevBuf<float> inst_verts;    // packed mesh-space vertices of all geometries (build input)
+    DevBuf<uint32_t> inst_tris;  // their indices, rebased
+    uint32_t *d_inst_maxabs = nullptr;   // kGeomsPerLaunch words
     bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
     uint32_t bvh_order_tris = 0;
     bool last_commit_refit = false;
@@ -783,6 +795,7 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         g.stride = stride;
         g.has_verts = true;
         g.bounds_stale = true;   // the caller's buffer may hold anything now
+        g.blas_dirty = true;
         if (idx && g.quad) {
             // quads are traced as triangle pairs: the caller's indices are converted into a library-owned array
             if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), (size_t)g.n_tris * 12 + 4));
@@ -792,8 +805,8 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
             ls::launch_quads_to_triangles(tr->stream, idx, g.n_elems, g.d_idx);
             g.shared_idx = nullptr;
             if (!g.has_idx) tr->layout_dirty = true;
-            g.has_idx = true; g.idx_dirty = true; g.order_stale = true;
-        } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; }
+            g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = true;
+        } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = true; }
         return LS_OK;
     }
     if (!verts && !idx) return LS_OK;   // transform only: nothing is copied, nothing to order
@@ -826,10 +839,12 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         if (!g.has_verts) tr->layout_dirty = true;
         g.has_verts = true;
         g.bounds_stale = true;
+        g.blas_dirty = true;
     }
     if (idx) {
         g.shared_idx = nullptr;
         g.order_stale = true;
+        g.blas_dirty = true;
         const size_t bytes = g.quad ? (size_t)g.n_elems * 16 : (size_t)g.n_tris * 12;
         if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), (size_t)g.n_tris * 12 + 4));
         if (g.quad && !g.d_quad_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_quad_idx), bytes ? bytes : 4));
@@ -938,6 +953,137 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
     return LS_OK;
 }
 
+// ---- BVH engine, instanced mode (LS_OPT_BVH_INSTANCED) --------------------------------------------------------------
+// mesh -> sensor of one geometry is p = Mlin v + Mtr with Mlin = Rinv A_lin, Mtr = Rinv (a - t).  Its inverse (double
+// precision) gives the sensor origin and the direction map in mesh space; false if the matrix is (nearly) singular --
+// such a scene takes the classic path (build / refit in the sensor frame).
+bool inst_inverse(const ls_tracer *tr, const Geometry &ge, double *minv9, double *o3, double *cond)
+{
+    double M[9], tr3[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += (double)tr->rinv[3 * i + k] * (double)ge.affine[4 * k + j];
+            M[3 * i + j] = acc;
+        }
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k) acc += (double)tr->rinv[3 * i + k] * ((double)ge.affine[4 * k + 3] - (double)tr->t[k]);
+        tr3[i] = acc;
+    }
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    double nM = 0.0;
+    for (double v : M) nM += v * v;
+    if (!(std::fabs(det) > 1e-12 * std::pow(nM, 1.5)) || !std::isfinite(det)) return false;
+    const double id = 1.0 / det;
+    minv9[0] = c00 * id; minv9[1] = (M[2] * M[7] - M[1] * M[8]) * id; minv9[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    minv9[3] = c01 * id; minv9[4] = (M[0] * M[8] - M[2] * M[6]) * id; minv9[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    minv9[6] = c02 * id; minv9[7] = (M[1] * M[6] - M[0] * M[7]) * id; minv9[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+    double nI = 0.0;
+    for (int i = 0; i < 9; ++i) nI += minv9[i] * minv9[i];
+    *cond = std::sqrt(nM * nI) / 3.0;   // 1 for a rotation
+    for (int i = 0; i < 3; ++i) o3[i] = -(minv9[3 * i] * tr3[0] + minv9[3 * i + 1] * tr3[1] + minv9[3 * i + 2] * tr3[2]);
+    for (int i = 0; i < 3; ++i) if (!std::isfinite(o3[i])) return false;
+    return *cond < 1e3;
+}
+
+bool inst_possible(const ls_tracer *tr, const std::vector<Geometry *> &order)
+{
+    if (!tr->opt_bvh_instanced || order.size() > (size_t)ls::kGeomsPerLaunch) return false;
+    for (const Geometry *ge : order) {
+        double minv[9], o[3], cond;
+        if (!inst_inverse(tr, *ge, minv, o, &cond)) return false;
+    }
+    return true;
+}
+
+// Hierarchies of the geometries whose vertices or topology changed (all of them after a layout change), each over its
+// own slice of the shared key / record / node arrays, in MESH space: the same kernels as the classic build, fed with the
+// vertices as uploaded.  A commit after which only poses differ finds nothing to do here.
+int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool relayout)
+{
+    const uint32_t g = tr->leaf_size;
+    const bool fresh = relayout || !tr->inst_valid || tr->inst_leaf_size != g || tr->inst_layout.size() != order.size();
+    int rc;
+    if (fresh) {
+        tr->inst_layout.assign(order.size(), ls_tracer::InstSlot());
+        uint32_t nodes = 0, recs = 0, range = 0;
+        for (size_t i = 0; i < order.size(); ++i) {
+            ls_tracer::InstSlot &sl = tr->inst_layout[i];
+            const uint32_t L = (order[i]->n_tris + g - 1) / g;
+            sl.node_first = nodes; sl.rec_first = recs; sl.n_leaves = L; sl.range_first = range;
+            std::memset(&sl.rt, 0, sizeof(sl.rt));
+            uint32_t cnt = L, off = 0, lev = 0;
+            while (true) {
+                sl.rt.count[lev] = cnt; sl.rt.offset[lev] = off;
+                off += cnt; ++lev;
+                if (cnt <= 1) break;
+                cnt = (cnt + 1) / 2;
+            }
+            sl.rt.levels = lev;
+            nodes += L; recs += L * g; range += 2 * off + 2;
+        }
+        if ((rc = ensure(tr, tr->records, (size_t)recs))) return rc;
+        if ((rc = ensure(tr, tr->nodes, (size_t)nodes + 1))) return rc;
+        if ((rc = ensure(tr, tr->range_boxes, (size_t)range + 2))) return rc;
+        tr->n_leaves = nodes;
+        tr->inst_leaf_size = g;
+    }
+    bool any = false;
+    for (const Geometry *ge : order) any = any || fresh || ge->blas_dirty;
+    tr->last_commit_built = any;
+    if (any) {
+        if ((rc = ensure(tr, tr->inst_verts, (size_t)tr->n_verts * 3))) return rc;
+        if ((rc = ensure(tr, tr->inst_tris, (size_t)tr->n_tris * 3))) return rc;
+        if ((rc = ensure(tr, tr->keys_a, tr->n_tris))) return rc;
+        if ((rc = ensure(tr, tr->keys_b, tr->n_tris))) return rc;
+        if ((rc = ensure(tr, tr->vals_a, tr->n_tris))) return rc;
+        if ((rc = ensure(tr, tr->vals_b, tr->n_tris))) return rc;
+        uint32_t biggest = 0;
+        for (const Geometry *ge : order) biggest = std::max(biggest, ge->n_tris);
+        if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(biggest)))) return rc;
+        if (!tr->d_inst_maxabs) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_inst_maxabs), ls::kGeomsPerLaunch * 4));
+        tr->bvh_order_valid = false;   // the key arrays are the scratch of these builds
+        hipStream_t s = tr->stream;
+        static const float kIdA[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, kIdR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kZero[3] = {0, 0, 0};
+        LS_HIP(hipMemsetAsync(tr->d_inst_maxabs, 0, ls::kGeomsPerLaunch * 4, s));
+        for (size_t i = 0; i < order.size(); ++i) {
+            Geometry &ge = *order[i];
+            if (!fresh && !ge.blas_dirty) continue;
+            const ls_tracer::LayoutEntry &le = tr->layout[i];
+            const ls_tracer::InstSlot &sl = tr->inst_layout[i];
+            float *verts = tr->inst_verts.p + 3 * (size_t)le.vfirst;
+            uint32_t *tris = tr->inst_tris.p + 3 * (size_t)le.tfirst;
+            uint32_t *ka = tr->keys_a.p + le.tfirst, *kb = tr->keys_b.p + le.tfirst, *va = tr->vals_a.p + le.tfirst, *vb = tr->vals_b.p + le.tfirst;
+            // identity transform: the packed copy holds the vertices as uploaded (1 * x + 0 * y + 0 * z + 0 is x)
+            ls::launch_transform(s, ge.raw(), ge.stride, ge.n_verts, kIdA, kIdR, kZero, verts, tr->d_inst_maxabs + i);
+            ls::launch_rebase(s, ge.idx(), ge.n_tris * 3, 0u, tris);
+            ls::launch_morton(s, verts, tris, ge.n_tris, tr->d_inst_maxabs + i, ka, va);
+            ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, ka, kb, va, vb, ge.n_tris);
+            float4 *rb = tr->range_boxes.p + sl.range_first;
+            ls::launch_leaves(s, verts, tris, vb, ge.n_tris, g, tr->records.p + sl.rec_first, rb, true);
+            ls::launch_range_tree(s, sl.rt, rb);
+            ls::launch_hierarchy(s, kb, sl.n_leaves, g, sl.rt, rb, tr->nodes.p + sl.node_first);
+        }
+        LS_HIP(hipGetLastError());
+        // the extent of every rebuilt mesh (the widening of its boxes at trace time is scaled by it)
+        uint32_t bits[ls::kGeomsPerLaunch];
+        LS_HIP(hipMemcpyAsync(bits, tr->d_inst_maxabs, sizeof(bits), hipMemcpyDeviceToHost, s));
+        LS_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < order.size(); ++i) {
+            Geometry &ge = *order[i];
+            if (!fresh && !ge.blas_dirty) continue;
+            std::memcpy(&ge.mesh_maxabs, &bits[i], 4);
+            ge.blas_dirty = false;
+        }
+    }
+    tr->inst_valid = true;
+    tr->bvh_inst = true;
+    tr->bvh_built = true;
+    tr->scene_materialized = false;   // tr->verts / tr->tris (sensor frame) were not made: the debug views make them on demand
+    return LS_OK;
+}
+
 int commit_locked(ls_tracer *tr)
 {
     tr->committed = false;
@@ -1007,13 +1153,20 @@ int commit_locked(ls_tracer *tr)
     hipStream_t s = tr->stream;
     const bool want_bvh = !use_projection(tr);
     mark(tr, 0);
-    if (want_bvh) {
+    if (want_bvh && inst_possible(tr, order)) {
+        // BVH engine, instanced mode: per-geometry hierarchies in mesh space; nothing to do when only poses changed
+        if ((rc = commit_instanced(tr, order, relayout))) return rc;
+        mark(tr, 6);
+    } else if (want_bvh) {
         // BVH engine: transform every geometry into the sensor frame, then the LBVH: a full build (Morton keys, radix
         // sort, leaves, range tree, hierarchy), or -- when only vertices / poses changed since the last build, the case
         // OptixTracer handles with OPTIX_BUILD_OPERATION_UPDATE (OptixTracer.cpp:532-535) -- a REFIT: the triangles keep
         // their Morton order and the radix tree its topology (both come from the sorted keys, which stay), records and
         // every box are recomputed from the new vertices (leaf boxes, aligned-range tree, both child boxes of every
         // node by range query).  Always a valid BVH; the sort and the key pass (half of the build) are not run.
+        tr->bvh_inst = false;
+        tr->inst_valid = false;        // the shared record / node arrays are about to hold the sensor-frame hierarchy
+        tr->last_commit_built = true;
         bool any_idx_dirty = false;
         for (const Geometry *ge : order) any_idx_dirty = any_idx_dirty || ge->idx_dirty;
         const bool refit = tr->opt_bvh_refit && !relayout && !any_idx_dirty && tr->bvh_order_valid && tr->bvh_order_tris == nt;
@@ -1042,6 +1195,7 @@ int commit_locked(ls_tracer *tr)
         mark(tr, 6);
         LS_HIP(hipGetLastError());
         tr->bvh_built = true;
+        for (Geometry *ge : order) ge->blas_dirty = true;   // whatever instanced hierarchies there were are overwritten
     } else {
         // projection engine: no hierarchy to build -- the trace kernel streams the meshes as uploaded and applies
         // the vertex transform on the fly.  Big meshes keep a Morton order (per topology) and per-block bounds
@@ -1262,8 +1416,42 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         rq.chan_mul = tr->chan_mul;
         rq.refill_min = tr->refill_min;
         mark(tr, 7);
-        ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,
-                         tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
+        if (tr->bvh_inst) {
+            // this frame's poses: every geometry's ray map (inverse of mesh -> sensor) and exact transform
+            ls::InstBatch batch;
+            batch.n = (uint32_t)tr->layout.size();
+            for (uint32_t i = 0; i < batch.n; ++i) {
+                auto it = tr->geoms.find(tr->layout[i].name);
+                if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
+                const Geometry &ge = it->second;
+                const ls_tracer::InstSlot &sl = tr->inst_layout[i];
+                ls::InstGeom &ig = batch.g[i];
+                double minv[9], o[3], cond = 1.0;
+                const bool ok = !ge.blas_dirty && inst_inverse(tr, ge, minv, o, &cond);
+                if (!ok) return fail(tr, LS_ERR_NOT_COMMITTED, "a geometry or pose changed since the last commit");
+                ig.node_first = sl.node_first;
+                ig.rec_first = sl.rec_first;
+                ig.n_leaves = sl.n_leaves;
+                ig.n_tris = ge.n_tris;
+                ig.gid_first = tr->layout[i].tfirst;
+                static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                ig.xform = std::memcmp(ge.affine, kIdentity, sizeof(kIdentity)) == 0 ? 2 : 1;
+                float omax = 0.0f;
+                for (int k = 0; k < 3; ++k) { ig.o[k] = (float)o[k]; omax = std::max(omax, std::fabs(ig.o[k])); }
+                for (int k = 0; k < 9; ++k) ig.minv[k] = (float)minv[k];
+                // rounding of o (6e-8 |o|) and of minv * d along the way to any box (<= |o| + the mesh's extent), times
+                // the conditioning of the map, with a factor of ten in hand
+                ig.eps = 4e-6f * (float)std::max(1.0, cond) * (omax + 2.0f * ge.mesh_maxabs);
+                std::memcpy(ig.m.a, ge.affine, sizeof(ig.m.a));
+                std::memcpy(ig.m.rinv, tr->rinv, sizeof(ig.m.rinv));
+                std::memcpy(ig.m.t, tr->t, sizeof(ig.m.t));
+            }
+            ls::launch_trace_instanced(s, tr->trace_blocks, tb, rq, batch, tr->nodes.p, tr->records.p, tr->inst_leaf_size,
+                                       tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
+        } else {
+            ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,
+                             tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
+        }
         mark(tr, 8);
         ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p);
         tr->keys_armed = false;  // the counter array was just used with the BVH layout
@@ -1434,6 +1622,8 @@ void ls_tracer_destroy(ls_tracer *tr)
     }
     release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
     release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
+    release(tr->inst_verts); release(tr->inst_tris);
+    if (tr->d_inst_maxabs) (void)hipFree(tr->d_inst_maxabs);
     release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
     release(tr->row_counts); release(tr->points); release(tr->hits);
     if (tr->d_tables) (void)hipFree(tr->d_tables);
@@ -1719,7 +1909,8 @@ long ls_get_info(ls_tracer *tr, int what)
     }
     case LS_INFO_HOST_THREADS: return HostPool::get().threads();
     case LS_INFO_AZIMUTH_COUNT: return (long)tr->H;
-    case LS_INFO_LAST_COMMIT_REFIT: return tr->last_commit_refit ? 1 : 0;
+    case LS_INFO_LAST_COMMIT_REFIT: return (!tr->bvh_inst && tr->last_commit_refit) ? 1 : 0;
+    case LS_INFO_BVH_INSTANCED: return tr->bvh_inst ? (tr->last_commit_built ? 2 : 1) : 0;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }
@@ -1771,6 +1962,7 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         return LS_OK;
     case LS_OPT_DEBUG_FAULT: tr->opt_debug_fault = value != 0; return LS_OK;
     case LS_OPT_BVH_REFIT: tr->opt_bvh_refit = value != 0; return LS_OK;
+    case LS_OPT_BVH_INSTANCED: tr->opt_bvh_instanced = value != 0; tr->committed = false; return LS_OK;   // takes effect at the next commit
     case LS_OPT_BLOCK_CULL:
         if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto");
         tr->opt_block_cull = value;
@@ -1947,6 +2139,7 @@ int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records)
 {
     LS_ENTER(tr);
     if (!tr->committed || !tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "no BVH: commit with LS_OPT_ENGINE = 1");
+    if (tr->bvh_inst) return fail(tr, LS_ERR_NOT_COMMITTED, "the debug view shows the classic hierarchy: commit with LS_OPT_BVH_INSTANCED = 0");
     LS_HIP(hipStreamSynchronize(tr->stream));
     if (nodes) LS_HIP(hipMemcpy(nodes, tr->nodes.p, (size_t)tr->n_slots * sizeof(ls::FatNode), hipMemcpyDeviceToHost));
     if (tri_records) LS_HIP(hipMemcpy(tri_records, tr->records.p, (size_t)tr->n_tris * sizeof(ls::TriRecord), hipMemcpyDeviceToHost));

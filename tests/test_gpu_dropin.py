@@ -253,11 +253,12 @@ def test_bvh_refit(oracle, capi, sensors, meshes):
     gv, gt = synth.grid_mesh(120, 80, half=45.0, seed=2)
     bv, bt = meshes["ben"]
     tr = make_tracer(capi, s, "bvh")
+    tr.setOption(capi.LS_OPT_BVH_INSTANCED, 0)           # the classic hierarchy in the sensor frame (the instanced one never refits)
     tr.addGeometry("ground", gv.shape[0], gt.shape[0])
     tr.addGeometry("face", bv.shape[0], bt.shape[0])
     tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gv, gt)
     tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
-    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == 0
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 0
     poses = [((0, 0, 0), (0, 0, 0)), ((2.0, -1.0, 0.2), (0.0, 0.1, 0.8)), ((-25.0, 30.0, 1.0), (0.3, 0.0, -2.0)), ((40.0, 40.0, 5.0), (0.0, 0.0, 3.0))]
     for k, (lin, ang) in enumerate(poses):
         A = oracle.affine_from_components(np.array(lin, np.float32), np.array(ang, np.float32))
@@ -280,4 +281,84 @@ def test_bvh_refit(oracle, capi, sensors, meshes):
     tr.setOption(capi.LS_OPT_BVH_REFIT, 0)
     tr.updateGeometryTransform("face", oracle.IDENTITY_AFFINE)
     assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == 0
+    tr.close()
+
+
+def test_bvh_instanced(oracle, capi, sensors, meshes):
+    """BVH engine, instanced mode (the default): one hierarchy per geometry in mesh space, rays carried into it.  A commit
+    after which only poses differ builds nothing; a vertex or topology change rebuilds that geometry alone; matrices that
+    are not rigid work as long as they can be inverted, a singular one and a scene of more than 16 geometries take the
+    classic path.  Every frame equals the oracle bit for bit."""
+    from lidarshooter_amd import synth
+    s = sensors["0000"]
+    gv, gt = synth.grid_mesh(120, 80, half=45.0, seed=2)
+    bv, bt = meshes["ben"]
+    tr = make_tracer(capi, s, "bvh")
+    tr.addGeometry("ground", gv.shape[0], gt.shape[0])
+    tr.addGeometry("face", bv.shape[0], bt.shape[0])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gv, gt)
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 2
+
+    def check(k, scene):
+        rc, pts, hits = tr.traceScene(k)
+        ref = oracle.trace_frame(s, scene)
+        assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+        return len(pts)
+
+    assert check(0, [(0, gv, gt, oracle.IDENTITY_AFFINE), (1, bv, bt, oracle.IDENTITY_AFFINE)]) > 1000
+    # poses only: nothing is built, whatever the matrices (rigid, far away, scaled + sheared, mirrored)
+    mats = [oracle.affine_from_components(np.array(lin, np.float32), np.array(ang, np.float32))
+            for lin, ang in (((2.0, -1.0, 0.2), (0.0, 0.1, 0.8)), ((-25.0, 30.0, 1.0), (0.3, 0.0, -2.0)), ((40.0, 40.0, 5.0), (0.0, 0.0, 3.0)))]
+    mats.append(np.array([1.5, 0.2, 0.0, 1.0, -0.1, 0.7, 0.3, -2.0, 0.0, 0.4, 2.0, 0.5], np.float32))
+    mats.append(np.array([-1.0, 0.0, 0.0, 3.0, 0.0, 1.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.2], np.float32))
+    G = oracle.affine_from_components(np.array((0.5, 0.25, -0.1), np.float32), np.array((0.01, -0.02, 0.3), np.float32))
+    for k, A in enumerate(mats):
+        tr.updateGeometryTransform("face", A)
+        tr.updateGeometryTransform("ground", G if k % 2 else oracle.IDENTITY_AFFINE)
+        assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 1
+        check(k, [(0, gv, gt, G if k % 2 else oracle.IDENTITY_AFFINE), (1, bv, bt, A)])
+    # new vertices for one mesh: that hierarchy is rebuilt
+    gk = gv.copy()
+    gk[:, 2] += np.float32(0.4)
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gk, None)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 2
+    check(20, [(0, gk, gt, oracle.IDENTITY_AFFINE), (1, bv, bt, mats[-1])])
+    # new topology for the other
+    tr.updateGeometry("face", mats[0], bv, bt[::-1].copy())
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 2
+    check(21, [(0, gk, gt, oracle.IDENTITY_AFFINE), (1, bv, bt[::-1].copy(), mats[0])])
+    # a leaf size change rebuilds everything; 3 triangles per leaf leaves short last leaves
+    tr.setOption(capi.LS_OPT_LEAF_SIZE, 4)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 2
+    check(22, [(0, gk, gt, oracle.IDENTITY_AFFINE), (1, bv, bt[::-1].copy(), mats[0])])
+    # a singular matrix (the mesh squashed flat): the classic path, same answer
+    flat = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0], np.float32)
+    tr.updateGeometryTransform("face", flat)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 0
+    check(23, [(0, gk, gt, oracle.IDENTITY_AFFINE), (1, bv, bt[::-1].copy(), flat)])
+    # ... and back
+    tr.updateGeometryTransform("face", mats[1])
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 2
+    check(24, [(0, gk, gt, oracle.IDENTITY_AFFINE), (1, bv, bt[::-1].copy(), mats[1])])
+    tr.removeGeometry("face")                           # (commits by itself, EmbreeTracer.cpp:252: the layout change rebuilt already)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 1
+    check(25, [(0, gk, gt, oracle.IDENTITY_AFFINE)])
+    tr.close()
+    # more geometries than a launch carries: classic
+    tr = make_tracer(capi, s, "bvh")
+    scene = []
+    rng = np.random.default_rng(3)
+    for i in range(18):
+        v, t = synth.grid_mesh(8, 8, half=3.0, seed=i)
+        A = oracle.affine_from_components(rng.uniform(-15, 15, 3).astype(np.float32), rng.uniform(-1, 1, 3).astype(np.float32))
+        tr.addGeometry("m%d" % i, v.shape[0], t.shape[0])
+        tr.updateGeometry("m%d" % i, A, v, t)
+        scene.append((i, v, t, A))
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 0
+    check(30, scene)
+    for i in (17, 16):
+        tr.removeGeometry("m%d" % i)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) in (1, 2)
+    check(31, scene[:16])
     tr.close()

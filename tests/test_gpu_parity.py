@@ -194,6 +194,7 @@ def test_vertex_stride_and_transformed_vertices(oracle, capi, sensors, meshes, e
 def test_leaf_sizes(oracle, capi, sensors, meshes, leaf):
     s = sensors["0000"]
     tr = make_tracer(capi, s, "bvh")
+    tr.setOption(capi.LS_OPT_BVH_INSTANCED, 0)     # the downloaded structure and the visit counts are the classic hierarchy's
     tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
     _add(tr, "ground", meshes["ground"])
     _add(tr, "face", meshes["ben"])
@@ -220,6 +221,7 @@ def test_bvh_structure(oracle, capi, sensors, meshes):
     """Every node's child boxes contain the grandchildren's; the leaves partition the triangles;
     a left-first depth-first walk meets the leaves in Morton order."""
     tr = make_tracer(capi, sensors["0000"], "bvh")
+    tr.setOption(capi.LS_OPT_BVH_INSTANCED, 0)     # the debug download shows the classic sensor-frame hierarchy
     tr.setOption(capi.LS_OPT_LEAF_SIZE, 2)
     _add(tr, "face", meshes["ben"])
     tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
