@@ -362,3 +362,61 @@ def test_bvh_instanced(oracle, capi, sensors, meshes):
     assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) in (1, 2)
     check(31, scene[:16])
     tr.close()
+
+
+def test_bvh_instanced_stress(oracle, capi, sensors):
+    """Instanced hierarchies under hostile poses: soups of mixed triangle sizes whose mesh coordinates sit thousands of
+    metres from their own origin (the matrix brings them back around the sensor), anisotropic scales up to 30 : 1, shears,
+    mirrors, several geometries.  The ray map into mesh space and the widening of the boxes must never lose a hit: every
+    frame equals the projection engine's (which the other tests tie to the oracle), and the first ones the oracle's."""
+    import os
+    from test_gpu_parity import _random_soup, _syn_sensor
+    s0 = _syn_sensor(oracle, sensors, V=24, H=200)
+    s = oracle.Sensor(uid="soup", vertical=s0.vertical, h_begin=s0.h_begin, h_end=s0.h_end, h_count=s0.h_count,
+                      R=np.eye(3, dtype=np.float32).reshape(9), Rinv=np.eye(3, dtype=np.float32).reshape(9), t=np.zeros(3, np.float32))
+    n_cases = int(os.environ.get("LS_STRESS_SEEDS", "24"))
+    bvh, prj = make_tracer(capi, s, "bvh"), make_tracer(capi, s, "projection")
+    names = []
+    instanced = 0
+    for case in range(n_cases):
+        rng = np.random.default_rng(1000 + case)
+        for tr in (bvh, prj):
+            for nm in names:
+                tr.removeGeometry(nm)
+        names = []
+        scene = []
+        for gi in range(int(rng.integers(1, 4))):
+            v, t = _random_soup(rng, int(rng.integers(50, 1500)), float(rng.uniform(2.0, 12.0)))
+            # a well-conditioned but not rigid linear part: rotation * diag(scales) * rotation, sometimes mirrored / sheared
+            q1, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            q2, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            sc = np.exp(rng.uniform(np.log(0.2), np.log(6.0), 3))
+            lin = q1 @ np.diag(sc) @ q2
+            if rng.random() < 0.3:
+                lin = lin @ np.array([[1, rng.uniform(-0.8, 0.8), 0], [0, 1, 0], [0, 0, 1.0]])
+            if rng.random() < 0.3:
+                lin[:, 0] *= -1.0
+            # the mesh as uploaded lives far from its own origin; the matrix puts it back around the sensor
+            centre = rng.uniform(-1.0, 1.0, 3) * float(rng.choice([0.0, 50.0, 4000.0]))
+            mesh = (np.linalg.inv(lin) @ (v.astype(np.float64).T)).T + centre
+            A = np.concatenate([lin, (-lin @ centre)[:, None]], axis=1).astype(np.float32).reshape(12)
+            mv = mesh.astype(np.float32)
+            nm = "g%d" % gi
+            names.append(nm)
+            for tr in (bvh, prj):
+                tr.addGeometry(nm, mv.shape[0], t.shape[0])
+                tr.updateGeometry(nm, A, mv, t)
+            scene.append((gi, mv, t, A))
+        for tr in (bvh, prj):
+            assert tr.commitScene() == 0
+        instanced += 1 if bvh.info(capi.LS_INFO_BVH_INSTANCED) else 0
+        rc1, p1, h1 = bvh.traceScene(case)
+        rc2, p2, h2 = prj.traceScene(case)
+        assert rc1 == 0 and rc2 == 0 and np.array_equal(p1, p2) and np.array_equal(_hits_array(h1), _hits_array(h2)), case
+        if case < 4:
+            ref = oracle.trace_frame(s, scene)
+            assert np.array_equal(p1, ref["points"]) and np.array_equal(_hits_array(h1), ref["hits"])
+            assert len(p1) > 200
+    assert instanced >= n_cases - 2    # (a drawn matrix may exceed the conditioning limit: that scene takes the classic path)
+    bvh.close()
+    prj.close()
