@@ -267,7 +267,8 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_BVH_INSTANCED 12 /* BVH engine: 1 (default) one hierarchy per geometry, built once in MESH space; every frame
                                  *    carries the rays into each geometry's mesh space and tests a leaf's triangles exactly as
                                  *    the other paths do (corners through the frame's transform, same bits) -- a commit after
-                                 *    which only poses differ, the sensor's or a mesh's, builds and refits nothing.  Scenes of
+                                 *    which only poses differ, the sensor's or a mesh's, builds and refits nothing; new vertices refit that geometry
+                                 *    alone (LS_OPT_BVH_REFIT), new indices rebuild it.  Scenes of
                                  *    more than 16 geometries or with a (nearly) singular mesh matrix take the classic path
                                  *    (0: always): one hierarchy in the sensor frame, refitted per LS_OPT_BVH_REFIT.
                                  *    Identical results.  Takes effect at the next commit.                                */

@@ -53,6 +53,8 @@ struct Geometry {
     bool order_stale = true;    // the topology changed since d_perm / d_idx_sorted were made
     bool bounds_stale = true;   // vertices (may have) changed since d_boxes were made
     bool blas_dirty = true;     // BVH engine, instanced mode: vertices or topology changed since this geometry's hierarchy was built
+    bool blas_topo_dirty = true;   // ... the topology did (vertices alone: the sorted order stays, the hierarchy is refitted)
+    uint64_t blas_sorted_epoch = 0;   // key_scratch_epoch at which this geometry's sorted keys were written (0: never)
     float mesh_maxabs = 0.0f;   // largest |coordinate| of the mesh as uploaded (read back when that hierarchy is built)
     const void *raw() const { return shared_raw ? shared_raw : d_raw; }
     const uint32_t *idx() const { return shared_idx ? shared_idx : d_idx; }
@@ -287,6 +289,7 @@ struct ls_tracer {
     int opt_bvh_instanced = 1;   // LS_OPT_BVH_INSTANCED: per-geometry hierarchies in mesh space, no build / refit for pose changes
     bool bvh_inst = false;       // the committed BVH is the instanced one
     bool inst_valid = false;     // records / nodes / inst_layout hold instanced hierarchies for the current layout and leaf size
+    uint64_t key_scratch_epoch = 1;   // bumped whenever keys_b / vals_b are overwritten by something other than a geometry's own slice
     bool last_commit_built = false;
     struct InstSlot { uint32_t node_first, rec_first, n_leaves, range_first; ls::RangeTree rt; };
     std::vector<InstSlot> inst_layout;   // per layout entry
@@ -805,8 +808,8 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
             ls::launch_quads_to_triangles(tr->stream, idx, g.n_elems, g.d_idx);
             g.shared_idx = nullptr;
             if (!g.has_idx) tr->layout_dirty = true;
-            g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = true;
-        } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = true; }
+            g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true;
+        } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true; }
         return LS_OK;
     }
     if (!verts && !idx) return LS_OK;   // transform only: nothing is copied, nothing to order
@@ -844,7 +847,7 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
     if (idx) {
         g.shared_idx = nullptr;
         g.order_stale = true;
-        g.blas_dirty = true;
+        g.blas_dirty = g.blas_topo_dirty = true;
         const size_t bytes = g.quad ? (size_t)g.n_elems * 16 : (size_t)g.n_tris * 12;
         if (!g.d_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx), (size_t)g.n_tris * 12 + 4));
         if (g.quad && !g.d_quad_idx) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_quad_idx), bytes ? bytes : 4));
@@ -940,6 +943,7 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
         if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
         if (!tr->d_aabb6) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_aabb6), 32));
         tr->bvh_order_valid = false;   // keys_a / keys_b / vals_a are the scratch of this pass
+        ++tr->key_scratch_epoch;
         ls::launch_mesh_order(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.n_verts, g.idx(), nt, tr->d_aabb6,
                               tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->sort_temp.p, tr->sort_temp.cap, g.d_perm, g.d_idx_sorted);
         g.order_stale = false;
@@ -1043,7 +1047,8 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
         for (const Geometry *ge : order) biggest = std::max(biggest, ge->n_tris);
         if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(biggest)))) return rc;
         if (!tr->d_inst_maxabs) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_inst_maxabs), ls::kGeomsPerLaunch * 4));
-        tr->bvh_order_valid = false;   // the key arrays are the scratch of these builds
+        tr->bvh_order_valid = false;   // the key arrays hold per-geometry slices now
+        if (fresh) ++tr->key_scratch_epoch;   // the slices moved
         hipStream_t s = tr->stream;
         static const float kIdA[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, kIdR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kZero[3] = {0, 0, 0};
         LS_HIP(hipMemsetAsync(tr->d_inst_maxabs, 0, ls::kGeomsPerLaunch * 4, s));
@@ -1058,8 +1063,14 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             // identity transform: the packed copy holds the vertices as uploaded (1 * x + 0 * y + 0 * z + 0 is x)
             ls::launch_transform(s, ge.raw(), ge.stride, ge.n_verts, kIdA, kIdR, kZero, verts, tr->d_inst_maxabs + i);
             ls::launch_rebase(s, ge.idx(), ge.n_tris * 3, 0u, tris);
-            ls::launch_morton(s, verts, tris, ge.n_tris, tr->d_inst_maxabs + i, ka, va);
-            ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, ka, kb, va, vb, ge.n_tris);
+            // vertices alone changed and the geometry's sorted keys are still in place: a refit (same order, same
+            // topology, every box recomputed) -- what the classic path does with LS_OPT_BVH_REFIT
+            const bool refit = tr->opt_bvh_refit && !ge.blas_topo_dirty && ge.blas_sorted_epoch == tr->key_scratch_epoch;
+            if (!refit) {
+                ls::launch_morton(s, verts, tris, ge.n_tris, tr->d_inst_maxabs + i, ka, va);
+                ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, ka, kb, va, vb, ge.n_tris);
+                ge.blas_sorted_epoch = tr->key_scratch_epoch;
+            }
             float4 *rb = tr->range_boxes.p + sl.range_first;
             ls::launch_leaves(s, verts, tris, vb, ge.n_tris, g, tr->records.p + sl.rec_first, rb, true);
             ls::launch_range_tree(s, sl.rt, rb);
@@ -1074,7 +1085,7 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             Geometry &ge = *order[i];
             if (!fresh && !ge.blas_dirty) continue;
             std::memcpy(&ge.mesh_maxabs, &bits[i], 4);
-            ge.blas_dirty = false;
+            ge.blas_dirty = ge.blas_topo_dirty = false;
         }
     }
     tr->inst_valid = true;
@@ -1166,6 +1177,7 @@ int commit_locked(ls_tracer *tr)
         // node by range query).  Always a valid BVH; the sort and the key pass (half of the build) are not run.
         tr->bvh_inst = false;
         tr->inst_valid = false;        // the shared record / node arrays are about to hold the sensor-frame hierarchy
+        ++tr->key_scratch_epoch;
         tr->last_commit_built = true;
         bool any_idx_dirty = false;
         for (const Geometry *ge : order) any_idx_dirty = any_idx_dirty || ge->idx_dirty;
@@ -1195,7 +1207,7 @@ int commit_locked(ls_tracer *tr)
         mark(tr, 6);
         LS_HIP(hipGetLastError());
         tr->bvh_built = true;
-        for (Geometry *ge : order) ge->blas_dirty = true;   // whatever instanced hierarchies there were are overwritten
+        for (Geometry *ge : order) ge->blas_dirty = ge->blas_topo_dirty = true;   // whatever instanced hierarchies there were are overwritten
     } else {
         // projection engine: no hierarchy to build -- the trace kernel streams the meshes as uploaded and applies
         // the vertex transform on the fly.  Big meshes keep a Morton order (per topology) and per-block bounds
