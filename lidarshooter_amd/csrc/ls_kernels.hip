@@ -373,7 +373,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
                     const uint32_t sidx = base + rank;
                     if (!has && sidx < len) {
                         const uint32_t j = sidx / width, c = sidx - j * width;
-                        const uint32_t v = (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        // (j and chan_mul are below V: the product fits 32 bits for every real sensor; the 64-bit remainder is ~100 instructions)
+                        const uint32_t v = tb.V < 65536u ? (j * rq.chan_mul) % tb.V : (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
                         const uint32_t hl = first + c, h = tb.az0 + hl;
                         // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
                         const float st = tb.sin_theta[v];
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
                     const uint32_t sidx = base + rank;
                     if (!has && sidx < len) {
                         const uint32_t j = sidx / width, c = sidx - j * width;
-                        const uint32_t v = (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        // (j and chan_mul are below V: the product fits 32 bits for every real sensor; the 64-bit remainder is ~100 instructions)
+                        const uint32_t v = tb.V < 65536u ? (j * rq.chan_mul) % tb.V : (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
                         const uint32_t hl = first + c, h = tb.az0 + hl;
                         // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
                         const float st = tb.sin_theta[v];
