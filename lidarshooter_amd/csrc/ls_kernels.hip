@@ -303,8 +303,8 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict
 // ------------------------------------------------------------------------------------------
 // Fused ray generation + closest-hit traversal, persistent waves with ray refill.
 //
-// The grid is exactly the resident capacity of the chip (5 blocks of 256 per CU: the 32 KB of LDS
-// stack per block is the limiter).  The shard's rays sit in kQueues queues, one per XCD: queue x =
+// The grid is a fixed number of resident blocks per CU (trace_grid_blocks: 2 of the 5 that the 32 KB of LDS
+// stack per block would admit).  The shard's rays sit in kQueues queues, one per XCD: queue x =
 // azimuth sector x, enumerated channel by channel, so that the 64 rays a wave takes together are 64
 // consecutive azimuth columns of one channel (coherent: their node fetches share cache lines) and
 // an XCD's L2 keeps seeing its own sector of the BVH.  A wave reads its XCD id from HW_REG_XCC_ID
@@ -374,7 +374,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
                     if (!has && sidx < len) {
                         const uint32_t j = sidx / width, c = sidx - j * width;
                         // (j and chan_mul are below V: the product fits 32 bits for every real sensor; the 64-bit remainder is ~100 instructions)
-                        const uint32_t v = tb.V < 65536u ? (j * rq.chan_mul) % tb.V : (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        const uint32_t jj = tb.V < 65536u ? (j * rq.chan_mul) % tb.V : (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        const uint32_t v = rq.chan_order ? rq.chan_order[tb.V - 1u - jj] : jj;   // from the highest ring down
                         const uint32_t hl = first + c, h = tb.az0 + hl;
                         // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
                         const float st = tb.sin_theta[v];
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
 // construction), and at a leaf the exact test of every other path: the three corners through this frame's transform
 // (xform_vertex: the bits of k_transform / k_project), e1, e2, NgC, Embree's test against the table direction.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool SINGLE /* one geometry (the usual scene): its descriptor is wave-uniform, scalar registers */>
 __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueues rq, InstBatch batch, const FatNode *__restrict__ nodes,
                                                        const TriRecord *__restrict__ records, uint32_t g, float *__restrict__ t_out,
                                                        uint32_t *__restrict__ gid_out, uint32_t *__restrict__ spill,
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
     auto advance = [&]() {
         cur = kInvalid;
         if (sp) { --sp; cur = sp < (uint32_t)kStackLds ? s_stack[sp][tid] : my_spill[sp - kStackLds]; return; }
-        while (cur == kInvalid && ++gi < batch.n) enter(gi);
+        if (!SINGLE)
+            while (cur == kInvalid && ++gi < batch.n) enter(gi);
     };
 
     while (true) {
@@ -525,7 +527,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
                     if (!has && sidx < len) {
                         const uint32_t j = sidx / width, c = sidx - j * width;
                         // (j and chan_mul are below V: the product fits 32 bits for every real sensor; the 64-bit remainder is ~100 instructions)
-                        const uint32_t v = tb.V < 65536u ? (j * rq.chan_mul) % tb.V : (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        const uint32_t jj = tb.V < 65536u ? (j * rq.chan_mul) % tb.V : (uint32_t)(((unsigned long long)j * rq.chan_mul) % tb.V);
+                        const uint32_t v = rq.chan_order ? rq.chan_order[tb.V - 1u - jj] : jj;   // from the highest ring down
                         const uint32_t hl = first + c, h = tb.az0 + hl;
                         // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
                         const float st = tb.sin_theta[v];
@@ -534,7 +537,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
                         best = INFINITY; bid = kInvalid; sp = 0; has = true;
                         gi = 0;
                         enter(0);
-                        while (cur == kInvalid && ++gi < batch.n) enter(gi);
+                        if (!SINGLE)
+                            while (cur == kInvalid && ++gi < batch.n) enter(gi);
                     }
                     break;
                 }
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
             // (a leaf reached above belongs to `ig`; after advance() moved on to another geometry the loop ends and the
             // next trip continues there)
             const uint32_t at_entry = gi;
-            while (cur != kInvalid && (cur & kLeafBit) && gi == at_entry) {
+            while (cur != kInvalid && (cur & kLeafBit) && (SINGLE || gi == at_entry)) {
                 const uint32_t first = (cur & ~kLeafBit) * g;
                 const uint32_t last = min(first + g, ig.n_tris);
                 for (uint32_t s = first; s < last; ++s) {
@@ -611,8 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
             }
         };
         if (has) {
-            // one geometry (the usual scene): its descriptor is wave-uniform and lives in scalar registers
-            if (batch.n == 1u) step(batch.g[0]);
+            if (SINGLE) step(batch.g[0]);
             else step(batch.g[gi]);
             if (cur == kInvalid) {
                 t_out[q] = (bid == kInvalid) ? -1.0f : best;
@@ -957,14 +960,15 @@ void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleav
 
 uint32_t trace_grid_blocks(int device)
 {
-    // Persistent grid = resident capacity: 160 KB of LDS per CU / 32 KB of stack per block = 5 blocks
-    // (20 waves) per CU.  Over-subscription would be harmless (late blocks find the queues empty), so
-    // the figure is not taken from the occupancy API, which answers for a 64 KB LDS on this stack.
+    // Persistent grid: 2 blocks (8 waves) per CU.  The LDS stacks would admit 5, but the traversal is bound by what a trip
+    // costs a wave in issue and dependency latency, not by residency, and fewer waves leave more
+    // L1 per wave: with whole-wave refills and sequential channels, k_trace_inst takes 0.142 ms with 2, 0.148 with 3,
+    // 0.180 with 4, 0.20 with 1 (headline frame).  LS_TRACE_BLOCKS_PER_CU overrides.
     hipDeviceProp_t prop;
     uint32_t cus = 256u;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         cus = (uint32_t)prop.multiProcessorCount;
-    uint32_t per_cu = 5u;
+    uint32_t per_cu = 2u;
     if (const char *e = getenv("LS_TRACE_BLOCKS_PER_CU")) per_cu = (uint32_t)max(1, atoi(e));
     return cus * per_cu;
 }
@@ -997,12 +1001,11 @@ void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTab
     const uint32_t nq = tb.V * tb.naz;
     if (!nq || !batch.n) return;
     const uint32_t grid = min(grid_blocks, (nq + kBlock - 1) / kBlock);
-    if (visit_counts)
-        hipLaunchKernelGGL(k_trace_inst<true>, dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, records, leaf_size, t_out, gid_out,
-                           spill, visit_counts);
-    else
-        hipLaunchKernelGGL(k_trace_inst<false>, dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, records, leaf_size, t_out, gid_out,
-                           spill, visit_counts);
+#define LS_TRACE_INST(C, S) hipLaunchKernelGGL((k_trace_inst<C, S>), dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, records, leaf_size, \
+                                                t_out, gid_out, spill, visit_counts)
+    if (visit_counts) { if (batch.n == 1u) LS_TRACE_INST(true, true); else LS_TRACE_INST(true, false); }
+    else { if (batch.n == 1u) LS_TRACE_INST(false, true); else LS_TRACE_INST(false, false); }
+#undef LS_TRACE_INST
 }
 
 void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t n_quads, uint32_t *tri_idx)

@@ -236,7 +236,7 @@ struct ls_tracer {
     bool bvh_built = false;
     DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
     uint32_t *d_queue_heads = nullptr;
-    uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 24;
+    uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 56;
     // LS_OPT_PIPELINE: the finish + pack workgroups of frame i ride in the launch of frame i+1's k_project;
     // everything a frame in flight touches exists twice (parity), the queue counter three times
     int opt_pipeline = 0;
@@ -1427,6 +1427,8 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         rq.heads = tr->d_queue_heads;
         rq.chan_mul = tr->chan_mul;
         rq.refill_min = tr->refill_min;
+        rq.chan_order = reinterpret_cast<const uint32_t *>(tr->d_tables + 4 * (size_t)tr->V + 2 * (size_t)tr->H);   // chan_perm (fill_tables)
+        { static const bool no_order = getenv("LS_TRACE_NO_ORDER") != nullptr; if (no_order) rq.chan_order = nullptr; }
         mark(tr, 7);
         if (tr->bvh_inst) {
             // this frame's poses: every geometry's ray map (inverse of mesh -> sensor) and exact transform
@@ -1553,13 +1555,16 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
     if (tr->V > 32767u) tr->projection_ok = false;  // channel range is packed into 16+15 bits
     tr->trace_blocks = ls::trace_grid_blocks(hip_device);
     {
-        // channel visiting order (j * chan_mul) % V: a stride near 0.38 V that is coprime with V, so
-        // that cheap (sky) and expensive (grazing) channels alternate in every ray queue
+        // Ray order of the persistent trace grid.  Round 1 visited the channels at a stride near 0.38 V (cheap sky channels
+        // and expensive grazing ones alternate in every queue) and refilled 24 idle lanes at a time.  Measured again in
+        // round 2 (bench.py --engine bvh, k_trace_inst and k_trace alike): rings one after the other, from the highest
+        // elevation down (position (j * chan_mul) % V of the elevation order with chan_mul = 1: a wave's next 64 rays
+        // pass the nodes its last 64 did), whole-wave refills (idle lanes wait until 56 of 64 are idle) and 2 resident
+        // blocks per CU: 0.150 ms against 0.186.  The other direction, lowest ring first, takes 0.194 ms; tiles of
+        // 4 x 16 or 8 x 8 rays instead of 64 x 1 take 0.156 / 0.159.
         auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
-        uint32_t m = std::max<uint32_t>(1u, (uint32_t)(tr->V * 0.382f)) | 1u;
-        while (m > 1u && gcd(m, tr->V) != 1u) m += 2u;
-        tr->chan_mul = (tr->V > 1u) ? m % tr->V : 1u;
-        if (tr->chan_mul == 0u || gcd(tr->chan_mul, tr->V) != 1u) tr->chan_mul = 1u;
+        tr->chan_mul = 1u;
+        tr->refill_min = 56u;
         if (const char *e = getenv("LS_TRACE_CHAN_MUL")) { const uint32_t v = (uint32_t)atoi(e); if (v && gcd(v, tr->V) == 1u) tr->chan_mul = v; }
         if (const char *e = getenv("LS_TRACE_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) tr->refill_min = (uint32_t)v; }
     }
