@@ -9,6 +9,8 @@ namespace ls {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 constexpr uint32_t kLeafBit = 0x80000000u;  // child reference: bit 31 set = leaf index, else node index
+constexpr uint32_t kTreeletBit = 0x40000000u;   // instanced trace, one geometry: node index inside the LDS-staged top of the hierarchy
+constexpr uint32_t kTreeletNodes = 511;         // 32 KB of 64-byte nodes (nine levels of a balanced tree), next to the 32 KB of stacks
 constexpr int kMaxRangeLevels = 32;
 constexpr int kMaxGeoms = 1024;
 constexpr int kQueues = 8;           // one ray queue per XCD
@@ -178,9 +180,13 @@ struct InstBatch {
     uint32_t n;
     InstGeom g[kGeomsPerLaunch];
 };
+// treelet (nullable; used when the scene is one geometry): kTreeletNodes nodes, the top of that geometry's hierarchy in
+// breadth-first order with the references among them rewritten to kTreeletBit | slot (launch_treelet); every block of
+// the trace grid stages it in LDS once and walks the first levels of every ray there
+void launch_treelet(hipStream_t s, const FatNode *nodes, uint32_t n_leaves, FatNode *treelet);
 void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq, const InstBatch &batch,
-                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, float *t_out, uint32_t *gid_out,
-                            uint32_t *spill, unsigned long long *visit_counts /* nullptr = do not count */);
+                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
+                            uint32_t *gid_out, uint32_t *spill, unsigned long long *visit_counts /* nullptr = do not count */);
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts);
 // compact != 0: points are written as 16-byte records (x, y, z, ring) instead of the 32-byte PointCloud2 layout
 void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,

@@ -455,6 +455,40 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
     }
 }
 
+// Top of a hierarchy in breadth-first order, for the LDS of k_trace_inst: slot 0 = the root; a node's child that is an
+// internal node gets the next free slot while there are any (its reference becomes kTreeletBit | slot), leaves and
+// the nodes below the last slot keep their references.  One workgroup; a level at a time.
+__global__ __launch_bounds__(kBlock) void k_treelet(const FatNode *__restrict__ nodes, FatNode *__restrict__ out)
+{
+    __shared__ uint32_t s_q[kTreeletNodes];
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) { s_q[0] = 0u; s_n = 1u; }
+    __syncthreads();
+    uint32_t done = 0;
+    while (true) {
+        const uint32_t end = min(s_n, kTreeletNodes);
+        __syncthreads();
+        if (done >= end) break;
+        for (uint32_t slot = done + threadIdx.x; slot < end; slot += kBlock) {
+            const float4 *nd = nodes[s_q[slot]].q;
+            float4 A = nd[0], B = nd[1];
+            const float4 C = nd[2], D = nd[3];
+            uint32_t ref[2] = {__float_as_uint(A.w), __float_as_uint(B.w)};
+            for (int c = 0; c < 2; ++c) {
+                if (ref[c] & kLeafBit) continue;
+                const uint32_t idx = atomicAdd(&s_n, 1u);
+                if (idx < kTreeletNodes) { s_q[idx] = ref[c]; ref[c] = kTreeletBit | idx; }
+            }
+            A.w = __uint_as_float(ref[0]);
+            B.w = __uint_as_float(ref[1]);
+            float4 *o = out[slot].q;
+            o[0] = A; o[1] = B; o[2] = C; o[3] = D;
+        }
+        __syncthreads();
+        done = end;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Instanced mode: the same persistent waves and ray refill as k_trace, over one hierarchy PER GEOMETRY built once in
 // mesh space (InstBatch, ls_kernels.h).  A lane walks the geometries one after the other: ray origin o and direction
@@ -466,12 +500,22 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
 // ------------------------------------------------------------------------------------------
 template <bool COUNT, bool SINGLE /* one geometry (the usual scene): its descriptor is wave-uniform, scalar registers */>
 __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueues rq, InstBatch batch, const FatNode *__restrict__ nodes,
-                                                       const TriRecord *__restrict__ records, uint32_t g, float *__restrict__ t_out,
+                                                       const TriRecord *__restrict__ records, uint32_t g,
+                                                       const FatNode *__restrict__ treelet, float *__restrict__ t_out,
                                                        uint32_t *__restrict__ gid_out, uint32_t *__restrict__ spill,
                                                        unsigned long long *__restrict__ visit_counts)
 {
     __shared__ uint32_t s_stack[kStackLds][kBlock];
+    // one geometry: the top of its hierarchy (launch_treelet: breadth-first, kTreeletNodes nodes) sits in LDS; the first
+    // levels of every ray -- the fetches every lane of every wave makes -- are LDS reads instead of cache round trips
+    __shared__ float4 s_tree[SINGLE ? 4 * kTreeletNodes : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const bool use_tree = SINGLE && treelet != nullptr && batch.g[0].n_leaves > 1u;
+    if (SINGLE && use_tree) {
+        const float4 *src = reinterpret_cast<const float4 *>(treelet);
+        for (uint32_t i = tid; i < 4u * kTreeletNodes; i += kBlock) s_tree[i] = src[i];
+        __syncthreads();
+    }
     uint32_t *my_spill = spill + ((size_t)blockIdx.x * kBlock + tid) * kStackSpill;
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -499,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
         cxl = -(ig.o[0] + ig.eps) * ix; cxh = -(ig.o[0] - ig.eps) * ix;
         cyl = -(ig.o[1] + ig.eps) * iy; cyh = -(ig.o[1] - ig.eps) * iy;
         czl = -(ig.o[2] + ig.eps) * iz; czh = -(ig.o[2] - ig.eps) * iz;
-        cur = ig.n_leaves > 1u ? 0u : kLeafBit;
+        cur = ig.n_leaves > 1u ? (use_tree ? kTreeletBit : 0u) : kLeafBit;
     };
     // next thing to do for a lane whose current subtree is finished: the stack, else the next geometry, else done
     auto advance = [&]() {
@@ -553,8 +597,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
         // one traversal step of this lane in geometry `ig`: a node (both child boxes), then the leaves it leads to
         auto step = [&](const InstGeom &ig) {
             if (cur != kInvalid && !(cur & kLeafBit)) {
-                const float4 *nd = nodes[ig.node_first + cur].q;
-                const float4 A = nd[0], B = nd[1], C = nd[2], D = nd[3];
+                float4 A, B, C, D;
+                if (SINGLE && (cur & kTreeletBit)) {
+                    const float4 *nd = s_tree + 4u * (cur & (kTreeletBit - 1u));
+                    A = nd[0]; B = nd[1]; C = nd[2]; D = nd[3];
+                } else {
+                    const float4 *nd = nodes[ig.node_first + cur].q;
+                    A = nd[0]; B = nd[1]; C = nd[2]; D = nd[3];
+                }
                 if (COUNT) ++cn;
                 float x1 = fmaf(A.x, ix, cxl), x2 = fmaf(B.x, ix, cxh), y1 = fmaf(A.y, iy, cyl), y2 = fmaf(B.y, iy, cyh),
                       z1 = fmaf(A.z, iz, czl), z2 = fmaf(B.z, iz, czh);
@@ -994,15 +1044,21 @@ void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, c
                            leaf_size, ntris, t_out, gid_out, spill, visit_counts);
 }
 
+void launch_treelet(hipStream_t s, const FatNode *nodes, uint32_t n_leaves, FatNode *treelet)
+{
+    if (n_leaves < 2u) return;
+    hipLaunchKernelGGL(k_treelet, dim3(1), dim3(kBlock), 0, s, nodes, treelet);
+}
+
 void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq, const InstBatch &batch,
-                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, float *t_out, uint32_t *gid_out,
-                            uint32_t *spill, unsigned long long *visit_counts)
+                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
+                            uint32_t *gid_out, uint32_t *spill, unsigned long long *visit_counts)
 {
     const uint32_t nq = tb.V * tb.naz;
     if (!nq || !batch.n) return;
     const uint32_t grid = min(grid_blocks, (nq + kBlock - 1) / kBlock);
 #define LS_TRACE_INST(C, S) hipLaunchKernelGGL((k_trace_inst<C, S>), dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, records, leaf_size, \
-                                                t_out, gid_out, spill, visit_counts)
+                                                treelet, t_out, gid_out, spill, visit_counts)
     if (visit_counts) { if (batch.n == 1u) LS_TRACE_INST(true, true); else LS_TRACE_INST(true, false); }
     else { if (batch.n == 1u) LS_TRACE_INST(false, true); else LS_TRACE_INST(false, false); }
 #undef LS_TRACE_INST

@@ -297,6 +297,8 @@ struct ls_tracer {
     DevBuf<float> inst_verts;    // packed mesh-space vertices of all geometries (build input)
     DevBuf<uint32_t> inst_tris;  // their indices, rebased
     uint32_t *d_inst_maxabs = nullptr;   // kGeomsPerLaunch words
+    DevBuf<ls::FatNode> treelet; // one-geometry scenes: the top of that hierarchy, breadth-first (k_trace_inst stages it in LDS)
+    bool treelet_valid = false;
     bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
     uint32_t bvh_order_tris = 0;
     bool last_commit_refit = false;
@@ -1076,6 +1078,15 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             ls::launch_range_tree(s, sl.rt, rb);
             ls::launch_hierarchy(s, kb, sl.n_leaves, g, sl.rt, rb, tr->nodes.p + sl.node_first);
         }
+        // a scene of one geometry: the top of its hierarchy for the trace grid's LDS (static with the hierarchy)
+        tr->treelet_valid = false;
+        static const bool no_treelet = getenv("LS_TRACE_NO_TREELET") != nullptr;
+        if (order.size() == 1 && tr->inst_layout[0].n_leaves > 1u && !no_treelet) {
+            if ((rc = ensure(tr, tr->treelet, (size_t)ls::kTreeletNodes))) return rc;
+            LS_HIP(hipMemsetAsync(tr->treelet.p, 0, (size_t)ls::kTreeletNodes * sizeof(ls::FatNode), s));
+            ls::launch_treelet(s, tr->nodes.p + tr->inst_layout[0].node_first, tr->inst_layout[0].n_leaves, tr->treelet.p);
+            tr->treelet_valid = true;
+        }
         LS_HIP(hipGetLastError());
         // the extent of every rebuilt mesh (the widening of its boxes at trace time is scaled by it)
         uint32_t bits[ls::kGeomsPerLaunch];
@@ -1461,7 +1472,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                 std::memcpy(ig.m.t, tr->t, sizeof(ig.m.t));
             }
             ls::launch_trace_instanced(s, tr->trace_blocks, tb, rq, batch, tr->nodes.p, tr->records.p, tr->inst_leaf_size,
-                                       tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
+                                       (batch.n == 1u && tr->treelet_valid) ? tr->treelet.p : nullptr, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
         } else {
             ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,
                              tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
@@ -1639,7 +1650,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     }
     release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
     release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
-    release(tr->inst_verts); release(tr->inst_tris);
+    release(tr->inst_verts); release(tr->inst_tris); release(tr->treelet);
     if (tr->d_inst_maxabs) (void)hipFree(tr->d_inst_maxabs);
     release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
     release(tr->row_counts); release(tr->points); release(tr->hits);
