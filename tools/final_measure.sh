@@ -22,6 +22,7 @@ bash tools_profile.sh ${TAG} > gpurun_out/final/profile.log 2>&1
 python tools/prof_summary.py gpurun_out/prof_${TAG} gpurun_out/final/${TAG}_projection > gpurun_out/final/prof_summary.log 2>&1
 cp gpurun_out/prof_${TAG}/bench_stats.json gpurun_out/final/${TAG}_projection_bench_under_rocprof.json   # prof_summary also wrote ${TAG}_projection_kernel_isolated.json (dispatches that ran alone vs overlapped)
 BENCH_ARGS="--engine bvh --no-dropin" bash tools_pmc.sh ${TAG}_bvh "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/final/pmc_bvh.log 2>&1
+bash tools/bvh_stats.sh ${TAG} > gpurun_out/final/bvh_stats.log 2>&1
 python tools/pmc_to_hbm.py gpurun_out/pmc_${TAG}_bvh/summary.txt gpurun_out/final/${TAG}_bvh_hbm.json "bench.py --engine bvh (instanced hierarchies: nothing built per frame)" >> gpurun_out/final/pmc_bvh.log 2>&1
 # the two headline lines last: they read `roofline.traffic` from the profiles just taken (same kernel sources, same box)
 cp gpurun_out/final/${TAG}_projection_hbm.json gpurun_out/final/${TAG}_bvh_hbm.json profiles/
