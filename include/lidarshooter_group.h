@@ -49,7 +49,9 @@ uint32_t ls_group_decode_gathered(const void *gathered, uint32_t world, uint32_t
 /* rank 0 makes the id (ncclGetUniqueId) and ships it to the other ranks by any means (file, pipe, MPI, environment) */
 int ls_group_unique_id(uint8_t id[LS_GROUP_ID_BYTES]);
 /* Collective over all ranks.  `tr` is this rank's tracer (created on its own GPU, geometries may be added before or
- * after); the group puts it on a stream of its own, sets its shard (SHARDED) and owns its output buffers from now on. */
+ * after); the group puts it on a stream of its own, sets its shard (SHARDED) and owns its output buffers from now on.
+ * On failure the tracer is left, or put back, as ls_group_destroy leaves it: on its own stream, on the full turn, on
+ * its own output buffers -- usable as a single-GPU tracer (the fallback when RCCL is missing: LS_ERR_NO_DEVICE). */
 int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, ls_tracer *tr, ls_group **out);
 void ls_group_destroy(ls_group *g);
 /* One frame, after the caller's updateGeometry / commitScene on the tracer: nothing in it waits for the device.

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LS_ABI_VERSION 2
+#define LS_ABI_VERSION 3
 
 typedef struct ls_tracer ls_tracer;
 
@@ -129,8 +129,8 @@ int ls_remove_geometry(ls_tracer *tr, const char *name);
  * MeshTransformer.cpp:512-518; 4*n_elements for a quad geometry, :521-552); NULL keeps the indices of the previous update.  Host pointers; the
  * caller may reuse them as soon as the call returns (MeshProjector.cpp:448-461 does).  By default the copy
  * goes straight from the caller's pageable memory at PCIe rate and the call returns when the memory has been
- * read; with LS_UPLOAD_MODE=0 in the environment the library's worker threads stage it through pinned memory
- * instead and the call never waits for the device. */
+ * read; with LS_OPT_UPLOAD_MODE = 0 the library's worker threads stage it through pinned memory instead and the
+ * call never waits for the device. */
 int ls_update_geometry(ls_tracer *tr, const char *name, const float affine3x4[12], const void *verts,
                        uint32_t vert_stride, const uint32_t *tri_idx);
 
@@ -182,10 +182,15 @@ int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
 /* ---- ITracer::getGeometryCount (ITracer.hpp:101) */
 long ls_geometry_count(ls_tracer *tr);
 
-/* Per-name getters of EmbreeTracer (EmbreeTracer.cpp:369-439); negative status if unknown. */
+/* Per-name getters of EmbreeTracer (EmbreeTracer.cpp:82-113, :369-439); LS_ERR_UNKNOWN_GEOMETRY if the name is not
+ * registered (the reference returns -1 from getGeometryId and throws TraceException codes 1 / 4 / 8 from
+ * getVertexCount / getElementCount / getGeometryType: the adapter maps the status to exactly those). */
 int ls_geometry_id(ls_tracer *tr, const char *name);
 long ls_vertex_count(ls_tracer *tr, const char *name);
 long ls_element_count(ls_tracer *tr, const char *name);
+/* EmbreeTracer::getGeometryType (EmbreeTracer.cpp:103-113; test/EmbreeTracer_test.cpp:116-120): the LS_GEOMETRY_TYPE_*
+ * the geometry was added with (= the RTCGeometryType value). */
+int ls_geometry_type(ls_tracer *tr, const char *name);
 
 /* LidarDevice::getTotalRays / getTotalChannels (LidarDevice.cpp:411-419) for this handle. */
 uint32_t ls_total_rays(ls_tracer *tr);
@@ -277,6 +282,10 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
                                  *    of the raster and no column of the shard can meet.  0 off, 1 on, 2 (default) auto: on for
                                  *    geometries of 2 000 000 triangles or more (where the kernel is bandwidth-bound).
                                  *    Identical results.                                                                  */
+#define LS_OPT_UPLOAD_MODE 13   /* ls_update_geometry from host memory: 1 (default) one copy straight from the caller's pageable
+                                 *    memory at PCIe rate, the call returns when the memory has been read; 0: worker threads
+                                 *    stage it through pinned memory chunk by chunk, the call never waits for the device
+                                 *    (measured slower: 0.26-0.31 ms against 0.15 ms for 8 MB); 2: one thread, one copy.  */
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */
@@ -327,27 +336,15 @@ int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[4]);
  * memory owned by the caller: dir_x, dir_y, dir_z (origins are all zero, LidarDevice.cpp:320). */
 int ls_generate_rays(ls_tracer *tr, float *d_dir_x, float *d_dir_y, float *d_dir_z);
 
-/* ---- test / measurement hooks (used by tests/ and bench.py only) ---------------------------- */
-
-/* Dense per-ray results of the last trace, host buffers of n_rays entries (shard-local order
- * q = v*n_az + (h-first_az)): t (< 0 = miss) and global triangle id (0xFFFFFFFF = miss). */
-int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid);
-
-/* Exhaustive closest hit on the device (every ray against every triangle, same triangle test):
- * the full-size checker for the BVH path. */
-int ls_debug_trace_bruteforce(ls_tracer *tr, float *t, uint32_t *gid);
-
-/* Transformed (sensor-frame) vertices and rebased indices of the committed scene. */
-int ls_debug_scene_size(ls_tracer *tr, uint32_t *n_verts, uint32_t *n_tris, uint32_t *n_node_slots,
-                        uint32_t *leaf_size);
-int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx);
-
-/* BVH arrays: n_node_slots BVH2 nodes (64 B each) and n_tris triangle records (48 B each):
- *   node i: float4 q[4] = (L.lo.xyz, bits(left ref)), (L.hi.xyz, bits(right ref)), (R.lo.xyz, 0), (R.hi.xyz, 0)
- *     child ref: bit 31 set = leaf k (records [k*leaf_size, k*leaf_size+leaf_size) clipped to n_tris),
- *     else index of another node; node 0 is the root (a one-leaf scene has no node at all)
- *   triangle record: float v0[3]; uint32 gid; float e1[3]; float NgC; float e2[3]; uint32 pad */
-int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records);
+/* The same kernel's two outputs in the reference's own layout (LidarDeviceKernels.cu:38-51): n = ls_total_rays() records
+ * each, in ray-index order, device memory owned by the caller.
+ *   d_rays:  lidarshooter::Ray, 32 bytes (Ray.hpp:16-35): origin xyz f32@0 (0, 0, 0), tmin f32@12, direction xyz f32@16,
+ *            tmax f32@28.  The reference's kernel leaves tmin / tmax as it found them; here they are written as its
+ *            OptiX programs use them: tmin 0, tmax 1e16 (OptixTracerModules.cu:45-46).
+ *   d_hits:  lidarshooter::Hit, 24 bytes (Hit.hpp:16-29): t f32@0 = 1e16 ("no hit yet"), normal xyz f32@4 (left alone by
+ *            the reference; written as 0 here), intensity f32@16 = 64.0, ring i32@20 = the channel index.
+ * Either pointer may be NULL (that output is skipped). */
+int ls_generate_rays_aos(ls_tracer *tr, void *d_rays, void *d_hits);
 
 #ifdef __cplusplus
 }

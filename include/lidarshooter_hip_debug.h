@@ -1,0 +1,38 @@
+/*
+ * lidarshooter_hip_debug.h -- test and measurement hooks of liblidarshooter_hip.so: views into a tracer handle that
+ * tests/ and bench.py use to compare the device's results with the CPU oracle.  Not part of the drop-in surface of
+ * include/lidarshooter_hip.h (no ITracer virtual maps to any of these) and not needed by the adapter.
+ */
+#ifndef LIDARSHOOTER_HIP_DEBUG_H
+#define LIDARSHOOTER_HIP_DEBUG_H
+
+#include "lidarshooter_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Dense per-ray results of the last trace, host buffers of n_rays entries (shard-local order
+ * q = v*n_az + (h-first_az)): t (< 0 = miss) and global triangle id (0xFFFFFFFF = miss). */
+int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid);
+
+/* Exhaustive closest hit on the device (every ray against every triangle, same triangle test):
+ * the full-size checker for the BVH path. */
+int ls_debug_trace_bruteforce(ls_tracer *tr, float *t, uint32_t *gid);
+
+/* Transformed (sensor-frame) vertices and rebased indices of the committed scene. */
+int ls_debug_scene_size(ls_tracer *tr, uint32_t *n_verts, uint32_t *n_tris, uint32_t *n_node_slots,
+                        uint32_t *leaf_size);
+int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx);
+
+/* BVH arrays: n_node_slots BVH2 nodes (64 B each) and n_tris triangle records (48 B each):
+ *   node i: float4 q[4] = (L.lo.xyz, bits(left ref)), (L.hi.xyz, bits(right ref)), (R.lo.xyz, 0), (R.hi.xyz, 0)
+ *     child ref: bit 31 set = leaf k (records [k*leaf_size, k*leaf_size+leaf_size) clipped to n_tris),
+ *     else index of another node; node 0 is the root (a one-leaf scene has no node at all)
+ *   triangle record: float v0[3]; uint32 gid; float e1[3]; float NgC; float e2[3]; uint32 pad */
+int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARSHOOTER_HIP_DEBUG_H */

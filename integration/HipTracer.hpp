@@ -15,10 +15,13 @@
 //   * polygons are flattened and uploaded once per mesh and again only when their fingerprint changes (the
 //     reference never edits them after pcl::io::loadPolygonFileSTL, mainwindow.cpp:146);
 //   * vertices are uploaded every frame by default (MeshProjector::affineMeshCallback rewrites the cloud in
-//     place, MeshProjector.cpp:306-307, so the bytes have to be read anyway); setMeshPolicy(SkipUnchanged)
-//     or LIDARSHOOTER_HIP_SKIP_UNCHANGED=1 makes an update whose cloud still carries the same
-//     (buffer, size, header.seq, header.stamp, 64-vertex probe) a transform-only update: no copy at all
-//     -- what a joystick-driven pose change is (AffineMesh.cpp:108-128);
+//     place, MeshProjector.cpp:306-307, and checking 8 MB costs what sending 8 MB costs).  setMeshPolicy(
+//     SkipUnchanged) or LIDARSHOOTER_HIP_SKIP_UNCHANGED=1 is a CONTRACT, not a guess: an update whose cloud
+//     is the same buffer of the same size with the same header.seq and header.stamp as the one uploaded last
+//     is taken to hold the same vertices and becomes a transform-only update -- no copy at all, what a
+//     joystick-driven pose change is (AffineMesh.cpp:108-128).  Whoever edits vertices in place under that
+//     policy bumps header.seq / header.stamp or calls invalidateMesh(name) (one line in
+//     MeshProjector::affineMeshCallback); the tracer does not sample the data to second-guess it;
 //   * the vertex transform (MeshTransformer.cpp:142-205), ray generation, closest hit and 32-byte point
 //     packing (XYZIRBytes.cpp:24-40) run on the GPU; the points land in pinned host memory (16 bytes each:
 //     the other 16 of a record are constants) with one host wait and are expanded into PointCloud2::data by
@@ -53,8 +56,9 @@ public:
 
     /// What an updateGeometry() call does with the vertex data it is handed
     enum class MeshPolicy {
-        UploadAlways,   ///< default: always correct, ~0.15 ms per 8 MB of vertices
-        SkipUnchanged   ///< same buffer + size + header + probe as last time -> transform-only update
+        UploadAlways,   ///< default: vertices are sent every frame (~0.15 ms per 8 MB), whatever the caller did to them
+        SkipUnchanged   ///< contract: same buffer + size + header.seq + header.stamp as last time == same vertices ->
+                        ///< transform-only update; in-place edits are announced by the header or invalidateMesh()
     };
 
     /// Same signature as EmbreeTracer::create (EmbreeTracer.hpp:51) / OptixTracer::create (OptixTracer.hpp:91)
@@ -91,12 +95,15 @@ public:
     int removeGeometry(const std::string& _meshName) override
     {
         std::lock_guard<std::mutex> lock(_mutex);
+        const bool known = _meshes.count(_meshName) != 0;
         const int rc = ls_remove_geometry(_handle, _meshName.c_str());
-        if (rc >= 0) {
+        if (known && rc != -1) {
+            // the library erased the geometry before it re-committed: the bookkeeping follows even when that commit failed
             _meshes.erase(_meshName);
             setGeometryCount(getGeometryCount() - 1);
         }
-        return rc < -1 ? -1 : rc;
+        if (rc < -1) throw TraceException(__FILE__, ls_last_error(_handle), rc);   // the commit inside failed, as commitScene() reports it
+        return rc;
     }
 
     /// ITracer.hpp:69
@@ -149,29 +156,39 @@ public:
         return rc;
     }
 
-    // ---- the per-name getters of EmbreeTracer (EmbreeTracer.cpp:369-439): unknown names throw
+    // ---- the per-name getters of EmbreeTracer, with its behaviour for unknown names
+    /// EmbreeTracer.cpp:82-89: -1 when the name is unknown (no exception)
     int getGeometryId(const std::string& _meshName) const
     {
         const int rc = ls_geometry_id(_handle, _meshName.c_str());
-        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in geometry ID map", 7);
-        return rc;
+        return rc < 0 ? -1 : rc;
     }
-    long getVertexCount(const std::string& _meshName) const
+    /// EmbreeTracer.cpp:103-113 (test/EmbreeTracer_test.cpp:116-120): TraceException code 8 when unknown
+    RTCGeometryType getGeometryType(const std::string& _meshName)
+    {
+        const int rc = ls_geometry_type(_handle, _meshName.c_str());
+        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in geometry types map", 8);
+        return static_cast<RTCGeometryType>(rc);
+    }
+    /// EmbreeTracer.cpp:369-379: code 1
+    long getVertexCount(const std::string& _meshName)
     {
         const long rc = ls_vertex_count(_handle, _meshName.c_str());
-        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in vertex count map", 3);
+        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in vertex count map", 1);
         return rc;
     }
-    long getElementCount(const std::string& _meshName) const
+    /// EmbreeTracer.cpp:405-415: code 4
+    long getElementCount(const std::string& _meshName)
     {
         const long rc = ls_element_count(_handle, _meshName.c_str());
-        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in element count map", 5);
+        if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in element count map", 4);
         return rc;
     }
 
     void setMeshPolicy(MeshPolicy _policy) { _policy_ = _policy; }
     MeshPolicy getMeshPolicy() const { return _policy_; }
-    /// Forget what is known about a mesh: its next update re-sends vertices and polygons
+    /// Forget what is known about a mesh: its next update re-sends vertices and polygons.  Under SkipUnchanged this is how
+    /// an in-place edit that leaves the cloud's header alone is announced.
     void invalidateMesh(const std::string& _meshName)
     {
         std::lock_guard<std::mutex> lock(_mutex);
@@ -194,7 +211,7 @@ private:
         std::uint64_t polygonProbe = 0;
         const void* vertexStorage = nullptr;
         std::size_t vertexBytes = 0;
-        std::uint64_t vertexProbe = 0, stamp = 0;
+        std::uint64_t stamp = 0;
         std::uint32_t seq = 0, pointStep = 0;
         std::vector<std::uint32_t> flat;   // scratch of the one-off polygon flatten
     };
@@ -240,18 +257,6 @@ private:
         return h;
     }
 
-    static std::uint64_t probeVertices(const std::uint8_t* data, std::size_t count, std::size_t pointStep)
-    {
-        std::uint64_t h = 1469598103934665603ull;
-        const std::size_t step = count > 64 ? count / 64 : 1;
-        for (std::size_t i = 0; i < count; i += step) {
-            std::uint64_t w[2] = {0, 0};
-            std::memcpy(w, data + i * pointStep, 12);
-            h = mix(mix(h, w[0]), w[1]);
-        }
-        return h;
-    }
-
     int updateFromMesh(const std::string& _meshName, const float affine[12], pcl::PolygonMesh::Ptr& _mesh)
     {
         std::lock_guard<std::mutex> lock(_mutex);
@@ -290,14 +295,10 @@ private:
         const std::size_t vertexBytes = st.numVertices * pointStep;
         const std::uint64_t stamp = static_cast<std::uint64_t>(cloud.header.stamp);
         const std::uint32_t seq = static_cast<std::uint32_t>(cloud.header.seq);
-        bool unchanged = false;
-        std::uint64_t vertexProbe = 0;
-        if (_policy_ == MeshPolicy::SkipUnchanged) {
-            vertexProbe = probeVertices(vertexData, st.numVertices, pointStep);
-            unchanged = st.haveVertices && indices == nullptr && st.vertexStorage == static_cast<const void*>(vertexData) &&
-                        st.vertexBytes == vertexBytes && st.pointStep == pointStep && st.seq == seq && st.stamp == stamp &&
-                        st.vertexProbe == vertexProbe;
-        }
+        // SkipUnchanged is a contract (see MeshPolicy): identity of buffer and header stands for identity of content
+        const bool unchanged = _policy_ == MeshPolicy::SkipUnchanged && st.haveVertices && indices == nullptr &&
+                               st.vertexStorage == static_cast<const void*>(vertexData) && st.vertexBytes == vertexBytes &&
+                               st.pointStep == pointStep && st.seq == seq && st.stamp == stamp;
         int rc;
         if (unchanged) {
             rc = ls_update_geometry_transform(_handle, _meshName.c_str(), affine);
@@ -313,7 +314,6 @@ private:
         st.pointStep = static_cast<std::uint32_t>(pointStep);
         st.seq = seq;
         st.stamp = stamp;
-        st.vertexProbe = vertexProbe;
         if (indices != nullptr) {
             st.haveElements = true;
             st.polygonStorage = _mesh->polygons.data();

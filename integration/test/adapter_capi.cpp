@@ -236,5 +236,25 @@ void lsa_upload_counts(lsa_ctx* c, unsigned long long* uploads, unsigned long lo
 }
 void* lsa_handle(lsa_ctx* c) { return c->tracer->getHandle(); }
 
+// EmbreeTracer's per-name getters (EmbreeTracer.cpp:82-113, :369-415).  what: 0 getGeometryId, 1 getGeometryType,
+// 2 getVertexCount, 3 getElementCount.  A TraceException becomes -1000 - its code.
+long lsa_getter(lsa_ctx* c, int what, const char* name)
+{
+    try {
+        switch (what) {
+        case 0: return c->tracer->getGeometryId(name);
+        case 1: return static_cast<long>(c->tracer->getGeometryType(name));
+        case 2: return c->tracer->getVertexCount(name);
+        case 3: return c->tracer->getElementCount(name);
+        default: return -2;
+        }
+    } catch (const TraceException& e) {
+        g_error = e.what();
+        return -1000 - static_cast<long>(e.getErrorCode());
+    }
+}
+// HipTracer::invalidateMesh: how an in-place vertex edit that leaves the header alone is announced under SkipUnchanged
+void lsa_invalidate_mesh(lsa_ctx* c, const char* name) { c->tracer->invalidateMesh(name); }
+
 }  // extern "C"
 #pragma GCC visibility pop

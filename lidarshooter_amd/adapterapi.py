@@ -58,6 +58,10 @@ def load() -> C.CDLL:
     L.lsa_upload_counts.restype = None
     L.lsa_handle.argtypes = [vp]
     L.lsa_handle.restype = vp
+    L.lsa_getter.argtypes = [vp, C.c_int, C.c_char_p]
+    L.lsa_getter.restype = C.c_long
+    L.lsa_invalidate_mesh.argtypes = [vp, C.c_char_p]
+    L.lsa_invalidate_mesh.restype = None
     _lib = L
     return L
 
@@ -173,3 +177,11 @@ class AdapterTracer:
 
     def handle(self) -> int:
         return self.L.lsa_handle(self.c)
+
+    def getter(self, what: str, name: str) -> int:
+        """EmbreeTracer's per-name getters through the adapter: 'id', 'type', 'vertices', 'elements'.  A TraceException
+        comes back as -1000 - its error code (EmbreeTracer.cpp:369-415: codes 1, 4, 8)."""
+        return int(self.L.lsa_getter(self.c, {"id": 0, "type": 1, "vertices": 2, "elements": 3}[what], name.encode()))
+
+    def invalidateMesh(self, name: str):
+        self.L.lsa_invalidate_mesh(self.c, name.encode())

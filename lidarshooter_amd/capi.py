@@ -21,6 +21,10 @@ LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPE
 LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL, LS_OPT_BVH_REFIT = 7, 8, 9, 10, 11
 LS_INFO_LAST_COMMIT_REFIT = 6
 LS_OPT_BVH_INSTANCED = 12
+LS_OPT_UPLOAD_MODE = 13
+LS_GEOMETRY_TYPE_TRIANGLE, LS_GEOMETRY_TYPE_QUAD = 0, 1
+RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("direction", "<f4", 3), ("tmax", "<f4")])   # Ray.hpp:16-35
+REFHIT_DTYPE = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("intensity", "<f4"), ("ring", "<i4")])       # Hit.hpp:16-29
 LS_INFO_BVH_INSTANCED = 7
 LS_INFO_CONCURRENT_STREAMS, LS_INFO_PIPELINE_MODE, LS_INFO_DEVICE_STATUS, LS_INFO_HOST_THREADS, LS_INFO_AZIMUTH_COUNT = 1, 2, 3, 4, 5
 ENGINE_AUTO, ENGINE_BVH, ENGINE_PROJECTION = 0, 1, 2
@@ -34,9 +38,11 @@ SYMBOLS = (
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
     "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
-    "ls_get_visit_counts", "ls_generate_rays", "ls_debug_dense_hits", "ls_debug_trace_bruteforce",
-    "ls_debug_scene_size", "ls_debug_download_scene", "ls_debug_download_bvh",
+    "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type",
 )
+# include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
+DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",
+                 "ls_debug_download_bvh")
 
 
 class SensorDesc(C.Structure):
@@ -137,6 +143,8 @@ def load() -> C.CDLL:
     L.ls_get_timings.argtypes = [vp, f32p]
     L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ls_generate_rays.argtypes = [vp, vp, vp, vp]
+    L.ls_generate_rays_aos.argtypes = [vp, vp, vp]
+    L.ls_geometry_type.argtypes = [vp, C.c_char_p]
     L.ls_debug_dense_hits.argtypes = [vp, f32p, u32p]
     L.ls_debug_trace_bruteforce.argtypes = [vp, f32p, u32p]
     L.ls_debug_scene_size.argtypes = [vp, u32p, u32p, u32p, u32p]
@@ -273,6 +281,10 @@ class Tracer:
     def getGeometryId(self, name: str) -> int:
         return self.L.ls_geometry_id(self.h, name.encode())
 
+    def getGeometryType(self, name: str) -> int:
+        """EmbreeTracer::getGeometryType (EmbreeTracer.cpp:103-113): LS_GEOMETRY_TYPE_* or a negative status."""
+        return self.L.ls_geometry_type(self.h, name.encode())
+
     def getVertexCount(self, name: str) -> int:
         return int(self.L.ls_vertex_count(self.h, name.encode()))
 
@@ -342,6 +354,10 @@ class Tracer:
         return self._check(self.L.ls_generate_rays(self.h, d_dx, d_dy, d_dz), "ls_generate_rays")
 
     # ---- test hooks
+    def generateRaysAos(self, d_rays: int | None, d_hits: int | None):
+        """LidarDevice::allRaysGPU's two buffers (Ray 32 B, Hit 24 B per ray) in device memory of the caller."""
+        self._check(self.L.ls_generate_rays_aos(self.h, d_rays, d_hits), "ls_generate_rays_aos")
+
     def denseHits(self):
         n = self.getTotalRays()
         t = np.zeros(n, np.float32)

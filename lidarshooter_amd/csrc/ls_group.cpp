@@ -51,7 +51,7 @@ constexpr int kSets = 3;
 }  // namespace
 
 struct ls_group {
-    uint32_t world = 1, rank = 0;
+    uint32_t world = 1, rank = 0, full_turn = 0;
     int mode = LS_GROUP_SHARDED;
     ls_tracer *tr = nullptr;
     ncclComm_t comm = nullptr;
@@ -146,7 +146,8 @@ void ls_group_destroy(ls_group *g)
     if (g->tr) {
         (void)ls_tracer_synchronize(g->tr);
         (void)ls_tracer_set_output_buffers(g->tr, nullptr, nullptr, nullptr, 0);
-        (void)ls_tracer_set_stream(g->tr, nullptr);
+        (void)ls_tracer_set_stream(g->tr, nullptr);   // back on its own stream before the group's streams go
+        if (g->full_turn) (void)ls_tracer_set_shard(g->tr, 0, g->full_turn);
     }
     if (g->comm_stream) (void)hipStreamSynchronize(g->comm_stream);
     if (g->comm && rccl().CommDestroy) (void)rccl().CommDestroy(g->comm);
@@ -175,10 +176,13 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
     g->world = world;
     g->rank = rank;
     g->mode = mode;
-    g->tr = tr;
+    // Everything that can fail without the tracer comes first (streams, events, RCCL, the communicator, device memory):
+    // until `attached` the caller's tracer has not been touched and a failure leaves it exactly as it was.  Afterwards
+    // a failure puts it back on its own stream, on the full turn and on its own output buffers before the group's
+    // streams are destroyed (ls_group_destroy does that for an attached tracer).
+    bool attached = false;
     auto bail = [&](int code) {
-        std::string msg = g->err;
-        g->tr = nullptr;   // the tracer stays the caller's, untouched
+        if (!attached) g->tr = nullptr;
         ls_group_destroy(g);
         return code;
     };
@@ -186,7 +190,7 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
     const long h = ls_get_info(tr, LS_INFO_AZIMUTH_COUNT);
     if (h < 2 || !V) return bail(LS_ERR_INVALID_ARGUMENT);
     const uint32_t H = (uint32_t)h;
-    if (ls_tracer_set_shard(tr, 0, H) != LS_OK) return bail(LS_ERR_INVALID_ARGUMENT);   // the full turn unless sharded below
+    g->full_turn = H;
     if (hipStreamCreateWithFlags(&g->trace_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(LS_ERR_HIP);
@@ -194,12 +198,10 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
         if (hipEventCreateWithFlags(&g->ev_traced[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_collected[i], hipEventDisableTiming) != hipSuccess)
             return bail(LS_ERR_HIP);
-    if (ls_tracer_set_stream(tr, g->trace_stream) != LS_OK) return bail(LS_ERR_HIP);
     g->cloud_capacity = V * H;
+    uint32_t first = 0, n = H;
     if (mode == LS_GROUP_SHARDED) {
-        uint32_t first = 0, n = 0;
         ls_group_shard_columns(H, world, rank, &first, &n);
-        if (ls_tracer_set_shard(tr, first, n) != LS_OK) return bail(LS_ERR_INVALID_ARGUMENT);
         g->capacity = ls_group_slot_capacity(V, H, world);
         g->slot_bytes = (size_t)ls_group_slot_bytes(g->capacity);
         g->cloud_capacity = g->capacity * world;
@@ -220,6 +222,11 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
             hipMalloc(reinterpret_cast<void **>(&g->cloud_hits[i]), (size_t)g->cloud_capacity * 16) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&g->cloud_n[i]), 64) != hipSuccess)
             return bail(LS_ERR_HIP);
+    // ---- nothing but the tracer itself can fail from here on
+    g->tr = tr;
+    attached = true;
+    if (ls_tracer_set_stream(tr, g->trace_stream) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
+    if (ls_tracer_set_shard(tr, first, n) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_INVALID_ARGUMENT); }
     *out = g;
     return LS_OK;
 }

@@ -1,0 +1,415 @@
+// ls_handle.cpp -- the tracer handle: create / destroy (EmbreeTracer::create, EmbreeTracer.cpp:10-70), the sensor's
+// ray-direction tables (LidarDevice.cpp:294-342), options, facts, shard / stream / output-buffer plumbing and the small
+// stand-alone calls (ray generation, cloud to world, expansion of gathered hit slots).  No compute happens on the host:
+// if there is no usable HIP device the create call fails (LS_ERR_NO_DEVICE); there is no CPU fallback in this library.
+#include "ls_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace lsi {
+
+namespace {
+
+// LidarDevice.cpp:306-316 on the host: the V+H distinct angles of a revolution go through libm
+// (sinf/cosf, exactly like the reference's CPU path); the kernels only multiply table entries.
+void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
+{
+    const uint32_t V = tr->V, H = tr->H;
+    tab.resize(2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V + 2 * (size_t)H + (size_t)V);
+    const float step = tr->h_step;  // LidarDevice.cpp:611
+    if (!tr->given_tables.empty()) {
+        // ls_tracer_create_tables: the caller's factor tables, bit for bit
+        std::memcpy(tab.data(), tr->given_tables.data(), (2 * (size_t)V + 2 * (size_t)H) * sizeof(float));
+    } else {
+        for (uint32_t v = 0; v < V; ++v) {
+            const float preChi = tr->vertical[v];
+            const float theta = static_cast<float>((90.0 - static_cast<double>(preChi)) * M_PI / 180.0);
+            tab[v] = std::sin(theta);
+            tab[V + v] = std::cos(theta);
+        }
+        for (uint32_t h = 0; h < H; ++h) {
+            const float prePhi = tr->h_begin + step * static_cast<float>(h);
+            const float phi = static_cast<float>(static_cast<double>(prePhi) * M_PI / 180.0);
+            tab[2 * (size_t)V + h] = std::sin(phi);
+            tab[2 * (size_t)V + H + h] = std::cos(phi);
+        }
+    }
+    // projection engine: channels by ascending elevation; tan(elevation +- margin), nudged outwards
+    std::vector<uint32_t> perm(V);
+    for (uint32_t v = 0; v < V; ++v) perm[v] = v;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return tr->vertical[a] < tr->vertical[b]; });
+    float *up = tab.data() + 2 * (size_t)V + 2 * (size_t)H, *dn = up + V;
+    for (uint32_t i = 0; i < V; ++i) {
+        const double chi = tr->vertical[perm[i]];
+        const double hi = chi + kProjectMarginDeg, lo = chi - kProjectMarginDeg;
+        float tu = hi >= 90.0 ? INFINITY : (hi <= -90.0 ? -INFINITY : static_cast<float>(std::tan(hi * M_PI / 180.0)));
+        float td = lo <= -90.0 ? -INFINITY : (lo >= 90.0 ? INFINITY : static_cast<float>(std::tan(lo * M_PI / 180.0)));
+        up[i] = std::nextafter(tu, INFINITY);
+        dn[i] = std::nextafter(td, -INFINITY);
+        std::memcpy(&dn[V + i], &perm[i], 4);
+    }
+    // (cos_phi, sin_phi) interleaved
+    float *cs = tab.data() + 2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V;
+    for (uint32_t h = 0; h < H; ++h) {
+        cs[2 * (size_t)h] = tab[2 * (size_t)V + H + h];
+        cs[2 * (size_t)h + 1] = tab[2 * (size_t)V + h];
+    }
+    // inverse channel permutation
+    float *rank = cs + 2 * (size_t)H;
+    for (uint32_t i = 0; i < V; ++i) {
+        const uint32_t pos = i;
+        std::memcpy(&rank[perm[i]], &pos, 4);
+    }
+}
+
+}  // namespace
+
+}  // namespace lsi
+
+using namespace lsi;
+
+extern "C" {
+
+int ls_abi_version(void) { return LS_ABI_VERSION; }
+
+// shared tail of the two create calls: `tr` holds the sensor (V, H, vertical, h_begin / h_step, pose and, for
+// ls_tracer_create_tables, the given factor tables)
+static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev) {
+        delete tr;
+        return LS_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(hip_device) != hipSuccess) {
+        delete tr;
+        return LS_ERR_NO_DEVICE;
+    }
+    tr->device = hip_device;
+    tr->az0 = 0;
+    tr->naz = tr->H;
+    auto bail = [&](int code) {
+        ls_tracer_destroy(tr);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&tr->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(LS_ERR_HIP);
+    tr->stream = tr->own_stream;
+    std::vector<float> tab;
+    fill_tables(tr, tab);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_tables), tab.size() * 4) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMemcpy(tr->d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_maxabs), 4) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_queue_heads), ls::kQueues * 16 * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&tr->d_big_count), 4 * ls::kCounterSlotWords * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
+    for (float chi : tr->vertical)
+        if (!(chi >= -90.0f && chi <= 90.0f)) tr->projection_ok = false;  // elevation == channel angle only there
+    if (!std::isfinite(tr->h_begin) || !std::isfinite(tr->h_end)) tr->projection_ok = false;
+    if (tr->V > 32767u) tr->projection_ok = false;  // channel range is packed into 16+15 bits
+    tr->trace_blocks = ls::trace_grid_blocks(hip_device);
+    {
+        // Ray order of the persistent trace grid.  Round 1 visited the channels at a stride near 0.38 V (cheap sky channels
+        // and expensive grazing ones alternate in every queue) and refilled 24 idle lanes at a time.  Measured again in
+        // round 2 (bench.py --engine bvh, k_trace_inst and k_trace alike): rings one after the other, from the highest
+        // elevation down (position (j * chan_mul) % V of the elevation order with chan_mul = 1: a wave's next 64 rays
+        // pass the nodes its last 64 did), whole-wave refills (idle lanes wait until 56 of 64 are idle) and 2 resident
+        // blocks per CU: 0.150 ms against 0.186.  The other direction, lowest ring first, takes 0.194 ms; tiles of
+        // 4 x 16 or 8 x 8 rays instead of 64 x 1 take 0.156 / 0.159.
+        auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+        tr->chan_mul = 1u;
+        tr->refill_min = 56u;
+        { const uint32_t v = (uint32_t)tune_int("LS_TRACE_CHAN_MUL", 1); if (v && gcd(v, tr->V) == 1u) tr->chan_mul = v; }
+        { const int v = tune_int("LS_TRACE_REFILL_MIN", 56); if (v >= 1 && v <= 64) tr->refill_min = (uint32_t)v; }
+    }
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_status), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    *tr->h_status = 0u;
+    tr->slot_tri_first.assign(1, 0u);
+    *out = tr;
+    return LS_OK;
+}
+
+int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
+{
+    if (!out) return LS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return LS_ERR_INVALID_ARGUMENT;
+    if ((unsigned long long)sd->n_vertical * sd->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;  // ray indices are 32-bit
+    ls_tracer *tr = new ls_tracer();
+    tr->V = sd->n_vertical;
+    tr->H = sd->h_count;
+    tr->vertical.assign(sd->vertical_deg, sd->vertical_deg + sd->n_vertical);
+    tr->h_begin = sd->h_begin;
+    tr->h_end = sd->h_end;
+    tr->h_step = (sd->h_end - sd->h_begin) / static_cast<float>(sd->h_count - 1u);  // LidarDevice.cpp:611
+    std::memcpy(tr->rinv, sd->Rinv, sizeof(tr->rinv));
+    std::memcpy(tr->t, sd->t, sizeof(tr->t));
+    return create_device_state(tr, hip_device, out);
+}
+
+int ls_tracer_create_tables(const ls_sensor_tables *st, int hip_device, ls_tracer **out)
+{
+    if (!out) return LS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!st || !st->sin_theta || !st->cos_theta || !st->elevation_deg || !st->sin_phi || !st->cos_phi || st->n_vertical == 0 ||
+        st->h_count < 2)
+        return LS_ERR_INVALID_ARGUMENT;
+    if ((unsigned long long)st->n_vertical * st->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;
+    ls_tracer *tr = new ls_tracer();
+    const uint32_t V = tr->V = st->n_vertical, H = tr->H = st->h_count;
+    tr->vertical.assign(st->elevation_deg, st->elevation_deg + V);
+    tr->h_begin = st->h_begin_deg;
+    tr->h_step = st->h_step_deg;
+    tr->h_end = st->h_begin_deg + st->h_step_deg * static_cast<float>(H - 1u);
+    tr->given_tables.resize(2 * (size_t)V + 2 * (size_t)H);
+    std::memcpy(tr->given_tables.data(), st->sin_theta, V * sizeof(float));
+    std::memcpy(tr->given_tables.data() + V, st->cos_theta, V * sizeof(float));
+    std::memcpy(tr->given_tables.data() + 2 * (size_t)V, st->sin_phi, H * sizeof(float));
+    std::memcpy(tr->given_tables.data() + 2 * (size_t)V + H, st->cos_phi, H * sizeof(float));
+    std::memcpy(tr->rinv, st->Rinv, sizeof(tr->rinv));
+    std::memcpy(tr->t, st->t, sizeof(tr->t));
+    return create_device_state(tr, hip_device, out);
+}
+
+void ls_tracer_destroy(ls_tracer *tr)
+{
+    if (!tr) return;
+    (void)hipSetDevice(tr->device);
+    if (tr->stream) (void)hipStreamSynchronize(tr->stream);
+    for (auto &kv : tr->geoms) free_geometry(kv.second);
+    for (int i = 0; i < 3; ++i)
+        if (tr->slot_stream[i]) (void)hipStreamSynchronize(tr->slot_stream[i]);
+    release(tr->best_keys_b); release(tr->big_queue_b); release(tr->points_b); release(tr->hits_b); release(tr->pack_status);
+    release(tr->best_keys_c); release(tr->big_queue_c); release(tr->points_c); release(tr->hits_c);
+    if (tr->d_n_points_b) (void)hipFree(tr->d_n_points_b);
+    if (tr->d_n_points_c) (void)hipFree(tr->d_n_points_c);
+    if (tr->ev_main) (void)hipEventDestroy(tr->ev_main);
+    for (int i = 0; i < 3; ++i) {
+        if (tr->ev_done[i]) (void)hipEventDestroy(tr->ev_done[i]);
+        bool dup = false;
+        for (int k = 0; k < i; ++k) dup = dup || tr->slot_stream[k] == tr->slot_stream[i];
+        if (tr->slot_stream[i] && !dup) (void)hipStreamDestroy(tr->slot_stream[i]);
+    }
+    release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
+    release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
+    release(tr->inst_verts); release(tr->inst_tris); release(tr->treelet);
+    if (tr->d_inst_maxabs) (void)hipFree(tr->d_inst_maxabs);
+    release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
+    release(tr->row_counts); release(tr->points); release(tr->hits);
+    if (tr->d_tables) (void)hipFree(tr->d_tables);
+    if (tr->d_maxabs) (void)hipFree(tr->d_maxabs);
+    if (tr->d_visits) (void)hipFree(tr->d_visits);
+    if (tr->d_n_points) (void)hipFree(tr->d_n_points);
+    if (tr->d_queue_heads) (void)hipFree(tr->d_queue_heads);
+    if (tr->d_big_count) (void)hipFree(tr->d_big_count);
+    release(tr->cull_list);
+    if (tr->d_aabb6) (void)hipFree(tr->d_aabb6);
+    release(tr->best_keys);
+    release(tr->big_queue);
+    release(tr->spill);
+    if (tr->h_points) (void)hipHostFree(tr->h_points);
+    if (tr->h_hits) (void)hipHostFree(tr->h_hits);
+    if (tr->h_n_points) (void)hipHostFree(tr->h_n_points);
+    if (tr->h_status) (void)hipHostFree(tr->h_status);
+    for (auto &r : tr->trec)
+        for (auto &e : r.ev)
+            if (e) (void)hipEventDestroy(e);
+    if (tr->own_stream) (void)hipStreamDestroy(tr->own_stream);
+    delete tr;
+}
+
+uint32_t ls_total_rays(ls_tracer *tr) { return tr ? shard_rays(tr) : 0u; }
+uint32_t ls_total_channels(ls_tracer *tr) { return tr ? tr->V : 0u; }
+
+const char *ls_last_error(ls_tracer *tr) { return tr ? tr->err.c_str() : "null tracer"; }
+
+int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az)
+{
+    LS_ENTER(tr);
+    if (n_az == 0 || first_az >= tr->H || n_az > tr->H - first_az) return fail(tr, LS_ERR_OUT_OF_RANGE, "shard outside [0, H)");
+    const int rc = flush_pipeline(tr);   // frames in flight keep their shard; the keys are re-armed behind them
+    if (rc) return rc;
+    tr->az0 = first_az;
+    tr->naz = n_az;
+    tr->traced = false;
+    tr->keys_armed = false;
+    tr->keys_b_armed = false;
+    tr->keys_c_armed = false;
+    return LS_OK;
+}
+
+int ls_cloud_to_world(ls_tracer *tr, const float *affine3x4, const float *R, const void *d_points32_in,
+                      const uint32_t *d_n_points, void *d_points32_out, const uint32_t *d_out_base,
+                      uint32_t *d_out_total, uint32_t out_capacity)
+{
+    LS_ENTER(tr);
+    if (!R || !d_points32_in || !d_n_points || !d_points32_out)
+        return fail(tr, LS_ERR_INVALID_ARGUMENT, "R, the input cloud, its count and the output cloud are required");
+    static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    ls::Affine m;
+    std::memcpy(m.a, affine3x4 ? affine3x4 : kIdentity, sizeof(m.a));
+    std::memcpy(m.rinv, R, sizeof(m.rinv));
+    std::memcpy(m.t, tr->t, sizeof(m.t));
+    // a traced cloud never holds more points than the sensor has rays; a merged input may: bound by the capacity
+    const uint32_t max_points = std::max(out_capacity, tr->V * tr->H);
+    ls::launch_cloud_to_world(tr->stream, m, d_points32_in, d_n_points, d_points32_out, d_out_base, d_out_total, out_capacity,
+                              max_points);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream)
+{
+    LS_ENTER(tr);
+    const int rc = flush_pipeline(tr);
+    if (rc) return rc;
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    tr->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : tr->own_stream;
+    return LS_OK;
+}
+
+long ls_get_info(ls_tracer *tr, int what)
+{
+    LS_ENTER(tr);
+    switch (what) {
+    case LS_INFO_CONCURRENT_STREAMS: return tr->concurrent_streams;
+    case LS_INFO_PIPELINE_MODE: return tr->opt_pipeline;
+    case LS_INFO_DEVICE_STATUS: {
+        const int rc = flush_pipeline(tr);
+        if (rc) return rc;
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        return (long)__atomic_exchange_n(tr->h_status, 0u, __ATOMIC_ACQ_REL);
+    }
+    case LS_INFO_HOST_THREADS: return host_pool_threads();
+    case LS_INFO_AZIMUTH_COUNT: return (long)tr->H;
+    case LS_INFO_LAST_COMMIT_REFIT: return (!tr->bvh_inst && tr->last_commit_refit) ? 1 : 0;
+    case LS_INFO_BVH_INSTANCED: return tr->bvh_inst ? (tr->last_commit_built ? 2 : 1) : 0;
+    default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
+    }
+}
+
+int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, uint32_t *d_n_points, uint32_t capacity)
+{
+    LS_ENTER(tr);
+    if (!d_points32) {
+        tr->ext_points = tr->ext_hits = nullptr;
+        tr->ext_n_points = nullptr;
+        tr->ext_capacity = 0;
+        return LS_OK;
+    }
+    if (!d_hits || !d_n_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "all three output buffers are required");
+    tr->ext_points = d_points32;
+    tr->ext_hits = d_hits;
+    tr->ext_n_points = d_n_points;
+    tr->ext_capacity = capacity;
+    return LS_OK;
+}
+
+int ls_tracer_set_option(ls_tracer *tr, int option, int value)
+{
+    LS_ENTER(tr);
+    switch (option) {
+    case LS_OPT_LEAF_SIZE:
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(tr, LS_ERR_INVALID_ARGUMENT, "leaf size must be 1, 2, 4 or 8");
+        tr->leaf_size = (uint32_t)value;
+        return LS_OK;
+    case LS_OPT_TIMING:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "timing level must be 0, 1 or 2");
+        tr->opt_timing = value;
+        tr->trec_open = false;
+        return LS_OK;
+    case LS_OPT_COUNT_VISITS: tr->opt_count = value != 0; return LS_OK;
+    case LS_OPT_HOST_OUTPUT:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_HOST_OUTPUT: 0, 1 or 2");
+        tr->opt_host_output = value;
+        return LS_OK;
+    case LS_OPT_READBACK_HITS:
+        if (value < 0 || value > 1) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_READBACK_HITS: 0 or 1");
+        tr->opt_readback_hits = value;
+        return LS_OK;
+    case LS_OPT_UPLOAD_MODE:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_UPLOAD_MODE: 0, 1 or 2");
+        tr->opt_upload_mode = value;
+        return LS_OK;
+    case LS_OPT_DEBUG_FAULT: tr->opt_debug_fault = value != 0; return LS_OK;
+    case LS_OPT_BVH_REFIT: tr->opt_bvh_refit = value != 0; return LS_OK;
+    case LS_OPT_BVH_INSTANCED: tr->opt_bvh_instanced = value != 0; tr->committed = false; return LS_OK;   // takes effect at the next commit
+    case LS_OPT_BLOCK_CULL:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto");
+        tr->opt_block_cull = value;
+        return LS_OK;
+    case LS_OPT_PIPELINE: {
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_PIPELINE: 0 off, 1 two frames on one stream, 2 three streams");
+        if (value == 2) {
+            // three-stream mode needs three streams whose kernels really overlap; with fewer the frames would
+            // serialise silently, so the handle takes mode 1 (two frames on one stream) and says so
+            int rc = flush_pipeline(tr);
+            if (rc) return rc;
+            LS_HIP(hipStreamSynchronize(tr->stream));
+            if ((rc = ensure_slot_streams(tr))) return rc;
+            if (tr->concurrent_streams < 3) {
+                tr->err = "LS_OPT_PIPELINE = 2: only " + std::to_string(tr->concurrent_streams) +
+                          " mutually concurrent streams found on this device; using mode 1 (two frames in flight on one stream)";
+                value = 1;
+            }
+        }
+        if (value == tr->opt_pipeline) return LS_OK;
+        const int rc = flush_pipeline(tr);
+        if (rc) return rc;
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        LS_HIP(hipMemset(tr->d_big_count, 0, 4 * ls::kCounterSlotWords * sizeof(uint32_t)));   // the modes rotate the queue counters differently
+        tr->pipe_seq = 0;
+        tr->ms_seq = 0;
+        tr->opt_pipeline = value;
+        return LS_OK;
+    }
+    case LS_OPT_ENGINE:
+        if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "engine must be 0 (auto), 1 (BVH) or 2 (projection)");
+        if (value == 2 && !tr->projection_ok) return fail(tr, LS_ERR_INVALID_ARGUMENT, "projection engine needs channel angles within [-90, 90] degrees");
+        tr->engine = value;
+        tr->traced = false;
+        return LS_OK;
+    default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown option");
+    }
+}
+
+int ls_expand_gathered_hits_on(ls_tracer *tr, void *hip_stream, const void *d_gathered, uint32_t world, uint32_t capacity,
+                               void *d_points32, void *d_hits, uint32_t *d_n_points)
+{
+    LS_ENTER(tr);
+    if (!d_gathered || !d_points32 || !d_hits || !d_n_points || !world || !capacity)
+        return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
+    ls::launch_expand_slots(hip_stream ? static_cast<hipStream_t>(hip_stream) : tr->stream, tables(tr),
+                            static_cast<const uint32_t *>(d_gathered), world, capacity, 16u + 4u * capacity,
+                            static_cast<uint8_t *>(d_points32), d_hits, d_n_points);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
+                            void *d_hits, uint32_t *d_n_points)
+{
+    return ls_expand_gathered_hits_on(tr, nullptr, d_gathered, world, capacity, d_points32, d_hits, d_n_points);
+}
+
+int ls_generate_rays(ls_tracer *tr, float *dx, float *dy, float *dz)
+{
+    LS_ENTER(tr);
+    if (!dx || !dy || !dz) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    ls::launch_raygen(tr->stream, tables(tr), dx, dy, dz);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+int ls_generate_rays_aos(ls_tracer *tr, void *d_rays, void *d_hits)
+{
+    LS_ENTER(tr);
+    if (!d_rays && !d_hits) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null outputs");
+    ls::launch_raygen_aos(tr->stream, tables(tr), d_rays, d_hits);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+}  // extern "C"

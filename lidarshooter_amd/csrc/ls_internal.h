@@ -1,0 +1,279 @@
+// ls_internal.h -- the tracer handle (struct ls_tracer) and the functions the translation units of the host side share.
+// Internal to liblidarshooter_hip.so; the public surface is include/lidarshooter_hip.h (+ lidarshooter_hip_debug.h).
+//
+//   ls_handle.cpp    lifetime, sensor tables, options, info, shard / stream / output buffers, the small stand-alone calls
+//   ls_registry.cpp  ITracer's geometry bookkeeping: add / remove / update (EmbreeTracer.cpp:115-288), uploads
+//   ls_commit.cpp    commitScene: layout, group-culling data, BVH build / refit / instanced hierarchies
+//   ls_trace.cpp     traceScene: output buffers, frames in flight, the per-frame launch sequence, stage timings
+//   ls_host_pool.cpp worker threads for host-side copies, point expansion
+//   ls_debug.cpp     include/lidarshooter_hip_debug.h (tests and bench.py only)
+#pragma once
+
+#include "../../include/lidarshooter_hip.h"
+#include "ls_kernels.h"
+#include "ls_tuning.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace lsi {
+
+struct Geometry {
+    std::string name;
+    int id = -1;
+    uint32_t n_verts = 0, n_tris = 0;
+    bool quad = false;          // RTC_GEOMETRY_TYPE_QUAD: n_elems quads, traced as n_tris = 2 n_elems triangles
+    uint32_t n_elems = 0;       // elements as registered by addGeometry (= n_tris for triangle geometries)
+    uint32_t *d_quad_idx = nullptr;   // 4*n_elems indices as handed over (converted into d_idx)
+    void *d_raw = nullptr;      // vertex records as uploaded (n_verts * stride bytes)
+    size_t raw_cap = 0;
+    uint32_t stride = 0;
+    uint32_t *d_idx = nullptr;  // 3*n_tris mesh-local vertex indices
+    const void *shared_raw = nullptr;       // ls_update_geometry_device_shared: caller-owned device buffers
+    const uint32_t *shared_idx = nullptr;   // read in place by the kernels, never copied or freed
+    bool has_verts = false, has_idx = false, idx_dirty = true;
+    // host uploads (ls_update_geometry): pinned staging, written by the copy pool, read by the DMA
+    void *h_stage_v = nullptr, *h_stage_i = nullptr;
+    size_t stage_v_cap = 0, stage_i_cap = 0;
+    hipEvent_t ev_stage_v = nullptr, ev_stage_i = nullptr;   // recorded behind the last DMA that reads the staging buffer
+    // group culling (projection engine, meshes with 64 triangles per wave): Morton order of the triangles, the
+    // indices in that order, a mesh-space bound (sheared box) per kCullGroup sorted triangles
+    uint32_t *d_perm = nullptr, *d_idx_sorted = nullptr;
+    float4 *d_boxes = nullptr;
+    bool order_stale = true;    // the topology changed since d_perm / d_idx_sorted were made
+    bool bounds_stale = true;   // vertices (may have) changed since d_boxes were made
+    bool blas_dirty = true;     // BVH engine, instanced mode: vertices or topology changed since this geometry's hierarchy was built
+    bool blas_topo_dirty = true;   // ... the topology did (vertices alone: the sorted order stays, the hierarchy is refitted)
+    uint64_t blas_sorted_epoch = 0;   // key_scratch_epoch at which this geometry's sorted keys were written (0: never)
+    float mesh_maxabs = 0.0f;   // largest |coordinate| of the mesh as uploaded (read back when that hierarchy is built)
+    const void *raw() const { return shared_raw ? shared_raw : d_raw; }
+    const uint32_t *idx() const { return shared_idx ? shared_idx : d_idx; }
+    float affine[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+};
+
+}  // namespace lsi
+
+struct ls_tracer {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    // sensor (LidarDevice state needed by the path)
+    std::vector<float> vertical;
+    float h_begin = 0, h_end = 0, h_step = 0;
+    std::vector<float> given_tables;   // ls_tracer_create_tables: sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H] as handed over
+    uint32_t V = 0, H = 0;
+    float rinv[9], t[3];
+    float *d_tables = nullptr;  // sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H]
+    uint32_t az0 = 0, naz = 0;
+
+    // geometry registry
+    std::map<std::string, lsi::Geometry> geoms;
+    long geometry_count = 0;
+    bool layout_dirty = true;
+
+    // committed scene
+    std::vector<int> slot_geom_ids;       // geometry ids in layout order
+    std::vector<uint32_t> slot_tri_first; // [n+1]
+    uint32_t n_verts = 0, n_tris = 0, n_leaves = 0, n_slots = 0, leaf_size = 1, committed_leaf_size = 1;
+    bool committed = false;
+    lsi::DevBuf<float> verts;
+    lsi::DevBuf<uint32_t> tris, keys_a, keys_b, vals_a, vals_b, geom_table;
+    lsi::DevBuf<uint8_t> sort_temp;
+    lsi::DevBuf<ls::TriRecord> records;
+    lsi::DevBuf<ls::FatNode> nodes;
+    lsi::DevBuf<float4> range_boxes;
+    lsi::DevBuf<unsigned long long> best_keys;  // projection engine: per-ray (t bits, gid) closest-hit key
+    lsi::DevBuf<uint8_t> big_queue;             // projection engine: triangles with very large footprints
+    uint32_t big_capacity = 0;
+    uint32_t *d_big_count = nullptr;
+    bool keys_armed = false;               // best_keys all ~0, counters 0 (k_pack re-arms them every frame)
+    uint32_t frame_parity = 0;             // which of the two block-counter arrays this frame adds into
+    bool scene_materialized = false;       // verts / tris hold the transformed scene of the last commit
+    struct LayoutEntry { std::string name; uint32_t vfirst, tfirst; };
+    std::vector<LayoutEntry> layout;
+    bool projection_ok = true;             // all channel elevations within [-90, 90] degrees
+    int engine = 0;                        // LS_OPT_ENGINE: 0 auto, 1 BVH, 2 projection
+    bool bvh_built = false;
+    lsi::DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
+    uint32_t *d_queue_heads = nullptr;
+    uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 56;
+    // LS_OPT_PIPELINE: the finish + pack workgroups of frame i ride in the launch of frame i+1's k_project;
+    // everything a frame in flight touches exists twice (parity), the queue counter three times
+    int opt_pipeline = 0;
+    bool pipe_pending = false;              // a frame is projected, its finish + pack not launched yet
+    uint32_t pipe_seq = 0;                  // frames issued in pipelined mode since the last flush
+    ls::FinishPackArgs pipe_fa{};           // the pending frame's finish + pack
+    lsi::DevBuf<unsigned long long> pack_status; // chained prefix: (epoch << 32) | hits of every 256-ray workgroup
+    uint32_t pack_epoch = 0;
+    lsi::DevBuf<unsigned long long> best_keys_b; // parity 1 twins of best_keys, big_queue, points, hits, d_n_points
+    lsi::DevBuf<uint8_t> big_queue_b, points_b, hits_b;
+    uint32_t *d_n_points_b = nullptr;
+    bool keys_b_armed = false;
+    // LS_OPT_PIPELINE = 2: whole frames rotate over three streams (three frames in flight); slot 0 / 1 use
+    // the buffers above, slot 2 the ones below; every slot has its own block-count array
+    hipStream_t slot_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_main = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
+    bool slot_pending[3] = {false, false, false};   // frames issued on slot_stream[s] since the last flush
+    // the library enqueues mesh copies on the handle's stream; a slot stream whose epoch is behind orders itself
+    // after that stream before its next frame (every slot, not only the first frame after the copy)
+    uint64_t main_epoch = 0, slot_epoch[3] = {0, 0, 0};
+    uint32_t ms_seq = 0;
+    lsi::DevBuf<unsigned long long> best_keys_c;
+    lsi::DevBuf<uint8_t> big_queue_c, points_c, hits_c;
+    uint32_t *d_n_points_c = nullptr;
+    bool keys_c_armed = false;
+    bool traced_projection = false;        // the last trace ran on the projection engine (dense arrays on demand)
+    const void *last_d_hits = nullptr;     // its hit records and count (device)
+    const uint32_t *last_d_n = nullptr;
+    std::vector<ls::GeomSource> project_srcs;  // scratch of trace_locked
+    ls::RangeTree rt{};
+    uint32_t range_entries = 0;
+    uint32_t *d_maxabs = nullptr;
+    unsigned long long *d_visits = nullptr;
+
+    // trace outputs
+    lsi::DevBuf<float> hit_t;
+    lsi::DevBuf<uint32_t> hit_gid, row_counts;
+    lsi::DevBuf<uint8_t> points;   // 32 B per ray
+    lsi::DevBuf<uint8_t> hits;     // 16 B per ray
+    uint32_t *d_n_points = nullptr;
+    void *ext_points = nullptr, *ext_hits = nullptr;
+    uint32_t *ext_n_points = nullptr;
+    uint32_t ext_capacity = 0;
+    uint8_t *h_points = nullptr;
+    ls_hit *h_hits = nullptr;
+    size_t h_cap = 0;  // records
+    uint32_t *h_n_points = nullptr;
+    bool traced = false;
+    int opt_bvh_refit = 1;       // LS_OPT_BVH_REFIT
+    int opt_bvh_instanced = 1;   // LS_OPT_BVH_INSTANCED: per-geometry hierarchies in mesh space, no build / refit for pose changes
+    bool bvh_inst = false;       // the committed BVH is the instanced one
+    bool inst_valid = false;     // records / nodes / inst_layout hold instanced hierarchies for the current layout and leaf size
+    uint64_t key_scratch_epoch = 1;   // bumped whenever keys_b / vals_b are overwritten by something other than a geometry's own slice
+    bool last_commit_built = false;
+    struct InstSlot { uint32_t node_first, rec_first, n_leaves, range_first; ls::RangeTree rt; };
+    std::vector<InstSlot> inst_layout;   // per layout entry
+    uint32_t inst_leaf_size = 0;
+    lsi::DevBuf<float> inst_verts;    // packed mesh-space vertices of all geometries (build input)
+    lsi::DevBuf<uint32_t> inst_tris;  // their indices, rebased
+    uint32_t *d_inst_maxabs = nullptr;   // kGeomsPerLaunch words
+    lsi::DevBuf<ls::FatNode> treelet; // one-geometry scenes: the top of that hierarchy, breadth-first (k_trace_inst stages it in LDS)
+    bool treelet_valid = false;
+    bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
+    uint32_t bvh_order_tris = 0;
+    bool last_commit_refit = false;
+    int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (geometries of 2 M triangles or more, cull_enabled)
+    lsi::DevBuf<uint32_t> cull_list;  // three survivor lists (one per frame that can be in flight) of cull_chunks entries
+    uint32_t cull_chunks = 0;
+    uint32_t *d_aabb6 = nullptr; // scratch of launch_mesh_order
+    int opt_host_output = 1;     // LS_OPT_HOST_OUTPUT: the pack kernel writes the pinned host buffers itself
+    int opt_readback_hits = 1;   // LS_OPT_READBACK_HITS
+    int opt_upload_mode = 1;     // LS_OPT_UPLOAD_MODE
+    int opt_debug_fault = 0;     // LS_OPT_DEBUG_FAULT (one frame)
+    uint32_t *h_status = nullptr;   // sticky device status word in pinned host memory (bit 0: chained prefix gave up)
+    int concurrent_streams = 0;     // LS_OPT_PIPELINE = 2 calibration result (0 = not run yet)
+
+    // options / measurement
+    int opt_timing = 0;  // 0 off, 1 every stage, 2 only the trace kernel
+    bool opt_count = false;
+    // hipEvent records: one TimingRecord per frame (commit marks 0..6, trace marks 7..9), kept until
+    // ls_get_timings averages and recycles them, so that timing a run never synchronises inside it.
+    struct TimingRecord {
+        hipEvent_t ev[LS_T_COUNT + 2];
+        bool set[LS_T_COUNT + 2];
+    };
+    std::vector<TimingRecord> trec;
+    size_t trec_used = 0;
+    bool trec_open = false;
+};
+
+namespace lsi {
+
+#define LS_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            tr->err = std::string(#call) + ": " + hipGetErrorString(e_);                             \
+            return LS_ERR_HIP;                                                                       \
+        }                                                                                            \
+    } while (0)
+
+inline int fail(ls_tracer *tr, int code, const char *msg)
+{
+    tr->err = msg;
+    return code;
+}
+
+template <typename T>
+inline int ensure(ls_tracer *tr, DevBuf<T> &b, size_t need)
+{
+    if (need <= b.cap) return LS_OK;
+    if (b.p) LS_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t cap = need + need / 8 + 64;
+    LS_HIP(hipMalloc(reinterpret_cast<void **>(&b.p), cap * sizeof(T)));
+    b.cap = cap;
+    return LS_OK;
+}
+
+template <typename T>
+inline void release(DevBuf<T> &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+constexpr float kProjectMarginDeg = 0.005f;  // ~8.7e-5 rad: 5x the polynomial atan2 error (1e-3 deg) + table / test rounding
+
+inline bool use_projection(const ls_tracer *tr) { return tr->engine == 2 || (tr->engine == 0 && tr->projection_ok); }
+inline uint32_t shard_rays(const ls_tracer *tr) { return tr->V * tr->naz; }
+
+// ls_trace.cpp
+ls::SensorTables tables(const ls_tracer *tr);
+ls::ProjectParams project_params(const ls_tracer *tr);
+ls::GeomTable geom_table(const ls_tracer *tr);
+int ensure_slot_streams(ls_tracer *tr);
+int check_device_status(ls_tracer *tr);
+int flush_pipeline(ls_tracer *tr);   // order the handle's stream after every frame still in flight (no host wait)
+inline int order_after_projects(ls_tracer *tr) { return flush_pipeline(tr); }
+void mark(ls_tracer *tr, int i, hipEvent_t *ride = nullptr);
+int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback);
+// ls_registry.cpp
+void affine_from_components(const float *lin, const float *ang, float *A);
+void free_geometry(Geometry &g);
+// ls_commit.cpp
+int materialize_scene(ls_tracer *tr, bool with_maxabs);
+bool cull_enabled(const ls_tracer *tr, const Geometry &g);
+bool inst_inverse(const ls_tracer *tr, const Geometry &ge, double *minv9, double *o3, double *cond);
+int commit_locked(ls_tracer *tr);
+// ls_host_pool.cpp
+void parallel_copy(void *dst, const void *src, size_t bytes);
+int host_pool_threads();
+
+}  // namespace lsi
+
+// every entry point that takes a handle: argument check, the handle's mutex, its device
+#define LS_ENTER(tr)                                   \
+    if (!(tr)) return LS_ERR_INVALID_ARGUMENT;         \
+    std::lock_guard<std::mutex> lock_((tr)->mu);       \
+    if (hipSetDevice((tr)->device) != hipSuccess) return lsi::fail((tr), LS_ERR_HIP, "hipSetDevice failed")

@@ -251,6 +251,8 @@ void launch_dense_from_hits(hipStream_t s, const SensorTables &tb, const void *h
 void launch_expand_slots(hipStream_t s, const SensorTables &tb, const uint32_t *gathered, uint32_t world, uint32_t cap,
                          uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points);
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz);
+// the reference's own buffers (LidarDeviceKernels.cu:38-51): Ray 32 B, Hit 24 B per ray; either may be nullptr
+void launch_raygen_aos(hipStream_t s, const SensorTables &tb, void *rays32, void *hits24);
 void launch_bruteforce(hipStream_t s, const SensorTables &tb, const float *verts, const uint32_t *tris,
                        uint32_t ntris, float *t_out, uint32_t *gid_out);
 

@@ -16,6 +16,7 @@
 //                        (OptixTracer.cpp:895-942)
 #include "ls_kernels.h"
 #include "ls_device.h"
+#include "ls_tuning.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -596,6 +597,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
         if (COUNT) ++trips;
         // one traversal step of this lane in geometry `ig`: a node (both child boxes), then the leaves it leads to
         auto step = [&](const InstGeom &ig) {
+            // `ig` is geometry `gi` as this trip started; advance() may move the lane on to another geometry, whose
+            // leaves must not be tested with `ig`'s records and transform: they wait for the next trip
+            const uint32_t at_entry = gi;
             if (cur != kInvalid && !(cur & kLeafBit)) {
                 float4 A, B, C, D;
                 if (SINGLE && (cur & kTreeletBit)) {
@@ -632,9 +636,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
                     advance();
                 }
             }
-            // (a leaf reached above belongs to `ig`; after advance() moved on to another geometry the loop ends and the
-            // next trip continues there)
-            const uint32_t at_entry = gi;
+            // (a leaf reached above belongs to `ig` unless advance() moved on to another geometry: then the loop does not
+            // run and the next trip continues there)
             while (cur != kInvalid && (cur & kLeafBit) && (SINGLE || gi == at_entry)) {
                 const uint32_t first = (cur & ~kLeafBit) * g;
                 const uint32_t last = min(first + g, ig.n_tris);
@@ -881,6 +884,26 @@ __global__ __launch_bounds__(kBlock) void k_raygen(SensorTables tb, float *__res
     dz[q] = tb.cos_theta[v];
 }
 
+// allRaysGPUKernel's outputs in its own layout (LidarDeviceKernels.cu:25-52): lidarshooter::Ray = origin xyz, tmin,
+// direction xyz, tmax (Ray.hpp:16-35); lidarshooter::Hit = t, normal xyz, intensity, ring (Hit.hpp:16-29), initialised
+// as there: t = 1e16, intensity = 64.0, ring = channel.  Two 16-byte stores per ray, three 8-byte stores per hit record.
+__global__ __launch_bounds__(kBlock) void k_raygen_aos(SensorTables tb, float4 *__restrict__ rays, float2 *__restrict__ hits)
+{
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= tb.V * tb.naz) return;
+    const uint32_t v = q / tb.naz, h = tb.az0 + (q - v * tb.naz);
+    const float st = tb.sin_theta[v];
+    if (rays) {
+        rays[2 * (size_t)q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                      // origin, tmin
+        rays[2 * (size_t)q + 1] = make_float4(st * tb.cos_phi[h], st * tb.sin_phi[h], tb.cos_theta[v], 1e16f);   // direction, tmax
+    }
+    if (hits) {
+        hits[3 * (size_t)q] = make_float2(1e16f, 0.0f);                        // t, normal.x
+        hits[3 * (size_t)q + 1] = make_float2(0.0f, 0.0f);                     // normal.y, normal.z
+        hits[3 * (size_t)q + 2] = make_float2(64.0f, __int_as_float((int)v));  // intensity, ring
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Exhaustive checker: every ray against every triangle straight from the scene arrays (does not
 // touch the BVH or the triangle records).  Triangles are staged through LDS 256 at a time.
@@ -1019,7 +1042,7 @@ uint32_t trace_grid_blocks(int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         cus = (uint32_t)prop.multiProcessorCount;
     uint32_t per_cu = 2u;
-    if (const char *e = getenv("LS_TRACE_BLOCKS_PER_CU")) per_cu = (uint32_t)max(1, atoi(e));
+    per_cu = (uint32_t)max(1, lsi::tune_int("LS_TRACE_BLOCKS_PER_CU", (int)per_cu));
     return cus * per_cu;
 }
 
@@ -1032,7 +1055,7 @@ void launch_trace(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, c
     const uint32_t nq = tb.V * tb.naz;
     if (!nq || !nleaves) return;
     const uint32_t grid = min(grid_blocks, (nq + kBlock - 1) / kBlock);
-    static const int mode = getenv("LS_TRACE_LOAD_MODE") ? atoi(getenv("LS_TRACE_LOAD_MODE")) : 0;
+    static const int mode = lsi::tune_int("LS_TRACE_LOAD_MODE", 0);
     if (visit_counts)
         hipLaunchKernelGGL((k_trace<true, 0>), dim3(grid), dim3(kBlock), 0, s, tb, rq, nodes, records, nleaves, leaf_size,
                            ntris, t_out, gid_out, spill, visit_counts);
@@ -1140,6 +1163,13 @@ void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, 
     const uint32_t n = tb.V * tb.naz;
     if (!n) return;
     hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n)), dim3(kBlock), 0, s, tb, dx, dy, dz);
+}
+
+void launch_raygen_aos(hipStream_t s, const SensorTables &tb, void *rays32, void *hits24)
+{
+    const uint32_t n = tb.V * tb.naz;
+    if (!n) return;
+    hipLaunchKernelGGL(k_raygen_aos, dim3(blocks_for(n)), dim3(kBlock), 0, s, tb, static_cast<float4 *>(rays32), static_cast<float2 *>(hits24));
 }
 
 void launch_bruteforce(hipStream_t s, const SensorTables &tb, const float *verts, const uint32_t *tris,

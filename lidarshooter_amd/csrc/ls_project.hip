@@ -25,6 +25,7 @@
 #include <vector>
 #include "ls_kernels.h"
 #include "ls_device.h"
+#include "ls_tuning.h"
 
 namespace ls {
 
@@ -283,22 +284,16 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Build option -DLS_WAVE_TIMELINE (tools/exp_build.sh, tools/exp_timeline.py; never in the shipped library): every wave
-// of the 400th k_project launch records its start / end (s_memrealtime) and the cycle count at four marks; the host
-// writes the records to $LS_TIMELINE_OUT at the 600th launch.  This is where DESIGN.md's per-phase numbers come from.
+// Per-wave timeline instrumentation of k_project (tools/timeline/, build option -DLS_WAVE_TIMELINE of tools/exp_build.sh;
+// DESIGN.md's per-phase numbers come from it): the marks in project_body are empty in the shipped library.
 #ifdef LS_WAVE_TIMELINE
-__device__ unsigned long long g_timeline[8 * 32768];
-__device__ uint32_t g_tl_on;
-__device__ __forceinline__ unsigned long long tl_mark()
-{
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long t = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define TL_MARK(x) const unsigned long long x = tl_mark()
+#include "../../tools/timeline/ls_wave_timeline.inc"
 #else
+#define TL_BEGIN()
 #define TL_MARK(x)
+#define TL_LOADS_LANDED(raw, best)
+#define TL_END(block_idx, w, lane, total)
+#define TL_HOST_HOOK(s)
 #endif
 
 template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
@@ -312,9 +307,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     auto &s_meta = lds.meta;
     auto &s_pref = lds.pref;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-#ifdef LS_WAVE_TIMELINE
-    const unsigned long long tl_w0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    TL_BEGIN();
     TL_MARK(tl_0);
     // one launch covers up to kGeomsPerLaunch geometries: the workgroup finds its own (uniform)
     uint32_t gi = 0;
@@ -354,8 +347,10 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         if (tris_per_wave == 64u && pp.spread) {
             // big mesh: eight runs of eight triangles, a stride of the wave count apart (same reason as above: a wave's
             // share of the near field, where the cells are, is then the same for every wave)
-            const uint32_t n_waves = (src.ntris + 63u) / 64u;
-            k = ((lane >> 3) * n_waves + (block * (kBlock / 64) + w)) * 8u + (lane & 7u);
+            const uint32_t n_waves = (src.ntris + 63u) / 64u, rank = block * (kBlock / 64) + w;
+            // (the grid is rounded up to whole workgroups: a wave behind the last one would alias onto the next run of
+            // waves 0..2 and project those triangles a second time)
+            if (rank < n_waves) k = ((lane >> 3) * n_waves + rank) * 8u + (lane & 7u);
         } else if (lane < tris_per_wave) {
             k = (block * (kBlock / 64) + w) * tris_per_wave + lane;
         }
@@ -385,9 +380,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     }
     if (!live_wave) return;   // (no barrier follows)
     TL_MARK(tl_1);   // tables staged
-#ifdef LS_WAVE_TIMELINE
-    { float acc = 0.f; for (int i = 0; i < 9; ++i) acc += raw[i]; if (acc == 12345.6789f) best[1] = 0; }   // the loads have landed
-#endif
+    TL_LOADS_LANDED(raw, best);
     TL_MARK(tl_2);
     uint32_t cells = 0, slot = 0;
     if (k < src.ntris) {
@@ -484,19 +477,8 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         wave_lds_fence();
     }
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
-#ifdef LS_WAVE_TIMELINE
     TL_MARK(tl_4);
-    if (g_tl_on && lane == 0) {
-        const uint32_t id = block_idx * (kBlock / 64) + w;
-        if (id < 32768u) {
-            unsigned long long *r = g_timeline + 8 * (size_t)id;
-            uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            r[0] = tl_w0; r[1] = __builtin_amdgcn_s_memrealtime(); r[2] = tl_0; r[3] = tl_1; r[4] = tl_2; r[5] = tl_3; r[6] = tl_4;
-            r[7] = ((unsigned long long)total << 32) | ((unsigned long long)(xcc & 0xF) << 28) | (hwid & 0x0FFFFFFFu);
-        }
-    }
-#endif
+    TL_END(block_idx, w, lane, total);
 }
 
 template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
@@ -1098,8 +1080,8 @@ void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long l
 }
 
 namespace {
-uint32_t min_tpw() { static const uint32_t v = getenv("LS_PROJECT_MIN_TPW") ? (uint32_t)std::max(1, atoi(getenv("LS_PROJECT_MIN_TPW"))) : 1u; return v; }
-uint32_t tpw_waves() { static const uint32_t v = getenv("LS_PROJECT_TPW_WAVES") ? (uint32_t)atoi(getenv("LS_PROJECT_TPW_WAVES")) : 8192u; return v; }
+uint32_t min_tpw() { static const uint32_t v = (uint32_t)std::max(1, lsi::tune_int("LS_PROJECT_MIN_TPW", 1)); return v; }
+uint32_t tpw_waves() { static const uint32_t v = (uint32_t)lsi::tune_int("LS_PROJECT_TPW_WAVES", 8192); return v; }
 
 }  // namespace
 
@@ -1148,22 +1130,8 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
                     uint32_t *cull_list, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (!(pp.tb.V * pp.tb.naz)) return;
-#ifdef LS_WAVE_TIMELINE
-    {
-        static int n_launch = 0;
-        ++n_launch;
-        const uint32_t on = n_launch == 400 ? 1u : 0u;
-        if (n_launch == 400 || n_launch == 401) (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tl_on), &on, 4, 0, hipMemcpyHostToDevice, s);
-        if (n_launch == 600 && getenv("LS_TIMELINE_OUT")) {
-            (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h(8 * 32768);
-            (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_timeline), h.size() * 8);
-            FILE *f = fopen(getenv("LS_TIMELINE_OUT"), "wb");
-            if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-        }
-    }
-#endif
-    static const int fp_at = getenv("LS_PROJECT_FP_AT") ? atoi(getenv("LS_PROJECT_FP_AT")) : -1;
+    TL_HOST_HOOK(s);
+    static const int fp_at = lsi::tune_int("LS_PROJECT_FP_AT", -1);
     BigItem *bq = static_cast<BigItem *>(big);
     const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
     const bool lt = pp.tb.V <= 2048u;   // channel tables fit in LDS (40 KB at most)

@@ -1,0 +1,628 @@
+// ls_trace.cpp -- traceScene (ITracer.hpp:94; EmbreeTracer.cpp:297-367; OptixTracer.cpp:277-358): output buffers, frames in
+// flight (rider mode, three slot streams), the per-frame launch sequence of both engines, stage timings.
+#include "ls_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace lsi {
+
+ls::SensorTables tables(const ls_tracer *tr)
+{
+    ls::SensorTables tb;
+    tb.sin_theta = tr->d_tables;
+    tb.cos_theta = tr->d_tables + tr->V;
+    tb.sin_phi = tr->d_tables + 2 * (size_t)tr->V;
+    tb.cos_phi = tr->d_tables + 2 * (size_t)tr->V + tr->H;
+    tb.cs_phi = reinterpret_cast<const float2 *>(tr->d_tables + 5 * (size_t)tr->V + 2 * (size_t)tr->H);
+    tb.V = tr->V;
+    tb.H = tr->H;
+    tb.az0 = tr->az0;
+    tb.naz = tr->naz;
+    return tb;
+}
+
+ls::GeomTable geom_table(const ls_tracer *tr)
+{
+    ls::GeomTable gt;
+    gt.n = (uint32_t)tr->slot_geom_ids.size();
+    gt.tri_first = tr->geom_table.p;
+    gt.geom_ids = tr->geom_table.p + gt.n + 1;
+    gt.prim_shift = gt.geom_ids + gt.n;
+    return gt;
+}
+
+ls::ProjectParams project_params(const ls_tracer *tr)
+{
+    ls::ProjectParams pp;
+    pp.tb = tables(tr);
+    pp.chan_tan_up = tr->d_tables + 2 * (size_t)tr->V + 2 * (size_t)tr->H;
+    pp.chan_tan_dn = pp.chan_tan_up + tr->V;
+    pp.chan_perm = reinterpret_cast<const uint32_t *>(pp.chan_tan_dn + tr->V);
+    pp.chan_rank = reinterpret_cast<const uint32_t *>(tr->d_tables + 5 * (size_t)tr->V + 4 * (size_t)tr->H);
+    pp.begin_deg = tr->h_begin;
+    pp.step_deg = tr->h_step;  // LidarDevice.cpp:611
+    pp.inv_step_deg = pp.step_deg != 0.0f ? 1.0f / pp.step_deg : 0.0f;
+    pp.inv_period = std::fabs(pp.step_deg) / 360.0f;
+    pp.margin_deg = kProjectMarginDeg;
+    // azimuth sector of the shard, padded by the angular margin and 1.5 columns per side, as two boundary
+    // directions in counter-clockwise order; used to reject triangles early when it spans less than 180 degrees
+    pp.sector_on = 0;
+    pp.sec_a[0] = pp.sec_a[1] = pp.sec_b[0] = pp.sec_b[1] = 0.0f;
+    if (tr->naz < tr->H && pp.step_deg != 0.0f) {
+        const double step = pp.step_deg, pad = kProjectMarginDeg + 1.5 * std::fabs(step);
+        double lo = (double)tr->h_begin + step * (double)tr->az0, hi = (double)tr->h_begin + step * (double)(tr->az0 + tr->naz - 1u);
+        if (lo > hi) std::swap(lo, hi);
+        lo -= pad;
+        hi += pad;
+        if (hi - lo < 179.0) {
+            pp.sector_on = 1;
+            pp.sec_a[0] = (float)std::cos(lo * M_PI / 180.0); pp.sec_a[1] = (float)std::sin(lo * M_PI / 180.0);
+            pp.sec_b[0] = (float)std::cos(hi * M_PI / 180.0); pp.sec_b[1] = (float)std::sin(hi * M_PI / 180.0);
+        }
+    }
+    static const uint32_t big_cells = (uint32_t)tune_int("LS_PROJECT_BIG_CELLS", 128);
+    static const int debug = tune_int("LS_PROJECT_DEBUG", 0);
+    pp.big_cells = big_cells;
+    pp.debug = debug;
+    pp.spread = 1;   // trace_locked clears it for frames that overlap on the three slot streams
+    return pp;
+}
+
+namespace {
+
+// LS_OPT_PIPELINE = 2 needs three streams whose kernels really run side by side.  The runtime multiplexes
+// streams onto a few hardware queues (which ones depends on every stream created before, by anybody in the
+// process), and two streams on one queue serialise: 24 us per frame instead of 16.  So: candidates are created
+// and tried pairwise with an idle 200 us wave each -- two on one queue take twice as long as two on two --
+// until three mutually concurrent ones are found; the rest is destroyed.  A few milliseconds, once per handle.
+// The number found is kept (LS_INFO_CONCURRENT_STREAMS); with fewer than three the handle runs mode 1 instead.
+int pick_slot_streams(ls_tracer *tr)
+{
+    constexpr int kCandidates = 8;
+    constexpr unsigned long long kTicks = 20000;   // 200 us
+    hipStream_t cand[kCandidates] = {};
+    for (auto &c : cand) LS_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    LS_HIP(hipEventCreate(&e0));
+    LS_HIP(hipEventCreate(&ea));
+    LS_HIP(hipEventCreate(&eb));
+    // device-side timing: both waves are launched behind e0; on one hardware queue the second one ends ~400 us
+    // after e0, on two queues ~200 us -- host scheduling noise does not enter
+    auto pair_us = [&](hipStream_t a, hipStream_t b, double &us) -> int {
+        LS_HIP(hipStreamSynchronize(a));
+        LS_HIP(hipStreamSynchronize(b));
+        LS_HIP(hipEventRecord(e0, a));
+        ls::launch_spin(a, kTicks);
+        ls::launch_spin(b, kTicks);
+        LS_HIP(hipEventRecord(ea, a));
+        LS_HIP(hipEventRecord(eb, b));
+        LS_HIP(hipStreamSynchronize(a));
+        LS_HIP(hipStreamSynchronize(b));
+        float ma = 0.f, mb = 0.f;
+        LS_HIP(hipEventElapsedTime(&ma, e0, ea));
+        LS_HIP(hipEventElapsedTime(&mb, e0, eb));
+        us = 1e3 * (double)std::max(ma, mb);
+        return LS_OK;
+    };
+    int rc;
+    double warm;
+    if ((rc = pair_us(cand[0], cand[1], warm))) return rc;   // first launches: code object upload etc.
+    int chosen[3] = {0, -1, -1}, n = 1;
+    for (int c = 1; c < kCandidates && n < 3; ++c) {
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {
+            double us;
+            if ((rc = pair_us(cand[chosen[k]], cand[c], us))) return rc;
+            ok = us < 1.5 * (double)kTicks / 100.0;   // concurrent: ~200 us; serialised: ~400 us
+        }
+        if (ok) chosen[n++] = c;
+    }
+    tr->concurrent_streams = n;
+    for (int i = 0; i < 3; ++i) tr->slot_stream[i] = cand[chosen[i] >= 0 ? chosen[i] : chosen[0]];
+    for (int c = 0; c < kCandidates; ++c) {
+        bool used = false;
+        for (int i = 0; i < 3; ++i) used = used || tr->slot_stream[i] == cand[c];
+        if (!used) (void)hipStreamDestroy(cand[c]);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return LS_OK;
+}
+
+}  // namespace
+
+int ensure_slot_streams(ls_tracer *tr)
+{
+    if (tr->slot_stream[0]) return LS_OK;
+    int rc;
+    LS_HIP(hipEventCreateWithFlags(&tr->ev_main, hipEventDisableTiming | hipEventDisableSystemFence));
+    if ((rc = pick_slot_streams(tr))) return rc;
+    for (int i = 0; i < 3; ++i)
+        LS_HIP(hipEventCreateWithFlags(&tr->ev_done[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    return LS_OK;
+}
+
+namespace {
+
+// pinned host buffers of the synchronous ls_trace_scene (written by the pack kernel itself or by D2H copies)
+int ensure_host_buffers(ls_tracer *tr, size_t records)
+{
+    if (records <= tr->h_cap) return LS_OK;
+    if (tr->h_points) LS_HIP(hipHostFree(tr->h_points));
+    if (tr->h_hits) LS_HIP(hipHostFree(tr->h_hits));
+    tr->h_points = nullptr;
+    tr->h_hits = nullptr;
+    tr->h_cap = 0;
+    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_points), records * 32));
+    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_hits), records * 16));
+    tr->h_cap = records;
+    return LS_OK;
+}
+
+}  // namespace
+
+// the sticky device status word, read after a host wait: a frame whose chained prefix gave up is lost
+int check_device_status(ls_tracer *tr)
+{
+    const uint32_t st = __atomic_exchange_n(tr->h_status, 0u, __ATOMIC_ACQ_REL);
+    if (!st) return LS_OK;
+    tr->err = "device status " + std::to_string(st) + ": the chained prefix of a pipelined finish + pack pass gave up waiting; "
+              "that frame's cloud is incomplete";
+    return LS_ERR_HIP;
+}
+
+namespace {
+
+int ensure_outputs(ls_tracer *tr)
+{
+    const size_t nr = shard_rays(tr);
+    int rc;
+    if ((rc = ensure(tr, tr->hit_t, nr))) return rc;
+    if ((rc = ensure(tr, tr->hit_gid, nr))) return rc;
+    {
+        const size_t c0 = tr->row_counts.cap;
+        if ((rc = ensure(tr, tr->row_counts, 4 * ((nr + 255) / 256) + 8))) return rc;  // two frame-parity arrays (+ two: three-stream mode)
+        if (tr->row_counts.cap != c0) tr->keys_armed = false;
+    }
+    if (use_projection(tr)) {
+        const size_t cap0 = tr->best_keys.cap;
+        if ((rc = ensure(tr, tr->best_keys, nr))) return rc;
+        if (tr->best_keys.cap != cap0) tr->keys_armed = false;
+        if (!tr->big_queue.p) {
+            tr->big_capacity = 2048u;  // culled per 256-ray workgroup in k_project_finish; overflow is expanded in place
+            if ((rc = ensure(tr, tr->big_queue, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
+        }
+    } else {
+        if ((rc = ensure(tr, tr->spill, ls::trace_spill_bytes(tr->trace_blocks) / 4))) return rc;
+    }
+    if (!tr->ext_points) {
+        if ((rc = ensure(tr, tr->points, nr * 32))) return rc;
+        if ((rc = ensure(tr, tr->hits, nr * 16))) return rc;
+    }
+    if (tr->opt_pipeline == 2 && use_projection(tr)) {
+        const size_t cap0 = tr->best_keys_c.cap;
+        if ((rc = ensure(tr, tr->best_keys_c, nr))) return rc;
+        if (tr->best_keys_c.cap != cap0) tr->keys_c_armed = false;
+        if (!tr->big_queue_c.p && (rc = ensure(tr, tr->big_queue_c, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
+        if (!tr->ext_points) {
+            if ((rc = ensure(tr, tr->points_c, nr * 32))) return rc;
+            if ((rc = ensure(tr, tr->hits_c, nr * 16))) return rc;
+        }
+        if (!tr->d_n_points_c) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_n_points_c), 4));
+        if ((rc = ensure_slot_streams(tr))) return rc;
+    }
+    if ((tr->opt_pipeline || tr->pipe_seq) && use_projection(tr)) {   // twins: needed as long as the rotation may stand on parity 1
+        const size_t cap0 = tr->best_keys_b.cap;
+        if ((rc = ensure(tr, tr->best_keys_b, nr))) return rc;
+        if (tr->best_keys_b.cap != cap0) tr->keys_b_armed = false;
+        if (!tr->big_queue_b.p && (rc = ensure(tr, tr->big_queue_b, (size_t)tr->big_capacity * ls::project_big_item_bytes()))) return rc;
+        if (!tr->ext_points) {
+            if ((rc = ensure(tr, tr->points_b, nr * 32))) return rc;
+            if ((rc = ensure(tr, tr->hits_b, nr * 16))) return rc;
+        }
+        if (!tr->d_n_points_b) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_n_points_b), 4));
+        {
+            const size_t cap1 = tr->pack_status.cap;
+            if ((rc = ensure(tr, tr->pack_status, (nr + 255) / 256 + 1))) return rc;
+            if (tr->pack_status.cap != cap1) {   // fresh memory: no word may carry a live epoch tag
+                LS_HIP(hipMemsetAsync(tr->pack_status.p, 0, tr->pack_status.cap * 8, tr->stream));
+                tr->pack_epoch = 0;
+            }
+        }
+    }
+    return LS_OK;
+}
+
+}  // namespace
+
+int flush_pipeline(ls_tracer *tr)
+{
+    for (int i = 0; i < 3; ++i)
+        if (tr->slot_pending[i]) {   // three-stream mode: no per-frame event; the one recorded now covers the stream's frames
+            LS_HIP(hipEventRecord(tr->ev_done[i], tr->slot_stream[i]));
+            LS_HIP(hipStreamWaitEvent(tr->stream, tr->ev_done[i], 0));
+            tr->slot_pending[i] = false;
+        }
+    if (!tr->pipe_pending) return LS_OK;
+    ls::launch_finish_pack(tr->stream, project_params(tr), tr->pipe_fa, nullptr);
+    LS_HIP(hipGetLastError());
+    tr->pipe_pending = false;   // pipe_seq goes on: the next frame, in any mode, takes the next twin and queue counter
+    return LS_OK;
+}
+
+constexpr size_t kMaxTimingRecords = 4096;
+
+// Marks 0..6 bracket the six commit stages, 7..9 bracket trace and pack.  A commit opens a new
+// record; a trace without a preceding commit opens its own.
+// marks: 0..6 bracket the six commit stages; 7..10 bracket trace, trace_aux and pack
+// `ride` (optional): the event is not recorded on the stream here; the caller attaches it to a kernel dispatch
+// (hipExtLaunchKernel), where it carries the kernel's own begin or end timestamp
+void mark(ls_tracer *tr, int i, hipEvent_t *ride)
+{
+    if (ride) *ride = nullptr;
+    if (!tr->opt_timing) return;
+    if (tr->opt_timing == 2 && i != 7 && i != 8) return;
+    const bool opens = (i == 0) || (i == 7 && !tr->trec_open);
+    if (opens) {
+        if (tr->trec_used >= kMaxTimingRecords) { tr->trec_open = false; return; }
+        if (tr->trec_used == tr->trec.size()) {
+            ls_tracer::TimingRecord r;
+            for (auto &e : r.ev) e = nullptr;
+            tr->trec.push_back(r);
+        }
+        for (auto &b : tr->trec[tr->trec_used].set) b = false;
+        ++tr->trec_used;
+        tr->trec_open = true;
+    }
+    if (!tr->trec_open || tr->trec_used == 0) return;
+    ls_tracer::TimingRecord &r = tr->trec[tr->trec_used - 1];
+    if (!r.ev[i] && hipEventCreate(&r.ev[i]) != hipSuccess) return;
+    if (ride) { *ride = r.ev[i]; r.set[i] = true; }
+    else r.set[i] = hipEventRecord(r.ev[i], tr->stream) == hipSuccess;
+    if (i == 10 || (tr->opt_timing == 2 && i == 8)) tr->trec_open = false;
+}
+
+int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
+{
+    if (!out) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null frame");
+    std::memset(out, 0, sizeof(*out));
+    out->frame = frame;
+    out->n_rays = shard_rays(tr);
+    tr->traced = false;
+    if (!tr->committed || tr->n_tris == 0) return -1;  // OptixTracer.cpp:280-288: cleared cloud, -1
+    int rc;
+    if ((rc = ensure_outputs(tr))) return rc;
+    if (tr->ext_points && tr->ext_capacity < shard_rays(tr))
+        return fail(tr, LS_ERR_OUT_OF_RANGE, "external output buffers smaller than the shard's ray count");
+
+    hipStream_t s = tr->stream;   // three-stream mode switches to the frame's own stream below
+    const ls::SensorTables tb = tables(tr);
+    uint8_t *d_points = tr->ext_points ? static_cast<uint8_t *>(tr->ext_points) : tr->points.p;
+    void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
+    uint32_t *d_n = tr->ext_points ? tr->ext_n_points : tr->d_n_points;
+    // synchronous call with the library's own outputs: the pack kernel writes the pinned host buffers itself
+    const bool hv = readback && tr->opt_host_output && !tr->ext_points;
+    if (hv && (rc = ensure_host_buffers(tr, shard_rays(tr)))) return rc;
+    const uint32_t compact = hv && tr->opt_host_output == 2 ? 1u : 0u;
+    auto host_targets = [&]() {
+        if (!hv) return;
+        d_points = tr->h_points;
+        if (tr->opt_readback_hits) d_hits = tr->h_hits;
+        d_n = tr->h_n_points;
+    };
+    host_targets();
+    if (tr->opt_count) LS_HIP(hipMemsetAsync(tr->d_visits, 0, 32, s));
+    if (use_projection(tr)) {
+        // sensor-space projection engine: stream the triangles once, test only the covered rays
+        ls::ProjectParams pp = project_params(tr);
+        unsigned long long *stats = tr->opt_count ? tr->d_visits + 1 : nullptr;  // counts[1] = triangle tests
+        const uint32_t n_blocks = (shard_rays(tr) + 255u) / 256u;
+        const bool pipelined = tr->opt_pipeline == 1 && !tr->opt_count && !tr->opt_timing;
+        const bool multi = tr->opt_pipeline == 2 && !tr->opt_count && !tr->opt_timing;
+        if (!pipelined && !multi && (rc = flush_pipeline(tr))) return rc;
+        {   // spread runs balance the cells per wave (shorter kernel: 23.6 -> 21.2 us alone) but touch more cache lines,
+            // which costs more than it gains once three frames overlap (16.9 -> 17.2 us per frame): LS_PROJECT_SPREAD overrides
+            static const int spread_env = tune_int("LS_PROJECT_SPREAD", -1);
+            pp.spread = spread_env >= 0 ? spread_env : (multi ? 0 : 1);
+        }
+        // which set of keys / queue / outputs and which of the three queue counters this frame uses.
+        // Rider mode and frames that are not pipelined: pipe_seq counts the pipelined frames; a frame that is
+        // not pipelined re-arms what it used itself and leaves pipe_seq alone, so the rotation stays
+        // consistent across mode changes.  Three-stream mode: slot = frame number mod 3.
+        const uint32_t slot = multi ? tr->ms_seq % 3u : (tr->pipe_seq & 1u);
+        unsigned long long *keys = slot == 0 ? tr->best_keys.p : (slot == 1 ? tr->best_keys_b.p : tr->best_keys_c.p);
+        void *bigq = slot == 0 ? static_cast<void *>(tr->big_queue.p)
+                               : (slot == 1 ? static_cast<void *>(tr->big_queue_b.p) : static_cast<void *>(tr->big_queue_c.p));
+        uint32_t *big_count = tr->d_big_count + ls::kCounterSlotWords * (multi ? slot : tr->pipe_seq % 3u);
+        if (slot && !tr->ext_points) {
+            d_points = slot == 1 ? tr->points_b.p : tr->points_c.p;
+            d_hits = slot == 1 ? tr->hits_b.p : tr->hits_c.p;
+            d_n = slot == 1 ? tr->d_n_points_b : tr->d_n_points_c;
+        }
+        host_targets();
+        if (!tr->keys_armed) {
+            // first frame (or a new shard / raster): key set 0, all queue counters, the block counts.  In three-
+            // stream mode the other streams' frames use those counters too: the initialisation completes first
+            ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count, tr->row_counts.p);
+            if (multi) LS_HIP(hipStreamSynchronize(s));
+            tr->keys_armed = true;
+            tr->frame_parity = 0;
+        }
+        if (multi) {
+            // the frame's stream first sees what is enqueued on the handle's stream: the library's own mesh copies,
+            // or anything at all when the stream is the caller's (host API calls are not cheap: only when needed)
+            const bool dep = tr->slot_epoch[slot] != tr->main_epoch || tr->stream != tr->own_stream;
+            if (dep) LS_HIP(hipEventRecord(tr->ev_main, s));
+            s = tr->slot_stream[slot];
+            if (dep) LS_HIP(hipStreamWaitEvent(s, tr->ev_main, 0));
+            tr->slot_epoch[slot] = tr->main_epoch;
+        }
+        if (slot == 1 && !tr->keys_b_armed) {
+            LS_HIP(hipMemsetAsync(tr->best_keys_b.p, 0xFF, (size_t)shard_rays(tr) * 8, s));
+            tr->keys_b_armed = true;
+        }
+        if (slot == 2 && !tr->keys_c_armed) {
+            LS_HIP(hipMemsetAsync(tr->best_keys_c.p, 0xFF, (size_t)shard_rays(tr) * 8, s));
+            tr->keys_c_armed = true;
+        }
+        uint32_t *counts = tr->row_counts.p + (size_t)(multi ? slot : tr->frame_parity) * n_blocks;
+        uint32_t *next_counts = tr->row_counts.p + (size_t)(multi ? 3u : 1u - tr->frame_parity) * n_blocks;
+        // LS_OPT_TIMING = 2 (the dominant kernel alone): the two events ride on the k_project dispatch
+        hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+        const bool ride = tr->opt_timing == 2;
+        mark(tr, 7, ride ? &ev_k0 : nullptr);
+        std::vector<ls::GeomSource> &srcs = tr->project_srcs;
+        srcs.clear();
+        bool any_culled = false;
+        for (const auto &le : tr->layout) {
+            auto it = tr->geoms.find(le.name);
+            if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
+            const Geometry &ge = it->second;
+            ls::GeomSource src;
+            src.verts = static_cast<const uint8_t *>(ge.raw());
+            src.stride = ge.stride;
+            src.idx = ge.idx();
+            src.ntris = ge.n_tris;
+            src.gid_first = le.tfirst;
+            static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            src.xform = std::memcmp(ge.affine, kIdentity, sizeof(kIdentity)) == 0 ? 2 : 1;
+            std::memcpy(src.m.a, ge.affine, sizeof(src.m.a));
+            std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
+            std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
+            // block culling data is current (prepare_blocks ran at the commit) unless an update came in since
+            const bool culled = cull_enabled(tr, ge) && ge.d_boxes && !ge.order_stale && !ge.bounds_stale &&
+                                ls::project_tris_per_wave(ge.n_tris) == 64u;
+            src.perm = culled ? ge.d_perm : nullptr;
+            src.boxes = culled ? ge.d_boxes : nullptr;
+            if (culled) src.idx = ge.d_idx_sorted;
+            any_culled = any_culled || culled;
+            srcs.push_back(src);
+        }
+        // survivor list of this frame's k_cull: one of three (as many frames as can be in flight)
+        uint32_t *cull_list = nullptr;
+        if (any_culled) {
+            const uint32_t entries = ls::project_cull_entries(srcs.data(), (uint32_t)srcs.size());
+            if (entries) {
+                if (entries > tr->cull_chunks) {
+                    if ((rc = flush_pipeline(tr))) return rc;
+                    LS_HIP(hipStreamSynchronize(tr->stream));
+                    if ((rc = ensure(tr, tr->cull_list, 3 * (size_t)entries))) return rc;
+                    tr->cull_chunks = (uint32_t)(tr->cull_list.cap / 3);
+                }
+                cull_list = tr->cull_list.p + (size_t)(multi ? slot : tr->pipe_seq % 3u) * tr->cull_chunks;
+            }
+        }
+        const ls::GeomTable gt = geom_table(tr);
+        if (pipelined) {
+            // one launch: this frame's k_project workgroups + the previous frame's finish + pack workgroups
+            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, nullptr,
+                               tr->pipe_pending ? &tr->pipe_fa : nullptr, cull_list);
+            if (++tr->pack_epoch == 0u) {   // the epoch tag wrapped: no stale status word may match
+                LS_HIP(hipMemsetAsync(tr->pack_status.p, 0, tr->pack_status.cap * 8, s));
+                tr->pack_epoch = 1u;
+            }
+            ls::FinishPackArgs &fa = tr->pipe_fa;   // this frame's, launched with the next frame or by a flush
+            fa.best = keys;
+            fa.big = bigq;
+            fa.big_capacity = tr->big_capacity;
+            fa.big_count = big_count;
+            fa.rearm_big_count = tr->d_big_count + ls::kCounterSlotWords * ((tr->pipe_seq + 2u) % 3u);
+            fa.status = tr->pack_status.p;
+            fa.epoch = tr->pack_epoch;
+            fa.publish_epoch = tr->pack_epoch;
+            fa.spin_limit = 1u << 18;   // ~1 s of backed-off polls
+            fa.device_status = tr->h_status;
+            if (tr->opt_debug_fault) {   // LS_OPT_DEBUG_FAULT: this frame publishes a tag nobody waits for
+                fa.publish_epoch = tr->pack_epoch ^ 0x40000000u;
+                fa.spin_limit = 1u << 6;
+                tr->opt_debug_fault = 0;
+            }
+            fa.gt = gt;
+            fa.points32 = d_points;
+            fa.hits = d_hits;
+            fa.n_points = d_n;
+            fa.n_blocks = n_blocks;
+            fa.compact = compact;
+            tr->pipe_pending = true;
+            ++tr->pipe_seq;
+            if (readback && (rc = flush_pipeline(tr))) return rc;
+        } else {
+            // one launch per 16 geometries (the descriptors travel as kernel arguments)
+            if (ride) mark(tr, 8, &ev_k1);
+            ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list,
+                               ev_k0, ev_k1);
+            if (!ride) mark(tr, 8);
+            ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
+            mark(tr, 9);
+            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n, compact);
+            mark(tr, 10);
+            if (multi) {
+                // no event per frame: a flush (or a mesh copy) records one per stream and orders the handle's stream after it
+                tr->slot_pending[slot] = true;
+                ++tr->ms_seq;
+                s = tr->stream;
+                if (readback && (rc = flush_pipeline(tr))) return rc;
+            } else {
+                tr->frame_parity ^= 1u;
+            }
+        }
+        tr->traced_projection = true;
+        tr->last_d_hits = d_hits;
+        tr->last_d_n = d_n;
+    } else {
+        if (!tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "the BVH engine was selected after the last commit");
+        if ((rc = flush_pipeline(tr))) return rc;
+        LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
+        ls::RayQueues rq;
+        rq.heads = tr->d_queue_heads;
+        rq.chan_mul = tr->chan_mul;
+        rq.refill_min = tr->refill_min;
+        rq.chan_order = reinterpret_cast<const uint32_t *>(tr->d_tables + 4 * (size_t)tr->V + 2 * (size_t)tr->H);   // chan_perm (fill_tables)
+        { static const bool no_order = tune_int("LS_TRACE_NO_ORDER", 0) != 0; if (no_order) rq.chan_order = nullptr; }
+        mark(tr, 7);
+        if (tr->bvh_inst) {
+            // this frame's poses: every geometry's ray map (inverse of mesh -> sensor) and exact transform
+            ls::InstBatch batch;
+            batch.n = (uint32_t)tr->layout.size();
+            for (uint32_t i = 0; i < batch.n; ++i) {
+                auto it = tr->geoms.find(tr->layout[i].name);
+                if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
+                const Geometry &ge = it->second;
+                const ls_tracer::InstSlot &sl = tr->inst_layout[i];
+                ls::InstGeom &ig = batch.g[i];
+                double minv[9], o[3], cond = 1.0;
+                const bool ok = !ge.blas_dirty && inst_inverse(tr, ge, minv, o, &cond);
+                if (!ok) return fail(tr, LS_ERR_NOT_COMMITTED, "a geometry or pose changed since the last commit");
+                ig.node_first = sl.node_first;
+                ig.rec_first = sl.rec_first;
+                ig.n_leaves = sl.n_leaves;
+                ig.n_tris = ge.n_tris;
+                ig.gid_first = tr->layout[i].tfirst;
+                static const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                ig.xform = std::memcmp(ge.affine, kIdentity, sizeof(kIdentity)) == 0 ? 2 : 1;
+                float omax = 0.0f;
+                for (int k = 0; k < 3; ++k) { ig.o[k] = (float)o[k]; omax = std::max(omax, std::fabs(ig.o[k])); }
+                for (int k = 0; k < 9; ++k) ig.minv[k] = (float)minv[k];
+                // rounding of o (6e-8 |o|) and of minv * d along the way to any box (<= |o| + the mesh's extent), times
+                // the conditioning of the map, with a factor of ten in hand
+                ig.eps = 4e-6f * (float)std::max(1.0, cond) * (omax + 2.0f * ge.mesh_maxabs);
+                std::memcpy(ig.m.a, ge.affine, sizeof(ig.m.a));
+                std::memcpy(ig.m.rinv, tr->rinv, sizeof(ig.m.rinv));
+                std::memcpy(ig.m.t, tr->t, sizeof(ig.m.t));
+            }
+            ls::launch_trace_instanced(s, tr->trace_blocks, tb, rq, batch, tr->nodes.p, tr->records.p, tr->inst_leaf_size,
+                                       (batch.n == 1u && tr->treelet_valid) ? tr->treelet.p : nullptr, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
+        } else {
+            ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,
+                             tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
+        }
+        mark(tr, 8);
+        ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p);
+        tr->keys_armed = false;  // the counter array was just used with the BVH layout
+        mark(tr, 9);
+        const ls::GeomTable gt = geom_table(tr);
+        ls::launch_pack(s, tb, tr->hit_t.p, tr->hit_gid.p, tr->row_counts.p, gt, d_points, d_hits, d_n, compact);
+        tr->traced_projection = false;
+        mark(tr, 10);
+    }
+    LS_HIP(hipGetLastError());
+    tr->traced = true;
+    out->d_points32 = d_points;
+    out->d_hits = d_hits;
+    out->d_n_points = d_n;
+    if (!readback) return LS_OK;
+
+    if (hv) {
+        LS_HIP(hipStreamSynchronize(s));   // the only host wait of the frame
+        if ((rc = check_device_status(tr))) return rc;
+        out->n_points = *tr->h_n_points;
+        out->points32 = compact ? nullptr : tr->h_points;
+        out->compact16 = compact ? tr->h_points : nullptr;
+        out->hits = tr->opt_readback_hits ? tr->h_hits : nullptr;
+        return LS_OK;
+    }
+    LS_HIP(hipMemcpyAsync(tr->h_n_points, d_n, 4, hipMemcpyDeviceToHost, s));
+    LS_HIP(hipStreamSynchronize(s));
+    if ((rc = check_device_status(tr))) return rc;
+    const uint32_t n = *tr->h_n_points;
+    if ((rc = ensure_host_buffers(tr, std::max<size_t>(shard_rays(tr), n)))) return rc;
+    if (n) {
+        LS_HIP(hipMemcpyAsync(tr->h_points, d_points, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        if (tr->opt_readback_hits) LS_HIP(hipMemcpyAsync(tr->h_hits, d_hits, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+        LS_HIP(hipStreamSynchronize(s));
+    }
+    out->n_points = n;
+    out->points32 = tr->h_points;
+    out->hits = tr->opt_readback_hits ? tr->h_hits : nullptr;
+    return LS_OK;
+}
+
+}  // namespace lsi
+
+using namespace lsi;
+
+extern "C" {
+
+int ls_trace_scene(ls_tracer *tr, uint32_t frame_index, ls_frame *out)
+{
+    LS_ENTER(tr);
+    return trace_locked(tr, frame_index, out, true);
+}
+
+int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out)
+{
+    LS_ENTER(tr);
+    return trace_locked(tr, frame_index, out, false);
+}
+
+int ls_tracer_synchronize(ls_tracer *tr)
+{
+    LS_ENTER(tr);
+    const int rc = flush_pipeline(tr);
+    if (rc) return rc;
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    return check_device_status(tr);
+}
+
+int ls_tracer_flush(ls_tracer *tr)
+{
+    LS_ENTER(tr);
+    return flush_pipeline(tr);
+}
+
+int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT])
+{
+    LS_ENTER(tr);
+    if (!ms) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    static const int first[LS_T_COUNT] = {0, 1, 2, 3, 4, 5, 7, 8, 9};
+    double sum[LS_T_COUNT] = {};
+    uint32_t cnt[LS_T_COUNT] = {};
+    for (size_t k = 0; k < tr->trec_used; ++k) {
+        const ls_tracer::TimingRecord &r = tr->trec[k];
+        for (int i = 0; i < LS_T_COUNT; ++i) {
+            const int a = first[i], b = a + 1;
+            if (!r.set[a] || !r.set[b]) continue;
+            float v = 0.0f;
+            if (hipEventElapsedTime(&v, r.ev[a], r.ev[b]) == hipSuccess) { sum[i] += v; ++cnt[i]; }
+        }
+    }
+    for (int i = 0; i < LS_T_COUNT; ++i) ms[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.0f;
+    const int n = (int)tr->trec_used;
+    tr->trec_used = 0;
+    tr->trec_open = false;
+    return n;
+}
+
+int ls_get_visit_counts(ls_tracer *tr, uint64_t counts[4])
+{
+    LS_ENTER(tr);
+    if (!counts) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    LS_HIP(hipMemcpy(counts, tr->d_visits, 32, hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
+}  // extern "C"

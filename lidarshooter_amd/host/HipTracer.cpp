@@ -96,24 +96,34 @@ int HipTracer::traceScene(std::uint32_t _frameIndex)
 
 long HipTracer::getGeometryCount() const { return ls_geometry_count(_handle); }
 
+// EmbreeTracer.cpp:82-89: -1 when the name is unknown (no exception)
 int HipTracer::getGeometryId(const std::string& _meshName) const
 {
     const int rc = ls_geometry_id(_handle, _meshName.c_str());
-    if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in geometry ID map", 7);
-    return rc;
+    return rc < 0 ? -1 : rc;
 }
 
-long HipTracer::getVertexCount(const std::string& _meshName) const
+// EmbreeTracer.cpp:103-113: TraceException code 8 when the name is unknown
+RTCGeometryType HipTracer::getGeometryType(const std::string& _meshName)
+{
+    const int rc = ls_geometry_type(_handle, _meshName.c_str());
+    if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in geometry types map", 8);
+    return static_cast<RTCGeometryType>(rc);
+}
+
+// EmbreeTracer.cpp:369-379: code 1
+long HipTracer::getVertexCount(const std::string& _meshName)
 {
     const long rc = ls_vertex_count(_handle, _meshName.c_str());
-    if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in vertex count map", 3);
+    if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in vertex count map", 1);
     return rc;
 }
 
-long HipTracer::getElementCount(const std::string& _meshName) const
+// EmbreeTracer.cpp:405-415: code 4
+long HipTracer::getElementCount(const std::string& _meshName)
 {
     const long rc = ls_element_count(_handle, _meshName.c_str());
-    if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in element count map", 5);
+    if (rc < 0) throw TraceException(__FILE__, "Geometry key does not exist in element count map", 4);
     return rc;
 }
 

@@ -42,10 +42,12 @@ public:
     int traceScene(std::uint32_t _frameIndex);
 
     long getGeometryCount() const;
-    // EmbreeTracer.cpp:369-439: unknown names throw TraceException
+    // EmbreeTracer.cpp:82-113, :369-415: getGeometryId returns -1 for an unknown name, the others throw TraceException
+    // (codes 8, 1, 4)
     int getGeometryId(const std::string& _meshName) const;
-    long getVertexCount(const std::string& _meshName) const;
-    long getElementCount(const std::string& _meshName) const;
+    RTCGeometryType getGeometryType(const std::string& _meshName);
+    long getVertexCount(const std::string& _meshName);
+    long getElementCount(const std::string& _meshName);
 
     std::shared_ptr<PointCloud2> getTraceCloud() { return _traceCloud; }
     void setTraceCloud(std::shared_ptr<PointCloud2> _traceStorage) { _traceCloud = std::move(_traceStorage); }

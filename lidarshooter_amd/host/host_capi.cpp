@@ -145,6 +145,12 @@ int lsh_tracer_geometry_id(lsh_tracer* t, const char* name)
 {
     try { return t->p->getGeometryId(name); } catch (const std::exception& e) { g_err = e.what(); return -100; }
 }
+// TraceException -> -1000 - its code (EmbreeTracer.cpp:103-113: 8)
+int lsh_tracer_geometry_type(lsh_tracer* t, const char* name)
+{
+    try { return static_cast<int>(t->p->getGeometryType(name)); }
+    catch (const TraceException& e) { g_err = e.what(); return -1000 - static_cast<int>(e.getErrorCode()); }
+}
 // cloud of the last traceScene: out4 = width,height,point_step,seq; returns pointer to cloud.data
 const void* lsh_tracer_cloud(lsh_tracer* t, unsigned* out4)
 {

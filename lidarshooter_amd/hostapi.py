@@ -65,6 +65,7 @@ def load() -> C.CDLL:
     L.lsh_tracer_element_count.argtypes = [vp, C.c_char_p]
     L.lsh_tracer_element_count.restype = C.c_long
     L.lsh_tracer_geometry_id.argtypes = [vp, C.c_char_p]
+    L.lsh_tracer_geometry_type.argtypes = [vp, C.c_char_p]
     L.lsh_tracer_cloud.argtypes = [vp, u32p]
     L.lsh_tracer_cloud.restype = vp
     L.lsh_tracer_hits.argtypes = [vp, u32p]
@@ -240,6 +241,10 @@ class HipTracer:
 
     def getGeometryId(self, name):
         return self.L.lsh_tracer_geometry_id(self.h, name.encode())
+
+    def getGeometryType(self, name):
+        """RTCGeometryType value, or -1000 - the TraceException's code for an unknown name (8)"""
+        return self.L.lsh_tracer_geometry_type(self.h, name.encode())
 
     def getTraceCloud(self):
         out = (C.c_uint32 * 4)()

@@ -233,6 +233,27 @@ def ray_dirs(sensor: Sensor) -> np.ndarray:
     return d
 
 
+RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("direction", "<f4", 3), ("tmax", "<f4")])   # Ray.hpp:16-35
+HIT_DTYPE = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("intensity", "<f4"), ("ring", "<i4")])       # Hit.hpp:16-29
+
+
+def all_rays_aos(sensor: Sensor):
+    """LidarDevice::allRaysGPU's two buffers (LidarDeviceKernels.cu:38-51), ray index v*H + h: Ray{origin = 0,
+    direction = the table direction} and Hit{t = 1e16, intensity = 64.0, ring = v}.  The reference's kernel leaves
+    tmin / tmax / normal as it finds them; they are restated as its OptiX programs use them (tmin 0, tmax 1e16,
+    OptixTracerModules.cu:45-46) and as zeros.  Directions are the CPU path's (libm tables, LidarDevice.cpp:306-316): the
+    parity target is the Embree backend, not CUDA's sinf/cosf."""
+    n = sensor.total_rays
+    rays = np.zeros(n, RAY_DTYPE)
+    rays["direction"] = ray_dirs(sensor)
+    rays["tmax"] = np.float32(1e16)
+    hits = np.zeros(n, HIT_DTYPE)
+    hits["t"] = np.float32(1e16)
+    hits["intensity"] = np.float32(64.0)
+    hits["ring"] = np.repeat(np.arange(sensor.V, dtype=np.int32), sensor.H)
+    return rays, hits
+
+
 def affine_from_components(lin, ang) -> np.ndarray:
     lin = np.ascontiguousarray(lin, np.float32)
     ang = np.ascontiguousarray(ang, np.float32)

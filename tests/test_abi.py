@@ -7,8 +7,8 @@ import re
 from conftest import ROOT
 
 
-def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "lidarshooter_hip.h")).read()
+def _declared_symbols(header="lidarshooter_hip.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(ls_[a-z0-9_]+)\s*\(", hdr)))
 
@@ -22,8 +22,27 @@ def test_header_symbols_are_exported(capi):
         assert hasattr(lib, s), f"{s} is declared in the header but not exported"
 
 
+def test_debug_header_symbols_are_exported(capi):
+    # include/lidarshooter_hip_debug.h: the test / measurement hooks live apart from the drop-in surface
+    syms = _declared_symbols("lidarshooter_hip_debug.h")
+    assert sorted(capi.DEBUG_SYMBOLS) == syms
+    assert not [s for s in _declared_symbols() if s.startswith("ls_debug_")]
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), s
+
+
 def test_abi_version(capi):
-    assert capi.load().ls_abi_version() == 2
+    assert capi.load().ls_abi_version() == 3
+
+
+def test_shipped_library_reads_no_tuning_knobs_from_the_environment():
+    # experiment knobs go through lsi::tune_int (ls_tuning.h), which only reads the environment in an EXPERIMENTAL build
+    src = os.path.join(ROOT, "lidarshooter_amd", "csrc")
+    for fn in os.listdir(src):
+        if fn.endswith((".cpp", ".hip", ".h")) and fn != "ls_tuning.h":
+            assert "getenv" not in open(os.path.join(src, fn)).read(), fn
+    assert "LS_EXPERIMENTAL" in open(os.path.join(src, "ls_tuning.h")).read()
 
 
 def test_struct_sizes(capi):

@@ -164,9 +164,10 @@ def test_adapter_second_sensor_and_moving_mesh(adapterapi, oracle, sensors, mesh
 
 @pytest.mark.gpu
 def test_adapter_mesh_policies(adapterapi, oracle, sensors, meshes):
-    """UploadAlways (default) sees an in-place edit of the cloud (MeshProjector.cpp:306-307) with the same header;
-    SkipUnchanged turns a repeated cloud into a transform-only update and still sees an edit that touches the
-    header sequence number or the probed vertices."""
+    """UploadAlways (default) sees an in-place edit of the cloud (MeshProjector.cpp:306-307) with the same header.
+    SkipUnchanged is a contract: the same buffer, size, header.seq and header.stamp stand for the same vertices -> a
+    transform-only update; an edit is announced by the header or by invalidateMesh(), and the tracer does not sample the
+    data to second-guess it (an unannounced in-place edit is, by contract, not looked at)."""
     s = sensors["0000"]
     gv, gt = meshes["ground"]
     tr = adapterapi.AdapterTracer(CFG["0000"])
@@ -189,16 +190,48 @@ def test_adapter_mesh_policies(adapterapi, oracle, sensors, meshes):
     assert tr.uploadCounts() == (2, 0)
     # ---- SkipUnchanged
     tr.setSkipUnchanged(True)
-    assert np.array_equal(frame(2), want1)                      # first keyed frame records the key: still an upload
+    assert np.array_equal(frame(2), want1)                      # same buffer and header as the upload of frame 1
     assert np.array_equal(frame(3), want1)
-    assert tr.uploadCounts() == (3, 1)
+    assert tr.uploadCounts() == (2, 2)
     tr.setDisplacement("mesh", (0.5, 0.25, -0.125), (0.0, 0.0, 0.3))   # pose-only change: no vertex traffic
     A = oracle.affine_from_components(np.array((0.5, 0.25, -0.125), np.float32), np.array((0.0, 0.0, 0.3), np.float32))
     assert np.array_equal(frame(4), oracle.trace_frame(s, [(0, lifted, gt, A)])["points"])
-    assert tr.uploadCounts() == (3, 2)
+    assert tr.uploadCounts() == (2, 3)
     tr.setVertices("mesh", gv, seq=7)                           # a new mesh message: header.seq differs -> upload
-    assert np.array_equal(frame(5), oracle.trace_frame(s, [(0, gv, gt, A)])["points"])
-    assert tr.uploadCounts() == (4, 2)
+    want_gv = oracle.trace_frame(s, [(0, gv, gt, A)])["points"]
+    assert np.array_equal(frame(5), want_gv)
+    assert tr.uploadCounts() == (3, 3)
+    # an in-place edit that leaves the header alone is announced with invalidateMesh (the one line a maintainer adds
+    # to MeshProjector::affineMeshCallback); until then the contract says "same vertices"
+    tr.setVertices("mesh", lifted, seq=7)
+    assert np.array_equal(frame(6), want_gv) and tr.uploadCounts() == (3, 4)
+    tr.invalidateMesh("mesh")
+    assert np.array_equal(frame(7), oracle.trace_frame(s, [(0, lifted, gt, A)])["points"])
+    assert tr.uploadCounts() == (4, 4)
+    tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_per_name_getters(adapterapi, meshes):
+    """EmbreeTracer's getters through the adapter, with the reference's behaviour for unknown names: getGeometryId
+    returns -1 (EmbreeTracer.cpp:82-89), getVertexCount / getElementCount / getGeometryType throw TraceException codes
+    1 / 4 / 8 (:369-379, :405-415, :103-113); test/EmbreeTracer_test.cpp:99-120."""
+    gv, gt = meshes["ground"]
+    tr = adapterapi.AdapterTracer(CFG["0000"])
+    tr.meshFromArrays("mesh", gv, gt)
+    quads = np.array([[0, 1, 2, 3]], np.uint32)
+    tr.meshFromArrays("plate", gv[:4], quads)
+    assert tr.addGeometry("mesh") == 0 and tr.addGeometry("plate", 1) == 1
+    assert tr.getter("id", "mesh") == 0 and tr.getter("id", "plate") == 1          # AddGeometryId
+    assert tr.getter("type", "mesh") == 0 and tr.getter("type", "plate") == 1      # GeometryType: RTC_GEOMETRY_TYPE_TRIANGLE / QUAD
+    assert tr.getter("vertices", "mesh") == 98 and tr.getter("elements", "mesh") == 162
+    assert tr.getter("vertices", "plate") == 4 and tr.getter("elements", "plate") == 1
+    assert tr.getter("id", "nope") == -1
+    assert tr.getter("vertices", "nope") == -1001
+    assert tr.getter("elements", "nope") == -1004
+    assert tr.getter("type", "nope") == -1008
+    assert tr.removeGeometry("mesh") == 0                                          # DeleteGeometryId
+    assert tr.getter("id", "mesh") == -1 and tr.getter("type", "mesh") == -1008
     tr.close()
 
 

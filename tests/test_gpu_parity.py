@@ -80,8 +80,12 @@ def test_geometry_bookkeeping(capi, sensors, meshes):
     assert tr.getGeometryCount() == 1
     assert tr.getVertexCount("mesh") == 98 and tr.getElementCount("mesh") == 162
     assert tr.getGeometryId("mesh") == gid
+    assert tr.getGeometryType("mesh") == capi.LS_GEOMETRY_TYPE_TRIANGLE        # EmbreeTracer_test.cpp:116-120
     g2 = _add(tr, "face", meshes["ben"])
     assert g2 == gid + 1 and tr.getGeometryCount() == 2
+    assert tr.addGeometry("plate", 4, 1, geometry_type=capi.LS_GEOMETRY_TYPE_QUAD) == 2
+    assert tr.getGeometryType("plate") == capi.LS_GEOMETRY_TYPE_QUAD and tr.removeGeometry("plate") == 2
+    assert tr.getGeometryType("plate") < 0 and tr.getGeometryType("nope") < 0  # EmbreeTracer.cpp:103-113 throws code 8 there
     assert tr.addGeometry("face", 3, 1) < 0                                   # duplicate key
     assert tr.addGeometry("grid", 4, 1, geometry_type=2) < 0                  # unsupported type (RTC_GEOMETRY_TYPE_GRID)
     assert tr.removeGeometry("mesh") == gid
@@ -270,6 +274,41 @@ def test_raygen_kernel(oracle, capi, sensors):
     tr.close()
 
 
+@pytest.mark.parametrize("shard", [None, (37, 50)])
+def test_raygen_kernel_reference_buffers(oracle, capi, sensors, shard):
+    """allRaysGPUKernel's two outputs in the reference's own layout (LidarDeviceKernels.cu:38-51, Ray.hpp:16-35,
+    Hit.hpp:16-29): Ray{origin 0, direction} 32 B and Hit{t = 1e16, intensity = 64, ring = channel} 24 B per ray,
+    against the oracle's restatement; also one output at a time, and an azimuth shard (shard-compact order)."""
+    import torch
+    s = sensors["0001"]
+    tr = make_tracer(capi, s)
+    if shard:
+        tr.setShard(*shard)
+    n = tr.getTotalRays()
+    want_r, want_h = oracle.all_rays_aos(s)
+    if shard:
+        keep = (np.arange(s.V)[:, None] * s.H + shard[0] + np.arange(shard[1])[None, :]).reshape(-1)
+        want_r, want_h = want_r[keep], want_h[keep]
+    assert n == want_r.shape[0]
+    rays = torch.full((n * 32,), 0xAB, dtype=torch.uint8, device="cuda:0")
+    hits = torch.full((n * 24,), 0xAB, dtype=torch.uint8, device="cuda:0")
+    tr.generateRaysAos(rays.data_ptr(), hits.data_ptr())
+    tr.synchronize()
+    got_r = rays.cpu().numpy().view(capi.RAY_DTYPE)
+    got_h = hits.cpu().numpy().view(capi.REFHIT_DTYPE)
+    assert got_r.tobytes() == want_r.tobytes() and got_h.tobytes() == want_h.tobytes()
+    assert np.all(got_h["ring"] == np.repeat(np.arange(s.V), n // s.V)) and np.all(got_h["intensity"] == 64.0)
+    rays.fill_(0)
+    hits.fill_(0)
+    tr.generateRaysAos(rays.data_ptr(), None)
+    tr.generateRaysAos(None, hits.data_ptr())
+    tr.synchronize()
+    assert rays.cpu().numpy().tobytes() == want_r.tobytes() and hits.cpu().numpy().tobytes() == want_h.tobytes()
+    with pytest.raises(capi.LidarShooterHipError):
+        tr.generateRaysAos(None, None)
+    tr.close()
+
+
 def test_shards_union_equals_full(oracle, capi, sensors, meshes, engine):
     from lidarshooter_amd import synth
     s = sensors["0000"]
@@ -423,6 +462,45 @@ def test_many_geometries_one_frame(oracle, capi, sensors, engine):
             assert k == ref["points"].shape[0]
             assert np.array_equal(p.cpu().numpy()[:32 * k].reshape(k, 32), ref["points"])
             assert np.array_equal(h.cpu().numpy()[:16 * k].view(np.uint32).reshape(k, 4), ref["hits"])
+    tr.close()
+
+
+@pytest.mark.parametrize("leaf", [1, 8])
+def test_bvh_instanced_single_leaf_geometries(oracle, capi, sensors, leaf):
+    """Instanced BVH path (16 geometries or fewer) where geometries that are ONE leaf -- a lone triangle; with leaf
+    size 8 also a two-triangle quad and a 7-triangle soup -- do not come first in geomID order: a lane that leaves a
+    bigger hierarchy with an empty stack enters them as `cur = leaf`, and must test that leaf with ITS records and
+    transform, not the previous geometry's (at_entry was captured after the node branch)."""
+    rng = np.random.default_rng(101)
+    s = _syn_sensor(oracle, sensors, V=32, H=256)
+    tr = make_tracer(capi, s, "bvh")
+    tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
+    ml = []
+    big_v, big_t = _random_soup(rng, 400, 9.0)
+    # a wall of single triangles / small patches right around the sensor, so that most rays hit one of them
+    def near_tri(k):
+        a = 2.0 * np.pi * k / 5.0
+        c = np.array([3.0 * np.cos(a), 3.0 * np.sin(a), 0.0], np.float32)
+        v = (c + rng.normal(0, 1.6, (3, 3))).astype(np.float32)
+        return v, np.array([[0, 1, 2]], np.uint32)
+    quad_v = np.array([[2, -2, -1.5], [2, 2, -1.5], [2, 2, 1.5], [2, -2, 1.5]], np.float32)
+    quad_t = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    specs = [("big0", big_v, big_t), ("tri1", *near_tri(0)), ("tri2", *near_tri(1)), ("quad3", quad_v, quad_t),
+             ("soup4", *_random_soup(rng, 7, 4.0)), ("tri5", *near_tri(2)), ("big6", *_random_soup(rng, 120, 7.0)),
+             ("tri7", *near_tri(3))]
+    for g, (name, v, t) in enumerate(specs):
+        A = oracle.IDENTITY_AFFINE if g % 2 else oracle.affine_from_components(
+            rng.normal(0, 0.5, 3).astype(np.float32), rng.normal(0, 0.4, 3).astype(np.float32))
+        assert tr.addGeometry(name, v.shape[0], t.shape[0]) == g
+        tr.updateGeometry(name, A, v, t)
+        ml.append((g, v, t, A))
+    assert tr.commitScene() == 0
+    assert tr.info(capi.LS_INFO_BVH_INSTANCED) == 2
+    rc, pts, hits = tr.traceScene(0)
+    ref = _assert_parity(oracle, s, tr, ml, pts, hits)
+    geoms_hit = set(ref["hits"][:, 1].tolist())
+    assert {1, 2, 3, 5, 7} & geoms_hit, "the single-leaf geometries must actually be hit for the test to mean anything"
+    assert len(geoms_hit) >= 5
     tr.close()
 
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NEEDS an experimental build: the LS_PROJECT_* / LS_TRACE_* knobs are only read by a library built with -DLS_EXPERIMENTAL
+# (make -C lidarshooter_amd/csrc clean all EXPERIMENTAL=1, or tools/exp_build.sh + LS_LIB_PATH); the shipped library ignores them.
 # k_project ablation: LS_PROJECT_DEBUG stops the kernel after a phase (1 = vertex loads, 2 = stage 1,
 # 3 = stage 2 footprints); prints frame and kernel time for each.
 W=${W:-syn128x1m}

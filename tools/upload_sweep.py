@@ -1,4 +1,6 @@
-"""ls_update_geometry (8 MB of pcl::PointXYZ vertices) under the library's upload knobs; one process per setting."""
+"""ls_update_geometry (8 MB of pcl::PointXYZ vertices) under the library's upload knobs; one process per setting.
+LS_UPLOAD_MODE here selects LS_OPT_UPLOAD_MODE (an option of the handle); the chunk / run / thread knobs are read only
+by a library built with -DLS_EXPERIMENTAL (tools/exp_build.sh, then LS_LIB_PATH=build/exp/<name>/liblidarshooter_hip.so)."""
 import ctypes as C
 import json
 import os
@@ -17,6 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     padded[:, :3] = v
     tr = capi.Tracer(synth.syn_vertical(128), 0.0, 360.0, 4096, np.eye(3, dtype=np.float32).reshape(9), np.zeros(3, np.float32))
     tr.addGeometry("g", v.shape[0], t.shape[0])
+    tr.setOption(capi.LS_OPT_UPLOAD_MODE, int(os.environ.get("LS_UPLOAD_MODE", "1")))
     tr.updateGeometry("g", capi.IDENTITY_AFFINE, padded, t, stride=16)
     tr.synchronize()
     L, h = tr.L, tr.h
