@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import ctypes as C_  # noqa: E402
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -67,11 +69,15 @@ def parse_args():
     ap.add_argument("--no-cull", action="store_true", help="LS_OPT_BLOCK_CULL off")
     ap.add_argument("--classic-bvh", action="store_true", help="BVH engine: LS_OPT_BVH_INSTANCED off (one hierarchy in the sensor frame, refitted every frame)")
     ap.add_argument("--cull", action="store_true", help="LS_OPT_BLOCK_CULL on (default: the library's auto rule)")
-    ap.add_argument("--multi", default="interleaved", choices=["interleaved", "sharded"],
+    ap.add_argument("--multi", default="sharded", choices=["interleaved", "sharded"],
                     help="N > 1: which way of spreading the frame stream over the GPUs is reported as `value` (the other one is "
-                         "measured too and reported under also_measured): interleaved = whole frames per rank, no collective "
-                         "(weak scaling: K frames per rank); sharded = azimuth sectors of every frame + one all-gather of "
-                         "hit-record slots per frame (strong scaling: K frames in all)")
+                         "measured too and reported under also_measured): sharded (default, BASELINE.json's split) = azimuth "
+                         "sectors of every frame + one all-gather of hit-record slots per frame (strong scaling: K frames in "
+                         "all); interleaved = whole frames per rank, no collective (weak scaling: K frames per rank)")
+    ap.add_argument("--multi-driver", default="c", choices=["c", "torch"],
+                    help="sharded mode: c (default) = include/lidarshooter_group.h -- the frame loop, the RCCL all-gather and the "
+                         "rebuild of the cloud run in C, three frames in flight per rank; torch = torch.distributed issues the "
+                         "all-gather (two frames in flight; the path LS_BENCH_REHEARSAL rehearses over gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the ITracer-adapter (host buffers, PointCloud2) legs")
     ap.add_argument("--cpu-frames", type=int, default=6)
@@ -291,14 +297,24 @@ def main():
     if world == 1 or args.workload == "cfg5":
         out = measure(args, rank, world, device, dev_index, rehearsal, None)
     else:
-        # N > 1, one scene: two ways to spread a stream of frames over the GPUs, both measured, args.multi is `value`
+        # N > 1, one scene: two ways to spread a stream of frames over the GPUs, both measured, args.multi is `value`;
+        # the sharded split is measured on SYN-10M too (where a shard is work-bound), reported next to it
         other = "sharded" if args.multi == "interleaved" else "interleaved"
         out = measure(args, rank, world, device, dev_index, rehearsal, args.multi)
-        alt = measure(args, rank, world, device, dev_index, rehearsal, other)
+        keys = ("value", "unit", "ms_per_step", "frames_per_s", "scaling", "gathered_points_rank0", "host_enqueue_ms_per_step", "timing")
+
+        def brief(m):
+            b = {k: m.get(k) for k in keys}
+            b["workload"] = m["config"]["workload"]
+            b["parallelism"] = m["config"]["parallelism"]
+            return b
+        also = [brief(measure(args, rank, world, device, dev_index, rehearsal, other))]
+        if args.workload == "syn128x1m" and not rehearsal:
+            big = argparse.Namespace(**vars(args))
+            big.workload = "syn128x10m"
+            also.append(brief(measure(big, rank, world, device, dev_index, rehearsal, "sharded")))
         if rank == 0:
-            out["also_measured"] = {k: alt.get(k) for k in ("value", "unit", "ms_per_step", "frames_per_s", "scaling", "gathered_points_rank0",
-                                                             "host_enqueue_ms_per_step", "timing")}
-            out["also_measured"]["parallelism"] = alt["config"]["parallelism"]
+            out["also_measured"] = also
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -336,7 +352,10 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
     # a dedicated (non-default) stream shared by the tracer's kernels and, through torch, by RCCL's
     # stream dependencies: the all-gather of frame i is ordered after frame i's pack kernel
     stream = torch.cuda.Stream(device)
-    if world > 1 and not independent:   # no collective to order otherwise: the tracer keeps its own stream
+    # sharded frames through include/lidarshooter_group.h: frame loop, RCCL all-gather and cloud rebuild in C (RCCL does not
+    # take two ranks on one device: the gloo rehearsal on a one-GPU box goes through the torch driver)
+    cgroup = world > 1 and not independent and args.multi_driver == "c" and not rehearsal
+    if world > 1 and not independent and not cgroup:   # no collective to order otherwise: the tracer keeps its own stream
         tr.setStream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
 
@@ -362,6 +381,18 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
         count_words = out_bufs
         if pipeline:
             tr.setOption(capi.LS_OPT_PIPELINE, args.pipeline)
+    elif cgroup:
+        from lidarshooter_amd import groupapi
+        uid = torch.zeros(groupapi.ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            GL = groupapi.load()
+            idbuf = (C_.c_uint8 * groupapi.ID_BYTES)()
+            if GL.ls_group_unique_id(idbuf) != 0:
+                raise SystemExit("ls_group_unique_id failed (no RCCL?)")
+            uid = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=device)
+        dist.broadcast(uid, src=0)
+        grp = groupapi.Group(tr, world, rank, groupapi.SHARDED, bytes(uid.cpu().numpy().tobytes()))
+        count_words = None
     else:
         # N > 1: the travelling slot holds the count word and the 16-byte hit records only (shards.py);
         # two slots / two gather buffers alternate so that the all-gather of frame i overlaps frame i+1
@@ -440,6 +471,23 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
             if n > 0 and HL.lsh_stream_frames(h, sf_names, sf_aff, sf_n, len(fast_meshes), sf_p, sf_h, sf_c, 3, cap, first, n) < 0:
                 raise RuntimeError(tr.last_error())
 
+    if cgroup:
+        HL = hostapi.load()
+        HL.lsh_group_stream_frames.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(f32p), C.POINTER(C.c_uint), C.c_uint,
+                                               C.c_uint, C.c_uint]
+        gsf_names = (C.c_char_p * len(fast_meshes))(*[m[0] for m in fast_meshes])
+        gsf_aff = (f32p * len(fast_meshes))(*[C.cast(ident_c, f32p) for _ in fast_meshes])
+        gsf_n = (C.c_uint * len(fast_meshes))(*[1 for _ in fast_meshes])
+
+        def stream_frames(first, n):
+            if len(registered) < len(fast_meshes):      # the hand-over of the meshes happens once
+                for nm, pv, pt, _ in fast_meshes:
+                    if L.ls_update_geometry_device_shared(h, nm, C.cast(ident_c, f32p), pv, 12, pt) < 0:
+                        raise RuntimeError(tr.last_error())
+                    registered.add(nm)
+            if n > 0 and HL.lsh_group_stream_frames(grp.g, h, gsf_names, gsf_aff, gsf_n, len(fast_meshes), first, n) < 0:
+                raise RuntimeError(tr.last_error() + " / " + grp.L.ls_group_last_error(grp.g).decode())
+
     def update_and_trace(i, copy):
         if single and not copy:
             return fast_update_and_trace(i)
@@ -468,7 +516,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
     # launch of frame i+1) the slot of frame i is complete on the stream after call i+1, so its all-gather starts
     # one call later and has two frames of work to hide behind.  G(f) reads slot[f & 1], which the riders in the
     # launch of frame f+3 write again: G(f) is waited for (and its cloud rebuilt) at the start of frame f+3.
-    lagged = (not single) and engine == "projection" and not args.no_pipeline
+    lagged = (not single) and not cgroup and engine == "projection" and not args.no_pipeline
     if lagged:
         tr.setOption(capi.LS_OPT_PIPELINE, 1)
     state = {"prev": None}
@@ -480,6 +528,9 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
     def frame(i, copy=False):
         if single:
             update_and_trace(i, copy)
+            return
+        if cgroup:
+            stream_frames(i, 1)
             return
         b = i & 1
         if lagged:
@@ -497,7 +548,9 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
         start_gather(i)
 
     def flush():
-        if not single:
+        if cgroup:
+            grp.synchronize()
+        elif not single:
             if lagged:
                 tr.flush()                                 # the last frame's riders
                 if state["prev"] is not None:
@@ -523,7 +576,10 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
     n_node, n_tri, wave_trips, max_trips = tr.visitStats()
     tr.setOption(capi.LS_OPT_COUNT_VISITS, 0)
     shard_rays = tr.getTotalRays()
-    n_hits = int(count_words[0][:4].view(torch.int32).item())
+    if count_words is not None:
+        n_hits = int(count_words[0][:4].view(torch.int32).item())
+    else:   # C group: the slot's count word is the group's; the shard's dense result says how many of its rays hit
+        n_hits = int((tr.denseHits()[1] != 0xFFFFFFFF).sum())
     info = tr.sceneSize()
     n_tris_total = info["n_tris"]
 
@@ -691,17 +747,33 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
                  "wave_trips_mean": wave_trips / max(1, (shard_rays + 63) // 64), "wave_trips_max": max_trips}
     else:
         # k_project: every triangle is streamed once (12 B indices + 36 B vertex gather) and every hit folds 8 B into
-        # the per-ray key; the angle tables (V+H entries) stay on chip
+        # the per-ray key; the angle tables (V+H entries) stay on chip.  With group culling in effect
+        # (LS_OPT_BLOCK_CULL; the timed stage is then k_cull + k_project) the triangles of culled groups are never read:
+        # the bytes are the bounds k_cull reads (32 B per 256-triangle block, 32 B per group of 4 inside the blocks that
+        # survive), the survivor list (4 B written + 4 B read per surviving group) and 48 B per SURVIVING triangle
         kernel = "k_project"
-        b_launch = 48 * n_tris_total + 8 * n_hits
+        groups_alive, group_bounds_read = int(wave_trips), int(max_trips)
+        culled = groups_alive > 0
+        if culled:
+            n_blocks = sum(((t.shape[0] + 3) // 4 + 63) // 64 for _, _, t in meshes if t.shape[0] >= 524288)
+            tris_read = min(4 * groups_alive, n_tris_total) + sum(t.shape[0] for _, _, t in meshes if t.shape[0] < 524288)
+            b_launch = 32 * n_blocks + 32 * group_bounds_read + 8 * groups_alive + 48 * tris_read + 8 * n_hits
+            kernel = "k_cull + k_project"
+        else:
+            tris_read = n_tris_total
+            b_launch = 48 * n_tris_total + 8 * n_hits
         # the whole frame: + k_project_finish (8 B key read per ray) + k_pack (8 B key read + 8 B re-arm per ray,
         # 48 B point + hit record per hit)
         b_frame = b_launch + 24 * shard_rays + 48 * n_hits
-        units = {"triangles_per_launch": n_tris_total, "bytes_per_triangle": b_launch / max(1, n_tris_total),
+        units = {"triangles_per_launch": n_tris_total, "triangles_read_per_launch": tris_read,
+                 "bytes_per_triangle": b_launch / max(1, n_tris_total),
                  "candidate_tests_per_launch": n_tri, "tests_per_triangle": n_tri / max(1, n_tris_total),
-                 "rays_per_launch": shard_rays}
-        if wave_trips:
-            units["cull_groups_surviving"] = wave_trips     # LS_OPT_BLOCK_CULL in effect: groups of 4 triangles k_cull let through
+                 "rays_per_launch": shard_rays,
+                 "nominal_bytes_per_launch": 48 * n_tris_total + 8 * n_hits}
+        if culled:
+            units["cull"] = {"blocks_of_256": n_blocks, "group_bounds_read": group_bounds_read, "groups_surviving": groups_alive,
+                             "what": "bytes are priced on what the culled stage has to read: 32 B per block bound, 32 B per group bound "
+                                     "inside surviving blocks, 8 B per surviving group (list), 48 B per surviving triangle, 8 B per hit"}
     achieved = b_launch / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
     # HBM bytes of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB).  Counters cannot
     # be collected from inside this process, so the figure is the profiled one -- and only if the profile was taken
@@ -746,9 +818,13 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
                             + (("; two frames in flight (finish + pack of frame i ride in the launch of frame i+1)"
                                 if args.pipeline == 1 else "; three frames in flight (whole frames rotate over three streams)")
                                if pipeline else ""),
-                   "parallelism": f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
-                                  f"hit-record slots per frame (overlapped with the next "
-                                  f"{'two frames; two frames in flight per rank' if lagged else 'frame'}), cloud rebuilt on every rank"
+                   "parallelism": (f"azimuth-sector shards x{world}, scene replica per GPU, one ncclAllGather of hit-record slots per "
+                                   f"frame on a collective stream that waits for that frame alone, cloud rebuilt on every rank; three "
+                                   f"frames in flight per rank; frame loop, collective and rebuild in C (include/lidarshooter_group.h)"
+                                   if cgroup else
+                                   f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
+                                   f"hit-record slots per frame through torch.distributed (overlapped with the next "
+                                   f"{'two frames; two frames in flight per rank' if lagged else 'frame'}), cloud rebuilt on every rank")
                    if not single else ("single GPU" if world == 1 else
                                        (f"{world} independent replicas (one sensor pose per GPU), no collective" if replicas else
                                         f"frames interleaved over {world} GPUs: every rank traces the whole raster of its own frames "
@@ -762,7 +838,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         "hits_per_frame_rank0": n_hits,
         # N > 1: points of the whole frame as rebuilt from the gathered slots on rank 0 (= the 1-GPU hit count)
-        "gathered_points_rank0": None if single else int(cloud_n[0].item()),
+        "gathered_points_rank0": None if single else (int(grp.download(args.steps - 1)[0].shape[0]) if cgroup else int(cloud_n[0].item())),
         "rehearsal_gloo_shared_gpu": True if rehearsal else None,
         "roofline": dict({
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -791,6 +867,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi):
         out["trace_only_mrays_per_s"] = shard_rays / trace_only_s / 1e6
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not replicas:
         out["cpu_baseline"] = cpu_baseline(sensor, meshes, args.cpu_frames, total_rays)
+    if cgroup:
+        grp.close()
     tr.close()
     args.pipeline = pipeline_arg
     torch.cuda.set_stream(torch.cuda.default_stream(device))

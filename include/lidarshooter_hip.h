@@ -236,6 +236,16 @@ int ls_tracer_set_stream(ls_tracer *tr, void *hip_stream);
 int ls_tracer_synchronize(ls_tracer *tr);
 /* LS_OPT_PIPELINE: order the handle's stream after every frame still in flight (no host wait). */
 int ls_tracer_flush(ls_tracer *tr);
+/* Finer than a flush, for a consumer that works on frames one by one while later frames are already in flight (the
+ * collective stream of include/lidarshooter_group.h):
+ *   ls_tracer_order_after_last_frame  orders hip_stream (a hipStream_t) after the frame issued last -- its points, hit
+ *       records and count are complete for work enqueued on hip_stream afterwards -- and after nothing else: with
+ *       three frames in flight the two other frames keep running.
+ *   ls_tracer_wait_event  makes everything the handle does from now on (its next frames included, whatever stream
+ *       carries them) start after hip_event (a hipEvent_t) has completed -- e.g. the event behind the last reader of an
+ *       output buffer that the next frame writes again. */
+int ls_tracer_order_after_last_frame(ls_tracer *tr, void *hip_stream);
+int ls_tracer_wait_event(ls_tracer *tr, void *hip_event);
 
 /* Write packed points / hit records into caller-owned device buffers (capacity in records,
  * >= ls_total_rays of the shard) instead of the handle's own; NULL restores the default. */

@@ -38,7 +38,7 @@ SYMBOLS = (
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
     "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
-    "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type",
+    "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type", "ls_tracer_order_after_last_frame", "ls_tracer_wait_event",
 )
 # include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
 DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",
@@ -139,6 +139,8 @@ def load() -> C.CDLL:
     L.ls_expand_gathered_hits_on.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
     L.ls_cloud_to_world.argtypes = [vp, f32p, f32p, vp, vp, vp, vp, vp, u32]
     L.ls_tracer_flush.argtypes = [vp]
+    L.ls_tracer_order_after_last_frame.argtypes = [vp, vp]
+    L.ls_tracer_wait_event.argtypes = [vp, vp]
     L.ls_tracer_set_option.argtypes = [vp, i32, i32]
     L.ls_get_timings.argtypes = [vp, f32p]
     L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -314,6 +316,10 @@ class Tracer:
         return self._check(self.L.ls_expand_gathered_hits(self.h, d_gathered, world, capacity, d_points, d_hits, d_n),
                            "ls_expand_gathered_hits")
 
+    def expandGatheredHitsOn(self, stream_ptr: int, d_gathered: int, world: int, capacity: int, d_points: int, d_hits: int, d_n: int):
+        self._check(self.L.ls_expand_gathered_hits_on(self.h, stream_ptr, d_gathered, world, capacity, d_points, d_hits, d_n),
+                    "ls_expand_gathered_hits_on")
+
     def cloudToWorld(self, R, d_points_in: int, d_n_points: int, d_points_out: int, out_capacity: int, affine=None,
                      d_out_base: int | None = None, d_out_total: int | None = None):
         """ls_cloud_to_world: sensor-frame points (device) -> world frame, appended at *d_out_base."""
@@ -325,6 +331,12 @@ class Tracer:
 
     def info(self, what: int) -> int:
         return int(self._check(self.L.ls_get_info(self.h, what), "ls_get_info"))
+
+    def orderAfterLastFrame(self, stream_ptr: int):
+        self._check(self.L.ls_tracer_order_after_last_frame(self.h, stream_ptr), "ls_tracer_order_after_last_frame")
+
+    def waitEvent(self, event_ptr: int):
+        self._check(self.L.ls_tracer_wait_event(self.h, event_ptr), "ls_tracer_wait_event")
 
     def flush(self):
         return self._check(self.L.ls_tracer_flush(self.h), "ls_tracer_flush")

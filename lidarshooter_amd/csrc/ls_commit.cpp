@@ -50,10 +50,10 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
     int rc;
     if ((rc = flush_pipeline(tr))) return rc;
     ++tr->main_epoch;
-    const uint32_t nt = g.n_tris, ngroups = (nt + ls::kCullGroup - 1u) / ls::kCullGroup;
+    const uint32_t nt = g.n_tris;
     if (!g.d_perm) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_perm), (size_t)nt * 4));
     if (!g.d_idx_sorted) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx_sorted), (size_t)nt * 12));
-    if (!g.d_boxes) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_boxes), (size_t)ngroups * 32));
+    if (!g.d_boxes) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_boxes), ls::project_box_entries(nt) * 32));   // group bounds, then block bounds
     if (g.order_stale) {
         if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
         if ((rc = ensure(tr, tr->keys_b, nt))) return rc;

@@ -52,6 +52,7 @@ constexpr int kSets = 3;
 
 struct ls_group {
     uint32_t world = 1, rank = 0, full_turn = 0;
+    long pipeline_before = 0;   // the tracer's LS_OPT_PIPELINE as the group found it
     int mode = LS_GROUP_SHARDED;
     ls_tracer *tr = nullptr;
     ncclComm_t comm = nullptr;
@@ -146,6 +147,7 @@ void ls_group_destroy(ls_group *g)
     if (g->tr) {
         (void)ls_tracer_synchronize(g->tr);
         (void)ls_tracer_set_output_buffers(g->tr, nullptr, nullptr, nullptr, 0);
+        (void)ls_tracer_set_option(g->tr, LS_OPT_PIPELINE, (int)g->pipeline_before);
         (void)ls_tracer_set_stream(g->tr, nullptr);   // back on its own stream before the group's streams go
         if (g->full_turn) (void)ls_tracer_set_shard(g->tr, 0, g->full_turn);
     }
@@ -225,7 +227,12 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
     // ---- nothing but the tracer itself can fail from here on
     g->tr = tr;
     attached = true;
+    g->pipeline_before = std::max(0l, ls_get_info(tr, LS_INFO_PIPELINE_MODE));
     if (ls_tracer_set_stream(tr, g->trace_stream) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
+    // three frames in flight per rank (the library falls back to two on one stream when the device does not give it
+    // three concurrent streams): the gather + rebuild of frame f overlap the tracing of f+1 and f+2, per frame the
+    // collective stream waits for that frame alone (ls_tracer_order_after_last_frame), never for the tracer as a whole
+    if (ls_tracer_set_option(tr, LS_OPT_PIPELINE, 2) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
     if (ls_tracer_set_shard(tr, first, n) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_INVALID_ARGUMENT); }
     *out = g;
     return LS_OK;
@@ -253,16 +260,19 @@ int ls_group_trace(ls_group *g, uint32_t frame_index)
         return rc == -1 ? -1 : 0;
     }
     // the set's previous frame (three frames ago) must have left its slot: the gather reads it on the other stream
-    if (g->used[b]) LSG_HIP(hipStreamWaitEvent(g->trace_stream, g->ev_collected[b], 0));
+    if (g->used[b] && ls_tracer_wait_event(g->tr, g->ev_collected[b]) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
     if (ls_tracer_set_output_buffers(g->tr, g->local_points, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]),
                                      g->capacity) != LS_OK)
         return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
     const int rc = ls_trace_scene_async(g->tr, frame_index, &f);
     if (rc < -1) return fail(g, rc, ls_last_error(g->tr));
-    if (rc == -1) LSG_HIP(hipMemsetAsync(g->slot[b], 0, 4, g->trace_stream));   // empty scene: an empty slot travels
-    if (ls_tracer_flush(g->tr) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));   // frames-in-flight modes: the slot is complete on the stream
-    LSG_HIP(hipEventRecord(g->ev_traced[b], g->trace_stream));
-    LSG_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_traced[b], 0));
+    if (rc == -1) {   // empty scene: nothing was traced, an empty slot travels
+        LSG_HIP(hipMemsetAsync(g->slot[b], 0, 4, g->trace_stream));
+        LSG_HIP(hipEventRecord(g->ev_traced[b], g->trace_stream));
+        LSG_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_traced[b], 0));
+    } else if (ls_tracer_order_after_last_frame(g->tr, g->comm_stream) != LS_OK) {   // this frame's slot is complete for the gather; frames in flight go on
+        return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
+    }
     // the frame's one collective: every rank's slot to every rank (xGMI is fully connected: direct peer writes)
     LSG_NCCL(rccl().AllGather(g->slot[b], g->gathered[b], g->slot_bytes, ncclUint8, g->comm, g->comm_stream));
     if (ls_expand_gathered_hits_on(g->tr, g->comm_stream, g->gathered[b], g->world, g->capacity, g->cloud_points[b], g->cloud_hits[b],

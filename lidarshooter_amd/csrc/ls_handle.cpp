@@ -13,10 +13,10 @@ namespace {
 
 // LidarDevice.cpp:306-316 on the host: the V+H distinct angles of a revolution go through libm
 // (sinf/cosf, exactly like the reference's CPU path); the kernels only multiply table entries.
-void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
+void fill_tables(ls_tracer *tr, std::vector<float> &tab)
 {
     const uint32_t V = tr->V, H = tr->H;
-    tab.resize(2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V + 2 * (size_t)H + (size_t)V);
+    tab.resize(2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V + 2 * (size_t)H + (size_t)V + ls::kCullLutBuckets / 2);
     const float step = tr->h_step;  // LidarDevice.cpp:611
     if (!tr->given_tables.empty()) {
         // ls_tracer_create_tables: the caller's factor tables, bit for bit
@@ -60,6 +60,33 @@ void fill_tables(const ls_tracer *tr, std::vector<float> &tab)
     for (uint32_t i = 0; i < V; ++i) {
         const uint32_t pos = i;
         std::memcpy(&rank[perm[i]], &pos, 4);
+    }
+    // k_cull's look-up table over tan(elevation): bucket b starts at t0 + b / scale; lut[b] = first position whose
+    // tan_up is at or above the bucket's start.  Usable when every two consecutive buckets hold at most two channels
+    // (the kernel starts one bucket early and steps at most twice); the last bucket reaches to +infinity.
+    uint16_t *lut = reinterpret_cast<uint16_t *>(rank + V);
+    tr->lut_ok = false;
+    tr->lut_t0 = tr->lut_scale = 0.0f;
+    const uint32_t nb = ls::kCullLutBuckets;
+    const float first = up[0], last = up[V - 1];
+    if (V <= 65535u && std::isfinite(first) && std::isfinite(last) && last > first) {
+        const double t0 = first, width = ((double)last - (double)first) * (1.0 + 1e-6) / (double)(nb - 1);   // `last` falls into bucket nb - 2 or nb - 1
+        const float scale = (float)(1.0 / width);
+        std::vector<uint32_t> start(nb + 1);
+        uint32_t i = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            // the bucket start as the kernel's arithmetic sees it: x = (v - t0) * scale lands in bucket b for v >= s_b
+            const double s_b = t0 + (double)b * width;
+            while (i < V && (double)up[i] < s_b) ++i;
+            start[b] = i;
+            lut[b] = (uint16_t)i;
+        }
+        start[nb] = V;
+        bool ok = true;
+        for (uint32_t b = 0; b < nb && ok; ++b) ok = start[std::min(b + 2u, nb)] - start[b] <= 2u;
+        tr->lut_ok = ok;
+        tr->lut_t0 = first;
+        tr->lut_scale = scale;
     }
 }
 
@@ -186,6 +213,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->d_n_points_b) (void)hipFree(tr->d_n_points_b);
     if (tr->d_n_points_c) (void)hipFree(tr->d_n_points_c);
     if (tr->ev_main) (void)hipEventDestroy(tr->ev_main);
+    if (tr->ev_frame) (void)hipEventDestroy(tr->ev_frame);
     for (int i = 0; i < 3; ++i) {
         if (tr->ev_done[i]) (void)hipEventDestroy(tr->ev_done[i]);
         bool dup = false;

@@ -81,7 +81,9 @@ struct ls_tracer {
     std::vector<float> given_tables;   // ls_tracer_create_tables: sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H] as handed over
     uint32_t V = 0, H = 0;
     float rinv[9], t[3];
-    float *d_tables = nullptr;  // sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H]
+    float *d_tables = nullptr;  // sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H] ... (fill_tables)
+    float lut_t0 = 0.0f, lut_scale = 0.0f;   // k_cull's channel look-up table (ProjectParams::chan_lut)
+    bool lut_ok = false;
     uint32_t az0 = 0, naz = 0;
 
     // geometry registry
@@ -131,6 +133,7 @@ struct ls_tracer {
     // the buffers above, slot 2 the ones below; every slot has its own block-count array
     hipStream_t slot_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_main = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_frame = nullptr;          // ls_tracer_order_after_last_frame on the handle's stream
     bool slot_pending[3] = {false, false, false};   // frames issued on slot_stream[s] since the last flush
     // the library enqueues mesh copies on the handle's stream; a slot stream whose epoch is behind orders itself
     // after that stream before its next frame (every slot, not only the first frame after the copy)

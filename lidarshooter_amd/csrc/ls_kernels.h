@@ -86,6 +86,13 @@ struct ProjectParams {
     const float *chan_tan_dn;      // [V] tan(elevation - margin), same order
     const uint32_t *chan_perm;     // [V] position in that order -> channel index
     const uint32_t *chan_rank;     // [V] channel index -> position in that order (inverse of chan_perm)
+    // k_cull's channel query as a table look-up: chan_lut[b] = first position i with chan_tan_up[i] >= lut_t0 + b / lut_scale,
+    // kCullLutBuckets entries; lut_ok = the host verified that no two consecutive buckets hold more than two channels, so
+    // that a look-up (started one bucket early for rounding) and two compare-and-step reach the first channel at or
+    // above any value.  Sensors that fail the check use the binary search.
+    const uint16_t *chan_lut;
+    float lut_t0, lut_scale;
+    int lut_ok;
     float begin_deg, step_deg;     // azimuth of column h = begin + step*h (LidarDevice.cpp:306)
     float inv_step_deg, inv_period; // 1/step and |step|/360 (0 when step is 0)
     float margin_deg;              // angular slack of the footprint bounds
@@ -119,19 +126,29 @@ struct GeomBatch {
     uint32_t n;
     uint32_t block_first[kGeomsPerLaunch + 1];   // first workgroup of geometry i; [n] = grid size
     uint32_t tris_per_wave[kGeomsPerLaunch];     // 64, or less for a small mesh
-    uint32_t list_first[kGeomsPerLaunch + 1];    // group culling: first entry of geometry i in the survivor list (multiples of 256)
+    uint32_t list_first[kGeomsPerLaunch + 1];    // group culling: first entry of geometry i in the survivor list
+    uint32_t cull_first[kGeomsPerLaunch + 1];    // group culling: first k_cull workgroup of geometry i; [n] = k_cull's grid
+    uint32_t seg_cap[kGeomsPerLaunch];           // group culling: entries of each of geometry i's kCullSegs list segments
+    uint32_t cull_rounds;                        // group culling: k_cull's groups per workgroup / 256
     GeomSource g[kGeomsPerLaunch];
 };
 
-// group culling (ls_project.hip): sorted triangles are bounded and culled in groups of kCullGroup; the per-geometry
-// survivor counts of a frame live at words [kCullCountAt, kCullCountAt + kGeomsPerLaunch) of its counter slot, whose
-// word 0 is the length of the big-footprint queue; a slot is kCounterSlotWords words
+// group culling (ls_project.hip): sorted triangles are bounded and culled in groups of kCullGroup, and those in blocks
+// of kCullBlockGroups groups (a coarse bound, tested first).  A geometry's survivors are collected in kCullSegs list
+// segments, each with a counter of its own on its own 64-byte line: one hot address sustains ~90 atomics per
+// microsecond on MI355X, and the 2 441 workgroups of k_cull at 10 M triangles spent 27 of their 36 us queueing on a
+// single counter.  A frame's counter slot: word 0 = length of the big-footprint queue; counter (i, s) of geometry i,
+// segment s at word kCullCountAt + (i * kCullSegs + s) * 16.
 #ifndef LS_CULL_GROUP
 #define LS_CULL_GROUP 4
 #endif
 constexpr uint32_t kCullGroup = LS_CULL_GROUP;
+constexpr uint32_t kCullBlockGroups = 64;
+constexpr uint32_t kCullSegs = 32;
+constexpr uint32_t kCullLutBuckets = 2048;
 constexpr uint32_t kCullCountAt = 16;
-constexpr uint32_t kCounterSlotWords = 32;
+constexpr uint32_t kCullCounters = kGeomsPerLaunch * kCullSegs;
+constexpr uint32_t kCounterSlotWords = kCullCountAt + kCullCounters * 16;
 static_assert(64 % LS_CULL_GROUP == 0, "a wave takes a whole number of groups");
 
 // ---- build ---------------------------------------------------------------------------------
@@ -233,8 +250,10 @@ uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs);   // sur
 void launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,
                        uint32_t *aabb6, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, void *sort_temp, size_t sort_temp_bytes,
                        uint32_t *perm, uint32_t *idx_sorted);
-// per vertex upload: mesh-space sheared-box bound of every kCullGroup sorted triangles (2 float4 per group)
+// per vertex upload: mesh-space sheared-box bound of every kCullGroup sorted triangles (2 float4 per group), followed
+// in the same array by the bound of every kCullBlockGroups groups (project_box_entries() float4 pairs in all)
 void launch_group_bounds(hipStream_t s, const uint8_t *verts, uint32_t stride, const uint32_t *idx_sorted, uint32_t ntris, float4 *boxes);
+size_t project_box_entries(uint32_t ntris);
 void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats);
 // per ray: gather the queued big-footprint triangles, then hits per 256-ray block
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,

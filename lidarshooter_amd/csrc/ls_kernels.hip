@@ -761,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         }
         if (threadIdx.x == 0) next_block_counts[blockIdx.x] = 0u;
         if (q == 0) big_count[0] = 0u;                                             // queue length
-        if (q < (uint32_t)kGeomsPerLaunch) big_count[kCullCountAt + q] = 0u;        // group-cull survivor counts
+        if (q < kCullCounters) big_count[kCullCountAt + q * 16u] = 0u;             // group-cull survivor counts (one per list segment)
     }
     const bool hit = gid != kInvalid;
     const unsigned long long m = __ballot(hit);

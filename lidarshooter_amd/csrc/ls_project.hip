@@ -19,6 +19,7 @@
 // rtcIntersect16 over the committed scene (EmbreeTracer.cpp:297-367, :472-480) / optixLaunch
 // (OptixTracer.cpp:317-328, OptixTracerModules.cu:26-86).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <hip/hip_ext.h>
 #include <cstdio>
@@ -315,14 +316,17 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         while (gi + 1u < batch.n && block_idx >= batch.block_first[gi + 1u]) ++gi;
     const GeomSource &src = batch.g[gi];
     const uint32_t block = MULTI ? block_idx - batch.block_first[gi] : block_idx;
-    // CULLED: the groups of kCullGroup sorted triangles that survived k_cull sit packed at the front of this geometry's
-    // part of cull_list (count in big_count[kCullCountAt + gi]); a wave takes 64 / kCullGroup of them, so its lanes
-    // are dense; workgroups behind the survivors have nothing to do
+    // CULLED: the groups of kCullGroup sorted triangles that survived k_cull sit in kCullSegs segments of this
+    // geometry's part of cull_list, each packed to its front (count in the segment's counter); workgroup b of the
+    // geometry works on segment b % kCullSegs, position b / kCullSegs; a wave takes 64 / kCullGroup survivors, so its
+    // lanes are dense; workgroups behind a segment's survivors have nothing to do
     constexpr uint32_t kPerWave = 64u / kCullGroup;
-    uint32_t n_live = 0;
+    uint32_t n_live = 0, seg = 0, seg_block = 0;
     if (CULLED) {
-        n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)big_count[kCullCountAt + gi]);
-        if (block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
+        seg = block % kCullSegs;
+        seg_block = block / kCullSegs;
+        n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)big_count[kCullCountAt + (gi * kCullSegs + seg) * 16u]);
+        if (seg_block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
     }
     // ---- which triangle this lane takes, and its loads, BEFORE the channel tables are staged: index load -> vertex
     //      gather is a chain of two memory round trips, the staging (global -> LDS, then a workgroup barrier) a third
@@ -331,15 +335,16 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     uint32_t k = 0xFFFFFFFFu;
     bool live_wave = true;
     if (CULLED) {
-        const uint32_t rank = block * (kBlock / 64) + w;   // this wave among the geometry's waves
+        const uint32_t rank = seg_block * (kBlock / 64) + w;   // this wave among the segment's waves
         if (COUNT && rank == 0 && lane == 0) atomicAdd(&stats[1], (unsigned long long)n_live);   // counts[2]: surviving groups
         live_wave = rank * kPerWave < n_live;              // the survivors' last workgroup is partly filled
-        // a wave's groups are taken at a stride of the number of live waves: the survivors list is in mesh order, and the
-        // cells a group expands to vary by orders of magnitude with its distance from the sensor -- consecutive groups
+        // a wave's groups are taken at a stride of the number of live waves: a segment's list follows the mesh order, and
+        // the cells a group expands to vary by orders of magnitude with its distance from the sensor -- consecutive groups
         // would make a few waves next to the sensor walk ten times the cells of the others (and the kernel wait for them)
         const uint32_t live_waves = (n_live + kPerWave - 1u) / kPerWave;
         const uint32_t e = pp.spread ? (lane / kCullGroup) * live_waves + rank : rank * kPerWave + lane / kCullGroup;
-        if (live_wave && e < n_live) k = cull_list[batch.list_first[gi] + e] * kCullGroup + (lane % kCullGroup);
+        if (live_wave && e < n_live)
+            k = cull_list[batch.list_first[gi] + seg * batch.seg_cap[gi] + e] * kCullGroup + (lane % kCullGroup);
     } else {
         // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
         // join the cell tests): its footprints are large, and the cells are what takes the time
@@ -597,186 +602,311 @@ __global__ __launch_bounds__(kBlock) void k_permute_indices(const uint32_t *__re
     out[3 * (size_t)k + 2] = idx[3 * (size_t)t + 2];
 }
 
-// one lane per group of kCullGroup sorted triangles: bounds[2g] = (cx, cy, cz, hx), bounds[2g+1] = (hy, hz, sx, sy)
-__global__ __launch_bounds__(kBlock) void k_group_bounds(const uint8_t *__restrict__ verts, uint32_t stride,
-                                                         const uint32_t *__restrict__ idx_sorted, uint32_t ntris, float4 *__restrict__ bounds)
+// A sheared box from running sums: lo / hi = the axis-aligned extent, s** = second moments about its centre (cx, cy, cz);
+// returns the slopes of the least-squares plane z = cz + sx (x - cx) + sy (y - cy) through the vertices (any slopes
+// give a valid bound: the thickness is measured against whatever plane is chosen)
+__device__ __forceinline__ void plane_slopes(float sxx, float syy, float sxy, float sxz, float syz, float &sx, float &sy)
 {
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t first = g * kCullGroup;
-    if (first >= ntris) return;
-    const uint32_t n = min(kCullGroup, ntris - first) * 3u;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t j = 0; j < n; ++j) {
-        const float *p = reinterpret_cast<const float *>(verts + (size_t)idx_sorted[3 * (size_t)first + j] * stride);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
-    }
-    if (!(lo[0] <= hi[0]) || !(lo[1] <= hi[1]) || !(lo[2] <= hi[2]) || !(hi[0] - lo[0] < INFINITY) || !(hi[1] - lo[1] < INFINITY) ||
-        !(hi[2] - lo[2] < INFINITY)) {
-        // NaN / infinite coordinates: a bound that k_cull never rejects
-        bounds[2 * (size_t)g] = make_float4(0.f, 0.f, 0.f, INFINITY);
-        bounds[2 * (size_t)g + 1] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
-        return;
-    }
-    const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
-    // least-squares plane z = cz + sx (x - cx) + sy (y - cy) through the vertices (any slopes give a valid bound: the
-    // thickness below is measured against whatever plane is chosen)
-    float sxx = 0.f, syy = 0.f, sxy = 0.f, sxz = 0.f, syz = 0.f;
-    for (uint32_t j = 0; j < n; ++j) {
-        const float *p = reinterpret_cast<const float *>(verts + (size_t)idx_sorted[3 * (size_t)first + j] * stride);
-        const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
-        sxx += dx * dx; syy += dy * dy; sxy += dx * dy; sxz += dx * dz; syz += dy * dz;
-    }
     const float det = sxx * syy - sxy * sxy;
-    float sx = 0.f, sy = 0.f;
+    sx = sy = 0.f;
     if (det > 1e-6f * (sxx + syy) * (sxx + syy) && det > 0.f) {
         sx = (sxz * syy - syz * sxy) / det;
         sy = (syz * sxx - sxz * sxy) / det;
         if (!(fabsf(sx) <= 8.f) || !(fabsf(sy) <= 8.f)) sx = sy = 0.f;   // a wall: plain axis-aligned box
     }
-    float rmin = INFINITY, rmax = -INFINITY;
-    for (uint32_t j = 0; j < n; ++j) {
-        const float *p = reinterpret_cast<const float *>(verts + (size_t)idx_sorted[3 * (size_t)first + j] * stride);
-        const float r = (p[2] - cz) - (sx * (p[0] - cx) + sy * (p[1] - cy));
-        rmin = fminf(rmin, r); rmax = fmaxf(rmax, r);
-    }
-    // half extents rounded outwards: the residuals above carry a few ulps of |z| and of sx*dx
+}
+
+__device__ __forceinline__ void store_sheared_box(float4 *__restrict__ out, const float *lo, const float *hi, float cx, float cy, float cz,
+                                                  float sx, float sy, float rmin, float rmax)
+{
+    // half extents rounded outwards: the residuals carry a few ulps of |z| and of sx*dx
     const float zc = cz + 0.5f * (rmin + rmax);
     const float scale_ulps = 4e-7f * (fabsf(cz) + fabsf(lo[2]) + fabsf(hi[2]) + (fabsf(sx) * (hi[0] - lo[0]) + fabsf(sy) * (hi[1] - lo[1])));
     const float hx = 0.5f * (hi[0] - lo[0]) * 1.000001f + 1e-7f * (fabsf(lo[0]) + fabsf(hi[0]));
     const float hy = 0.5f * (hi[1] - lo[1]) * 1.000001f + 1e-7f * (fabsf(lo[1]) + fabsf(hi[1]));
     const float hz = 0.5f * (rmax - rmin) * 1.000001f + scale_ulps;
-    bounds[2 * (size_t)g] = make_float4(cx, cy, zc, hx);
-    bounds[2 * (size_t)g + 1] = make_float4(hy, hz, sx, sy);
+    out[0] = make_float4(cx, cy, zc, hx);
+    out[1] = make_float4(hy, hz, sx, sy);
 }
 
-// linear part L = Rinv * A and offset o = Rinv * (A.t - t) of the vertex transform p' = Rinv ((A v) - t), per geometry
-struct LinearMap { float l[9], o[3]; };
-
-__device__ __forceinline__ LinearMap linear_map(const GeomSource &src)
+__device__ __forceinline__ bool box_extent_bad(const float *lo, const float *hi)
 {
-    LinearMap m;
-    if (src.xform == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) m.l[i] = (i % 4 == 0) ? 1.f : 0.f;
-        m.o[0] = m.o[1] = m.o[2] = 0.f;
-        return m;
-    }
-    const Affine &a = src.m;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            m.l[3 * i + j] = a.rinv[3 * i] * a.a[j] + a.rinv[3 * i + 1] * a.a[4 + j] + a.rinv[3 * i + 2] * a.a[8 + j];
-        m.o[i] = a.rinv[3 * i] * (a.a[3] - a.t[0]) + a.rinv[3 * i + 1] * (a.a[7] - a.t[1]) + a.rinv[3 * i + 2] * (a.a[11] - a.t[2]);
-    }
-    return m;
+    return !(lo[0] <= hi[0]) || !(lo[1] <= hi[1]) || !(lo[2] <= hi[2]) || !(hi[0] - lo[0] < INFINITY) || !(hi[1] - lo[1] < INFINITY) ||
+           !(hi[2] - lo[2] < INFINITY);
 }
 
-// can any ray of this handle's raster meet the sheared box (centre, hx | hy, hz, sx, sy) of a group?
-__device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, const ChanTables &ct, const LinearMap &m, float4 b0, float4 b1)
+// one lane per group of kCullGroup sorted triangles: bounds[2g] = (cx, cy, cz, hx), bounds[2g+1] = (hy, hz, sx, sy); the 64
+// lanes of a wave are the kCullBlockGroups groups of one block, whose bound (same form, over all its vertices, by wave
+// reductions) goes to block_bounds[2b], [2b+1]
+__global__ __launch_bounds__(kBlock) void k_group_bounds(const uint8_t *__restrict__ verts, uint32_t stride,
+                                                         const uint32_t *__restrict__ idx_sorted, uint32_t ntris, float4 *__restrict__ bounds,
+                                                         float4 *__restrict__ block_bounds)
+{
+    static_assert(kCullBlockGroups == 64, "a wave bounds one block");
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t first = g * kCullGroup;
+    const bool live = first < ntris;
+    const uint32_t n = live ? min(kCullGroup, ntris - first) * 3u : 0u;
+    auto vertex = [&](uint32_t j) { return reinterpret_cast<const float *>(verts + (size_t)idx_sorted[3 * (size_t)first + j] * stride); };
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t j = 0; j < n; ++j) {
+        const float *p = vertex(j);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+    }
+    const bool bad = live && box_extent_bad(lo, hi);
+    if (live && bad) {
+        // NaN / infinite coordinates: a bound that k_cull never rejects
+        bounds[2 * (size_t)g] = make_float4(0.f, 0.f, 0.f, INFINITY);
+        bounds[2 * (size_t)g + 1] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+    } else if (live) {
+        const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+        float sxx = 0.f, syy = 0.f, sxy = 0.f, sxz = 0.f, syz = 0.f;
+        for (uint32_t j = 0; j < n; ++j) {
+            const float *p = vertex(j);
+            const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+            sxx += dx * dx; syy += dy * dy; sxy += dx * dy; sxz += dx * dz; syz += dy * dz;
+        }
+        float sx, sy;
+        plane_slopes(sxx, syy, sxy, sxz, syz, sx, sy);
+        float rmin = INFINITY, rmax = -INFINITY;
+        for (uint32_t j = 0; j < n; ++j) {
+            const float *p = vertex(j);
+            const float r = (p[2] - cz) - (sx * (p[0] - cx) + sy * (p[1] - cy));
+            rmin = fminf(rmin, r); rmax = fmaxf(rmax, r);
+        }
+        store_sheared_box(bounds + 2 * (size_t)g, lo, hi, cx, cy, cz, sx, sy, rmin, rmax);
+    }
+    // ---- the block of this wave's 64 groups (lanes without a group contribute nothing)
+    const bool any_live = __any(live);
+    if (!any_live) return;
+    const bool any_bad = __any(bad);
+    float blo[3], bhi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        blo[a] = lo[a]; bhi[a] = hi[a];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { blo[a] = fminf(blo[a], __shfl_xor(blo[a], off)); bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], off)); }
+    }
+    const float cx = 0.5f * (blo[0] + bhi[0]), cy = 0.5f * (blo[1] + bhi[1]), cz = 0.5f * (blo[2] + bhi[2]);
+    float sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!any_bad)
+        for (uint32_t j = 0; j < n; ++j) {
+            const float *p = vertex(j);
+            const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+            sums[0] += dx * dx; sums[1] += dy * dy; sums[2] += dx * dy; sums[3] += dx * dz; sums[4] += dy * dz;
+        }
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sums[a] += __shfl_xor(sums[a], off);
+    }
+    float sx, sy;
+    plane_slopes(sums[0], sums[1], sums[2], sums[3], sums[4], sx, sy);
+    float rmin = INFINITY, rmax = -INFINITY;
+    if (!any_bad)
+        for (uint32_t j = 0; j < n; ++j) {
+            const float *p = vertex(j);
+            const float r = (p[2] - cz) - (sx * (p[0] - cx) + sy * (p[1] - cy));
+            rmin = fminf(rmin, r); rmax = fmaxf(rmax, r);
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { rmin = fminf(rmin, __shfl_xor(rmin, off)); rmax = fmaxf(rmax, __shfl_xor(rmax, off)); }
+    if ((threadIdx.x & 63u) == 0) {
+        const size_t b = g / kCullBlockGroups;
+        if (any_bad) {
+            block_bounds[2 * b] = make_float4(0.f, 0.f, 0.f, INFINITY);
+            block_bounds[2 * b + 1] = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+        } else {
+            store_sheared_box(block_bounds + 2 * b, blo, bhi, cx, cy, cz, sx, sy, rmin, rmax);
+        }
+    }
+}
+
+// linear part L = Rinv * A and offset o = Rinv * (A.t - t) of the vertex transform p' = Rinv ((A v) - t), per geometry;
+// nrm >= the largest factor by which L stretches a vector (its Frobenius norm, rounded up: sqrt(3) for a rotation).
+// Uniform per geometry and only ever used in bounds: formed on the host (launch_project), once per launch.
+struct LinearMap { float l[9], o[3], nrm; };
+
+// what k_cull needs of the geometries of a launch (kernel argument)
+struct CullGeom {
+    const float4 *boxes;   // group bounds, then block bounds (launch_group_bounds)
+    uint32_t ntris;
+    LinearMap m;
+};
+struct CullBatch {
+    uint32_t n;
+    uint32_t cull_first[kGeomsPerLaunch + 1];   // first workgroup of geometry i; [n] = the grid
+    uint32_t list_first[kGeomsPerLaunch];       // as GeomBatch
+    uint32_t seg_cap[kGeomsPerLaunch];
+    uint32_t rounds;                            // groups per workgroup / 256
+    CullGeom g[kGeomsPerLaunch];
+};
+
+// k_cull's channel query: is there a channel i with tan_up[i] >= tan_lo and tan_dn[i] <= tan_hi (both tables ascending)?
+// SEARCH: binary search (any sensor).  LUT: ProjectParams::chan_lut -- one table look-up started one bucket early (the
+// float bucket number is good to 1e-3 buckets), two compare-and-steps, one compare; tan_up carries two +inf sentinels
+// behind its V entries.  Straight-line code: the four tests of a k_cull lane interleave instead of queueing behind each
+// other's LDS round trips.
+struct ChanQuery {
+    const float *tan_up, *tan_dn;   // LUT: [V + 2] each, +inf padded
+    const uint16_t *lut;
+    float t0, scale;
+    uint32_t V;
+};
+
+template <bool LUT>
+__device__ __forceinline__ bool chan_query(const ChanQuery &cq, float tan_lo, float tan_hi)
+{
+    if (LUT) {
+        const float x = fminf(fmaxf((tan_lo - cq.t0) * cq.scale - 0.5f, 0.0f), (float)(kCullLutBuckets - 1u));   // NaN -> 0
+        uint32_t i = cq.lut[(uint32_t)x];
+        i += cq.tan_up[i] < tan_lo ? 1u : 0u;
+        i += cq.tan_up[i] < tan_lo ? 1u : 0u;
+        return (i < cq.V) & (cq.tan_dn[i] <= tan_hi);
+    }
+    uint32_t lo_i = 0, hi_i = cq.V;
+    while (lo_i < hi_i) { const uint32_t mid = (lo_i + hi_i) >> 1; if (cq.tan_up[mid] < tan_lo) lo_i = mid + 1; else hi_i = mid; }
+    return lo_i < cq.V && cq.tan_dn[lo_i] <= tan_hi;
+}
+
+// Can any ray of this handle's raster meet the sheared box  { c + a e1 + b e2 + g e3 : |a|, |b|, |g| <= 1 },  e1 = (hx, 0, sx hx),
+// e2 = (0, hy, sy hy), e3 = (0, 0, hz)  (mesh space; b0 = (c, hx), b1 = (hy, hz, sx, sy))?  With p' = L p + o the sensor-
+// frame point and f = z' / rho' the tangent of its elevation:
+//     f(c + d) = f(c) + grad f . (L d) + R,   grad f = (-f x'/rho^2, -f y'/rho^2, 1/rho) at c',
+// and  grad f . (L d) = (L^T grad f) . d = g . d  -- the gradient carried back into MESH space, where the edges are
+// two-term vectors: the first-order half width is  hx |g.x + sx g.z| + hy |g.y + sy g.z| + hz |g.z|,  a dozen
+// operations instead of three transformed edge vectors and their radial / tangential projections.  Second order:
+// |R| <= (ez eps + (|z'| + ez) 2 eps^2) / rho  for eps = (er + et) / rho < 1/4  with the box's radial + tangential and
+// vertical half extents; both are bounded by the box's radius  rad = nrm (hx (1 + |sx|) + hy (1 + |sy|) + hz)
+// (er + et <= sqrt 2 rad, ez <= rad), and the bound is monotone in them.  The same radius bounds the reach of the box
+// seen from above (azimuth-sector test of a shard).  Everything is a bound with slack: approximate rsq / products are fine.
+template <bool LUT>
+__device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, const ChanQuery &cq, const LinearMap &m, float4 b0, float4 b1)
 {
     const float hx = b0.w, hy = b1.x, hz = b1.y, sx = b1.z, sy = b1.w;
-    if (!(hx < INFINITY)) return true;
-    // centre and edge vectors in the sensor frame
-    float c[3], e1[3], e2[3], e3[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        c[i] = (m.l[3 * i] * b0.x + m.l[3 * i + 1] * b0.y) + (m.l[3 * i + 2] * b0.z + m.o[i]);
-        e1[i] = hx * (m.l[3 * i] + sx * m.l[3 * i + 2]);
-        e2[i] = hy * (m.l[3 * i + 1] + sy * m.l[3 * i + 2]);
-        e3[i] = hz * m.l[3 * i + 2];
+    // (no early returns: every special case is a flag, folded in at the end in the order the cases apply)
+    const bool unbounded = !(hx < INFINITY);
+    const float cx = fmaf(m.l[0], b0.x, fmaf(m.l[1], b0.y, fmaf(m.l[2], b0.z, m.o[0])));
+    const float cy = fmaf(m.l[3], b0.x, fmaf(m.l[4], b0.y, fmaf(m.l[5], b0.z, m.o[1])));
+    const float cz = fmaf(m.l[6], b0.x, fmaf(m.l[7], b0.y, fmaf(m.l[8], b0.z, m.o[2])));
+    const float rho2 = fmaf(cx, cx, cy * cy);
+    const bool on_axis = !(rho2 > 1e-12f) || !(rho2 < INFINITY);
+    const float inv_rho = __builtin_amdgcn_rsqf(rho2), inv_rho2 = inv_rho * inv_rho;
+    const float fc = cz * inv_rho, k = fc * inv_rho2;
+    // g = L^T grad f,  grad f = (-k cx, -k cy, inv_rho)
+    const float ax = -k * cx, ay = -k * cy;
+    const float gx = fmaf(m.l[0], ax, fmaf(m.l[3], ay, m.l[6] * inv_rho));
+    const float gy = fmaf(m.l[1], ax, fmaf(m.l[4], ay, m.l[7] * inv_rho));
+    const float gz = fmaf(m.l[2], ax, fmaf(m.l[5], ay, m.l[8] * inv_rho));
+    const float w = fmaf(hx, fabsf(fmaf(sx, gz, gx)), fmaf(hy, fabsf(fmaf(sy, gz, gy)), hz * fabsf(gz)));
+    const float rad = m.nrm * fmaf(hx, 1.0f + fabsf(sx), fmaf(hy, 1.0f + fabsf(sy), hz)) * 1.00001f;
+    bool out_of_sector = false;
+    if (pp.sector_on) {   // uniform
+        // seen from above the box lies inside the disc of radius rad around its centre: outside a boundary plane of the
+        // shard's sector if the centre is further out than that
+        const float reach = fmaf(rad, 1.0001f, 1e-6f * rho2 * inv_rho);
+        out_of_sector = (pp.sec_a[0] * cy - pp.sec_a[1] * cx < -reach) | (cx * pp.sec_b[1] - cy * pp.sec_b[0] < -reach);
     }
-    const float rho2 = c[0] * c[0] + c[1] * c[1];
-    if (!(rho2 > 1e-12f) || !(rho2 < INFINITY)) return true;
-    const float inv_rho = __builtin_amdgcn_rsqf(rho2), rho = rho2 * inv_rho;
-    const float ux = c[0] * inv_rho, uy = c[1] * inv_rho;   // radial unit vector (1 ulp-ish: enters only bounds with slack)
-    // radial / tangential / vertical half extents
-    const float r1 = e1[0] * ux + e1[1] * uy, r2 = e2[0] * ux + e2[1] * uy, r3 = e3[0] * ux + e3[1] * uy;
-    const float t1 = e1[1] * ux - e1[0] * uy, t2 = e2[1] * ux - e2[0] * uy, t3 = e3[1] * ux - e3[0] * uy;
-    const float er = fabsf(r1) + fabsf(r2) + fabsf(r3), et = fabsf(t1) + fabsf(t2) + fabsf(t3);
-    const float ez = fabsf(e1[2]) + fabsf(e2[2]) + fabsf(e3[2]);
-    if (pp.sector_on) {
-        // the box lies inside the disc of radius er + et around its centre (seen from above): outside a boundary plane of
-        // the shard's sector if the centre is further out than that
-        const float reach = (er + et) * 1.0001f + 1e-6f * rho;
-        if (pp.sec_a[0] * c[1] - pp.sec_a[1] * c[0] < -reach) return false;
-        if (c[0] * pp.sec_b[1] - c[1] * pp.sec_b[0] < -reach) return false;
-    }
-    const float eps = (er + et) * inv_rho;
-    if (!(eps < 0.25f)) return true;   // next to the vertical axis: no first-order bound
-    // f = z / rho;  f(c + d) = f(c) + dz / rho - z dr / rho^2 + R,  |R| <= (ez eps + (|z| + ez) 2 eps^2) / rho  for eps < 1/4
-    const float fc = c[2] * inv_rho, k = c[2] * inv_rho * inv_rho;
-    const float w = fabsf(e1[2] * inv_rho - k * r1) + fabsf(e2[2] * inv_rho - k * r2) + fabsf(e3[2] * inv_rho - k * r3);
-    const float rem = (ez * eps + (fabsf(c[2]) + ez) * 2.0f * eps * eps) * inv_rho;
-    const float half = (w + rem) * 1.0001f + 2e-6f * (fabsf(fc) + 1e-3f);   // rounding of the dozen products above
-    const float tan_lo = fc - half, tan_hi = fc + half;
-    uint32_t lo_i = 0, hi_i = pp.tb.V;
-    while (lo_i < hi_i) { const uint32_t mid = (lo_i + hi_i) >> 1; if (ct.tan_up[mid] < tan_lo) lo_i = mid + 1; else hi_i = mid; }
-    return lo_i < pp.tb.V && ct.tan_dn[lo_i] <= tan_hi;
+    const float eps = 1.4142137f * rad * inv_rho;
+    const bool near_axis = !(eps < 0.25f);   // next to the vertical axis: no first-order bound
+    const float rem = fmaf(rad, eps, (fabsf(cz) + rad) * 2.0f * eps * eps) * inv_rho;
+    const float half = fmaf(w + rem, 1.0001f, 3e-6f * (fabsf(fc) + 1e-3f));   // rounding of the two dozen products above
+    const bool some_channel = chan_query<LUT>(cq, fc - half, fc + half);
+    return unbounded | on_axis | (!out_of_sector & (near_axis | some_channel));
 }
 
-// kCullPerBlock groups per workgroup (one lane per group, four rounds); every geometry's groups start at a multiple of
-// kCullPerBlock in the numbering (batch.list_first), so a workgroup belongs to one geometry.  Survivors are collected
-// in LDS and appended to the geometry's list with ONE global atomic per workgroup (a hot address sustains ~90 atomics
-// per microsecond: one per wave of a million-triangle mesh would take 40 us).
-constexpr uint32_t kCullPerBlock = 1024;
+// `rounds` x 256 groups per workgroup (one lane per group and round; batch.rounds, 2 .. kCullMaxRounds, is chosen by the
+// host so that the whole pass is ONE round of resident workgroups where it can: at 1 024 groups per workgroup SYN-10M
+// took 2 441 workgroups for 2 048 places -- two rounds of an 8 us workgroup); a workgroup belongs to one geometry
+// (batch.cull_first).  Round `it` of wave w is block  first/64 + 4 it + w  of the mesh -- 64 consecutive groups under one
+// coarse bound: lanes 0..3 of every wave test the wave's four block bounds first and the wave skips, loads included,
+// the rounds whose block no ring can meet (on SYN-10M 39 % of the blocks; a lone group survives 23 % of the time).
+// Survivors are collected in LDS and appended to one of the geometry's kCullSegs list segments -- workgroup j to
+// segment j % kCullSegs -- with ONE global atomic per workgroup on that segment's counter.
+constexpr uint32_t kCullMaxRounds = 8;
+constexpr uint32_t kCullMaxPerBlock = kCullMaxRounds * kBlock;
 
-template <bool LDS_TABLES>
-__global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, GeomBatch batch, uint32_t *__restrict__ list, uint32_t *__restrict__ counts)
+template <bool LDS_TABLES, bool COUNT, bool LUT /* needs LDS_TABLES */>
+__global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, CullBatch batch, uint32_t *__restrict__ list, uint32_t *__restrict__ counts,
+                                                 unsigned long long *__restrict__ stats)
 {
-    extern __shared__ float s_tan[];   // LDS_TABLES: tan_up[V], tan_dn[V]
-    __shared__ uint32_t s_keep[kCullPerBlock];
+    extern __shared__ float s_tan[];   // LDS_TABLES: tan_up[V + 2], tan_dn[V + 2] (two +inf sentinels each), LUT: then chan_lut
+    __shared__ uint32_t s_keep[kCullMaxPerBlock];
     __shared__ uint32_t s_n, s_base;
-    const uint32_t first = blockIdx.x * kCullPerBlock;
+    static_assert((kBlock / 64) * kCullBlockGroups == kBlock, "a round of a wave is one block");
+    const uint32_t rounds = batch.rounds;
     uint32_t gi = 0;
-    while (gi + 1u < batch.n && first >= batch.list_first[gi + 1u]) ++gi;
-    const GeomSource &src = batch.g[gi];
-    const uint32_t g0 = first - batch.list_first[gi];
-    // the four rounds are independent: all eight bound loads go out first (before the channel tables are staged: the
-    // two waits overlap), then four dependency chains interleave -- one workgroup per CU leaves nothing else to hide
-    // their latency behind
-    constexpr uint32_t kRounds = kCullPerBlock / kBlock;
-    float4 b0[kRounds], b1[kRounds];
+    while (gi + 1u < batch.n && blockIdx.x >= batch.cull_first[gi + 1u]) ++gi;
+    const CullGeom &src = batch.g[gi];
+    const uint32_t wg = blockIdx.x - batch.cull_first[gi];   // this workgroup among the geometry's
+    const uint32_t g0 = wg * rounds * kBlock;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t n_groups = (src.ntris + kCullGroup - 1u) / kCullGroup;
-#pragma unroll
-    for (uint32_t it = 0; it < kRounds; ++it) {
-        const uint32_t g = min(g0 + it * kBlock + threadIdx.x, n_groups - 1u);
-        b0[it] = src.boxes[2 * (size_t)g];
-        b1[it] = src.boxes[2 * (size_t)g + 1];
-    }
-    ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
+    const uint32_t n_blocks = (n_groups + kCullBlockGroups - 1u) / kCullBlockGroups;
+    // the wave's four coarse bounds go out first, before the channel tables are staged: the two waits overlap
+    const float4 *__restrict__ block_boxes = src.boxes + 2 * (size_t)n_groups;
+    const uint32_t my_block = g0 / kCullBlockGroups + lane * (kBlock / 64) + w;
+    const bool has_block = lane < rounds && my_block < n_blocks;
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+    if (has_block) { c0 = block_boxes[2 * (size_t)my_block]; c1 = block_boxes[2 * (size_t)my_block + 1]; }
+    const uint32_t V = pp.tb.V;
+    ChanQuery cq = {pp.chan_tan_up, pp.chan_tan_dn, pp.chan_lut, pp.lut_t0, pp.lut_scale, V};
     if (threadIdx.x == 0) s_n = 0;
     if (LDS_TABLES) {
-        const uint32_t V = pp.tb.V;
-        for (uint32_t i = threadIdx.x; i < V; i += kBlock) { s_tan[i] = pp.chan_tan_up[i]; s_tan[V + i] = pp.chan_tan_dn[i]; }
-        ct.tan_up = s_tan;
-        ct.tan_dn = s_tan + V;
-    }
-    __syncthreads();
-    const LinearMap m = linear_map(src);
-    bool keeps[kRounds];
-#pragma unroll
-    for (uint32_t it = 0; it < kRounds; ++it)
-        keeps[it] = g0 + it * kBlock + threadIdx.x < n_groups && group_meets_raster(pp, ct, m, b0[it], b1[it]);
-#pragma unroll
-    for (uint32_t it = 0; it < kRounds; ++it) {
-        const uint32_t g = g0 + it * kBlock + threadIdx.x;
-        const bool keep = keeps[it];
-        const unsigned long long mask = __ballot(keep);
-        if (mask) {   // uniform over the wave
-            uint32_t at = 0;
-            if ((threadIdx.x & 63u) == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
-            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-            if (keep) s_keep[at + lanes_below(mask)] = g;
+        float *s_up = s_tan, *s_dn = s_tan + V + 2u;
+        for (uint32_t i = threadIdx.x; i < V + 2u; i += kBlock) {
+            s_up[i] = i < V ? pp.chan_tan_up[i] : INFINITY;
+            s_dn[i] = i < V ? pp.chan_tan_dn[i] : INFINITY;
+        }
+        cq.tan_up = s_up;
+        cq.tan_dn = s_dn;
+        if (LUT) {
+            uint32_t *s_lut = reinterpret_cast<uint32_t *>(s_dn + V + 2u);
+            const uint32_t *g_lut = reinterpret_cast<const uint32_t *>(pp.chan_lut);
+            for (uint32_t i = threadIdx.x; i < kCullLutBuckets / 2u; i += kBlock) s_lut[i] = g_lut[i];
+            cq.lut = reinterpret_cast<const uint16_t *>(s_lut);
         }
     }
     __syncthreads();
+    const LinearMap &m = src.m;
+    const bool block_alive = group_meets_raster<LUT>(pp, cq, m, c0, c1);
+    const uint32_t alive = (uint32_t)__ballot(has_block && block_alive) & ((1u << rounds) - 1u);
+    // the rounds whose block is alive, two at a time: both rounds' bound loads go out first, then the two tests -- straight-
+    // line code -- interleave (an odd round out is tested on its own: its partner is a predicated-off copy of itself)
+    if (COUNT && lane == 0 && alive) atomicAdd(&stats[2], (unsigned long long)(__popc(alive) * kCullBlockGroups));   // counts[3]: group bounds read
+    auto append = [&](uint32_t it, bool keep) {
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {   // uniform over the wave
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (keep) s_keep[at + lanes_below(mask)] = g0 + it * kBlock + threadIdx.x;
+        }
+    };
+    for (uint32_t todo = alive; todo;) {   // uniform over the wave
+        const uint32_t ia = (uint32_t)__builtin_ctz(todo);
+        todo &= todo - 1u;
+        const bool pair = todo != 0u;
+        const uint32_t ib = pair ? (uint32_t)__builtin_ctz(todo) : ia;
+        todo &= todo - 1u;   // (0 stays 0)
+        const uint32_t ga = g0 + ia * kBlock + threadIdx.x, gb = g0 + ib * kBlock + threadIdx.x;
+        const uint32_t la = min(ga, n_groups - 1u), lb = min(gb, n_groups - 1u);
+        const float4 a0 = src.boxes[2 * (size_t)la], a1 = src.boxes[2 * (size_t)la + 1];
+        const float4 b0 = src.boxes[2 * (size_t)lb], b1 = src.boxes[2 * (size_t)lb + 1];
+        const bool ka = group_meets_raster<LUT>(pp, cq, m, a0, a1), kb = group_meets_raster<LUT>(pp, cq, m, b0, b1);
+        append(ia, ka && ga < n_groups);
+        if (pair) append(ib, kb && gb < n_groups);
+    }
+    // (one global atomic per WORKGROUP: one per wave -- four times as many on the same 32 counters -- measured 3 us
+    // slower on SYN-10M, the counters' ~11 ns per atomic showing again)
+    __syncthreads();
     const uint32_t n = s_n;
     if (!n) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&counts[gi], n);
+    const uint32_t seg = wg % kCullSegs;
+    if (threadIdx.x == 0) s_base = atomicAdd(&counts[(gi * kCullSegs + seg) * 16u], n);
     __syncthreads();
-    uint32_t *out = list + batch.list_first[gi] + s_base;
+    uint32_t *out = list + batch.list_first[gi] + seg * batch.seg_cap[gi] + s_base;
     for (uint32_t i = threadIdx.x; i < n; i += kBlock) out[i] = s_keep[i];
 }
 
@@ -968,7 +1098,7 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
         __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)fa.publish_epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (block_idx == 0) {   // the queue / survivor counters of the frame after the next: nobody reads them now
         if (threadIdx.x == 0) fa.rearm_big_count[0] = 0u;
-        if (threadIdx.x < (uint32_t)kGeomsPerLaunch) fa.rearm_big_count[kCullCountAt + threadIdx.x] = 0u;
+        for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) fa.rearm_big_count[kCullCountAt + i * 16u] = 0u;
     }
     // hits of all workgroups before this one.  Waiting is rare (every workgroup publishes within a few
     // microseconds of its neighbours unless the queue gather is heavy) and must stay cheap for the ones
@@ -1094,26 +1224,78 @@ uint32_t project_tris_per_wave(uint32_t ntris)
 }
 
 namespace {
-// the geometries that carry group bounds, as one batch: false if there are none or more than a launch takes
+// workgroups of k_cull that are resident at once: 8 per CU (four waves each, ~9 KB of LDS)
+uint32_t cull_resident_workgroups()
+{
+    static const uint32_t n = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return 8u * (uint32_t)prop.multiProcessorCount;
+        return 2048u;
+    }();
+    return n;
+}
+
+LinearMap linear_map(const GeomSource &src)
+{
+    LinearMap m;
+    if (src.xform == 0) {
+        for (int i = 0; i < 9; ++i) m.l[i] = (i % 4 == 0) ? 1.f : 0.f;
+        m.o[0] = m.o[1] = m.o[2] = 0.f;
+        m.nrm = 1.7320509f;
+        return m;
+    }
+    const Affine &a = src.m;
+    double sq = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            m.l[3 * i + j] = a.rinv[3 * i] * a.a[j] + a.rinv[3 * i + 1] * a.a[4 + j] + a.rinv[3 * i + 2] * a.a[8 + j];
+            sq += (double)m.l[3 * i + j] * (double)m.l[3 * i + j];
+        }
+        m.o[i] = a.rinv[3 * i] * (a.a[3] - a.t[0]) + a.rinv[3 * i + 1] * (a.a[7] - a.t[1]) + a.rinv[3 * i + 2] * (a.a[11] - a.t[2]);
+    }
+    m.nrm = (float)(std::sqrt(sq) * 1.00001);
+    return m;
+}
+
+// the geometries that carry group bounds, as one batch: false if there are none or more than a launch takes.
+// blocks = k_project's grid (worst case: every group survives), entries = survivor-list words, batch.cull_first[n] = k_cull's grid
 bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch, uint32_t &blocks, uint32_t &entries)
 {
     batch.n = 0;
     blocks = entries = 0;
+    uint32_t cull_blocks = 0;
+    constexpr uint32_t kGroupsPerWorkgroup = (kBlock / 64) * (64u / kCullGroup);   // survivors one k_project workgroup takes
+    // k_cull's groups per workgroup: the fewest rounds (from 2) with which all its workgroups are resident at once (8 per CU)
+    unsigned long long all_groups = 0;
+    for (uint32_t i = 0; i < n_srcs; ++i)
+        if (srcs[i].boxes && srcs[i].ntris) all_groups += (srcs[i].ntris + kCullGroup - 1) / kCullGroup;
+    uint32_t rounds = 2;
+    while (rounds < kCullMaxRounds && (all_groups + (unsigned long long)rounds * kBlock - 1) / ((unsigned long long)rounds * kBlock) > cull_resident_workgroups()) ++rounds;
+    batch.cull_rounds = rounds;
+    const uint32_t per_wg = rounds * kBlock;
     for (uint32_t i = 0; i < n_srcs; ++i) {
         const GeomSource &src = srcs[i];
         if (!src.boxes || !src.ntris) continue;
         if (batch.n == (uint32_t)kGeomsPerLaunch) return false;
+        const uint32_t groups = (src.ntris + kCullGroup - 1) / kCullGroup;
+        const uint32_t cull_wgs = (groups + per_wg - 1) / per_wg;                     // a k_cull workgroup belongs to one geometry
+        const uint32_t seg_cap = (cull_wgs + kCullSegs - 1) / kCullSegs * per_wg;     // a segment takes every kCullSegs-th workgroup's survivors
         batch.block_first[batch.n] = blocks;
         batch.tris_per_wave[batch.n] = 64u;
         batch.list_first[batch.n] = entries;
+        batch.cull_first[batch.n] = cull_blocks;
+        batch.seg_cap[batch.n] = seg_cap;
         batch.g[batch.n] = src;
-        blocks += (src.ntris + kBlock - 1) / kBlock;                       // worst case: every group survives
-        const uint32_t groups = (src.ntris + kCullGroup - 1) / kCullGroup;
-        entries += (groups + kCullPerBlock - 1) / kCullPerBlock * kCullPerBlock;   // a k_cull workgroup belongs to one geometry
+        blocks += kCullSegs * (seg_cap / kGroupsPerWorkgroup);
+        entries += kCullSegs * seg_cap;
+        cull_blocks += cull_wgs;
         ++batch.n;
     }
     batch.block_first[batch.n] = blocks;
     batch.list_first[batch.n] = entries;
+    batch.cull_first[batch.n] = cull_blocks;
     return batch.n > 0;
 }
 }  // namespace
@@ -1179,14 +1361,31 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         GeomBatch batch;
         uint32_t blocks, entries;
         if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries)) {
-            const dim3 cgrid(entries / kCullPerBlock);
-            const size_t clds = 2 * (size_t)pp.tb.V * sizeof(float);
-            if (ev_start) {   // the cull pass belongs to the timed stage: the clock starts with it
-                if (lt) hipExtLaunchKernelGGL(k_cull<true>, cgrid, dim3(kBlock), (uint32_t)clds, s, ev_start, nullptr, 0u, pp, batch, cull_list, big_count + kCullCountAt);
-                else hipExtLaunchKernelGGL(k_cull<false>, cgrid, dim3(kBlock), 0u, s, ev_start, nullptr, 0u, pp, batch, cull_list, big_count + kCullCountAt);
-                ev_start = nullptr;
-            } else if (lt) hipLaunchKernelGGL(k_cull<true>, cgrid, dim3(kBlock), clds, s, pp, batch, cull_list, big_count + kCullCountAt);
-            else hipLaunchKernelGGL(k_cull<false>, cgrid, dim3(kBlock), 0, s, pp, batch, cull_list, big_count + kCullCountAt);
+            const dim3 cgrid(batch.cull_first[batch.n]);
+            CullBatch cb;
+            cb.n = batch.n;
+            cb.rounds = batch.cull_rounds;
+            for (uint32_t i = 0; i < batch.n; ++i) {
+                cb.cull_first[i] = batch.cull_first[i];
+                cb.list_first[i] = batch.list_first[i];
+                cb.seg_cap[i] = batch.seg_cap[i];
+                cb.g[i].boxes = batch.g[i].boxes;
+                cb.g[i].ntris = batch.g[i].ntris;
+                cb.g[i].m = linear_map(batch.g[i]);
+            }
+            cb.cull_first[batch.n] = batch.cull_first[batch.n];
+            const bool lut = lt && pp.lut_ok;
+            const uint32_t clds = lt ? (uint32_t)(2 * ((size_t)pp.tb.V + 2) * sizeof(float) + (lut ? kCullLutBuckets * sizeof(uint16_t) : 0)) : 0u;
+            uint32_t *counts = big_count + kCullCountAt;
+            // (ev_start: the cull pass belongs to the timed stage, the clock starts with it)
+#define LS_CULL(L, C, U) do { \
+                if (ev_start) hipExtLaunchKernelGGL((k_cull<L, C, U>), cgrid, dim3(kBlock), clds, s, ev_start, nullptr, 0u, pp, cb, cull_list, counts, stats); \
+                else hipLaunchKernelGGL((k_cull<L, C, U>), cgrid, dim3(kBlock), clds, s, pp, cb, cull_list, counts, stats); } while (0)
+            if (lut) { if (stats) LS_CULL(true, true, true); else LS_CULL(true, false, true); }
+            else if (lt) { if (stats) LS_CULL(true, true, false); else LS_CULL(true, false, false); }
+            else { if (stats) LS_CULL(false, true, false); else LS_CULL(false, false, false); }
+#undef LS_CULL
+            ev_start = nullptr;
             launch(batch, blocks, cull_list);
             culled_done = true;
         }
@@ -1231,11 +1430,18 @@ void launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uin
     hipLaunchKernelGGL(k_permute_indices, tgrid, dim3(kBlock), 0, s, idx, perm, ntris, idx_sorted);
 }
 
+size_t project_box_entries(uint32_t ntris)
+{
+    const size_t groups = (ntris + kCullGroup - 1) / kCullGroup;
+    return groups + (groups + kCullBlockGroups - 1) / kCullBlockGroups;
+}
+
 void launch_group_bounds(hipStream_t s, const uint8_t *verts, uint32_t stride, const uint32_t *idx_sorted, uint32_t ntris, float4 *boxes)
 {
     if (!ntris) return;
     const uint32_t groups = (ntris + kCullGroup - 1) / kCullGroup;
-    hipLaunchKernelGGL(k_group_bounds, dim3((groups + kBlock - 1) / kBlock), dim3(kBlock), 0, s, verts, stride, idx_sorted, ntris, boxes);
+    hipLaunchKernelGGL(k_group_bounds, dim3((groups + kBlock - 1) / kBlock), dim3(kBlock), 0, s, verts, stride, idx_sorted, ntris, boxes,
+                       boxes + 2 * (size_t)groups);
 }
 
 void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats)

@@ -40,6 +40,10 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     pp.chan_tan_dn = pp.chan_tan_up + tr->V;
     pp.chan_perm = reinterpret_cast<const uint32_t *>(pp.chan_tan_dn + tr->V);
     pp.chan_rank = reinterpret_cast<const uint32_t *>(tr->d_tables + 5 * (size_t)tr->V + 4 * (size_t)tr->H);
+    pp.chan_lut = reinterpret_cast<const uint16_t *>(tr->d_tables + 6 * (size_t)tr->V + 4 * (size_t)tr->H);
+    pp.lut_t0 = tr->lut_t0;
+    pp.lut_scale = tr->lut_scale;
+    pp.lut_ok = tr->lut_ok ? 1 : 0;
     pp.begin_deg = tr->h_begin;
     pp.step_deg = tr->h_step;  // LidarDevice.cpp:611
     pp.inv_step_deg = pp.step_deg != 0.0f ? 1.0f / pp.step_deg : 0.0f;
@@ -590,6 +594,40 @@ int ls_tracer_flush(ls_tracer *tr)
 {
     LS_ENTER(tr);
     return flush_pipeline(tr);
+}
+
+int ls_tracer_wait_event(ls_tracer *tr, void *hip_event)
+{
+    LS_ENTER(tr);
+    if (!hip_event) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null event");
+    LS_HIP(hipStreamWaitEvent(tr->stream, static_cast<hipEvent_t>(hip_event), 0));
+    ++tr->main_epoch;   // every slot stream orders its next frame after the handle's stream
+    return LS_OK;
+}
+
+int ls_tracer_order_after_last_frame(ls_tracer *tr, void *hip_stream)
+{
+    LS_ENTER(tr);
+    if (!hip_stream) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null stream");
+    hipStream_t waiter = static_cast<hipStream_t>(hip_stream);
+    hipStream_t src = tr->stream;
+    hipEvent_t ev = nullptr;
+    if (tr->opt_pipeline == 2 && tr->ms_seq && tr->slot_pending[(tr->ms_seq - 1u) % 3u]) {
+        // three-stream mode: the frame issued last runs on its slot's stream; the other frames in flight are not waited for
+        const uint32_t slot = (tr->ms_seq - 1u) % 3u;
+        src = tr->slot_stream[slot];
+        ev = tr->ev_done[slot];
+    } else {
+        // one stream: rider mode still owes the last frame its finish + pack; then the handle's stream holds the frame
+        const int rc = flush_pipeline(tr);
+        if (rc) return rc;
+        if (!tr->ev_frame) LS_HIP(hipEventCreateWithFlags(&tr->ev_frame, hipEventDisableTiming | hipEventDisableSystemFence));
+        ev = tr->ev_frame;
+    }
+    if (src == waiter) return LS_OK;
+    LS_HIP(hipEventRecord(ev, src));
+    LS_HIP(hipStreamWaitEvent(waiter, ev, 0));
+    return LS_OK;
 }
 
 int ls_get_timings(ls_tracer *tr, float ms[LS_T_COUNT])

@@ -7,6 +7,7 @@
 
 #include "HipTracer.hpp"
 #include "Trajectory.hpp"
+#include "../../include/lidarshooter_group.h"
 
 using namespace lidarshooter;
 
@@ -190,6 +191,27 @@ int lsh_stream_frames(void* tracer, const char* const* names, const float* const
             if (rc < 0) return rc;
         }
         rc = ls_trace_scene_async(tr, frame, &f);
+        if (rc < -1) return rc;
+    }
+    return 0;
+}
+
+// The same loop over the GPUs of a node (include/lidarshooter_group.h): every rank restates its meshes' poses, commits and
+// hands the frame to its group -- azimuth shard + one all-gather of hit-record slots, or whole frames interleaved.
+int lsh_group_stream_frames(void* group, void* tracer, const char* const* names, const float* const* affines, const unsigned* n_affines,
+                            unsigned n_meshes, unsigned first_frame, unsigned n_frames)
+{
+    ls_tracer* tr = static_cast<ls_tracer*>(tracer);
+    ls_group* g = static_cast<ls_group*>(group);
+    for (unsigned k = 0; k < n_frames; ++k) {
+        const unsigned frame = first_frame + k;
+        for (unsigned m = 0; m < n_meshes; ++m) {
+            const int rc = ls_update_geometry_transform(tr, names[m], affines[m] + 12u * (n_affines[m] ? frame % n_affines[m] : 0u));
+            if (rc < 0) return rc;
+        }
+        int rc = ls_commit_scene(tr);
+        if (rc < -1) return rc;
+        rc = ls_group_trace(g, frame);
         if (rc < -1) return rc;
     }
     return 0;

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("mode_name", ["sharded", "interleaved"])
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_group_one_rank(oracle, capi, sensors, meshes, mode_name, pipeline):
     from lidarshooter_amd import groupapi
     s = sensors["0001"]
@@ -39,7 +39,9 @@ def test_group_one_rank(oracle, capi, sensors, meshes, mode_name, pipeline):
             for k in (f - 2, f - 1, f):
                 pts, hits = g.download(k)
                 assert np.array_equal(pts, refs[k]["points"]) and np.array_equal(hits, refs[k]["hits"])
+    assert tr.info(capi.LS_INFO_PIPELINE_MODE) == 2    # the group keeps three frames in flight per rank
     g.close()
+    assert tr.info(capi.LS_INFO_PIPELINE_MODE) == pipeline
     rc, pts, hits = tr.traceScene(99)              # the tracer is the caller's again
     assert rc == 0 and np.array_equal(pts, refs[-1]["points"])
     tr.close()
@@ -60,3 +62,78 @@ def test_lsbench_ranks_one(oracle, sensors, meshes, group):
     assert rec["ranks"] == 1 and rec["group"] == group and rec["points_last_frame"] == 1781
     ref = oracle.trace_frame(sensors["0000"], [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
     assert rec["points_sha256"] == hashlib.sha256(ref["points"].tobytes()).hexdigest()
+
+
+def test_sharded_path_two_logical_ranks_on_one_device(oracle, capi, sensors, meshes):
+    """Every kernel and every ordering primitive of the N > 1 sharded path on one device, against the oracle: world = 2 as
+    two handles (RCCL refuses two ranks on one GPU, so the device-side concatenation of the two slots stands in for
+    ncclAllGather).  Per frame and rank: ls_tracer_wait_event guards the slot that is written again (three buffer sets),
+    ls_tracer_set_shard'ed handle with the sector cull and group culling on, three frames in flight (LS_OPT_PIPELINE 2),
+    k_pack writes count word + hit records straight into the rank's slot of the gathered buffer,
+    ls_tracer_order_after_last_frame orders the collective stream after THAT frame only, ls_expand_gathered_hits_on
+    rebuilds the cloud there -- what ls_group_trace does (lidarshooter_amd/csrc/ls_group.cpp) -- while a mesh moves."""
+    import torch
+    from lidarshooter_amd import shards, synth
+    base = sensors["0000"]
+    s = oracle.Sensor(uid="syn", vertical=synth.syn_vertical(64), h_begin=np.float32(0.0), h_end=np.float32(360.0), h_count=1024,
+                      R=base.R, Rinv=base.Rinv, t=base.t)
+    gv, gt = synth.grid_mesh(600, 450, half=50.0, seed=7)        # 540 000 triangles: group culling applies (>= 524 288)
+    bv, bt = meshes["ben"]
+    world, sets, frames = 2, 3, 9
+    cap = shards.slot_capacity(s.V, s.H, world)
+    sb = shards.slot_bytes(cap)
+    dev = "cuda:0"
+    trs = []
+    for rank in range(world):
+        tr = make_tracer(capi, s, "projection")
+        tr.setShard(*shards.shard_columns(s.H, world, rank))
+        tr.setOption(capi.LS_OPT_BLOCK_CULL, 1)
+        tr.addGeometry("ground", gv.shape[0], gt.shape[0])
+        tr.addGeometry("face", bv.shape[0], bt.shape[0])
+        tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gv, gt)
+        tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+        assert tr.commitScene() == 0
+        tr.setOption(capi.LS_OPT_PIPELINE, 2)
+        assert tr.info(capi.LS_INFO_PIPELINE_MODE) in (1, 2)
+        trs.append(tr)
+    collect = torch.cuda.Stream(dev)
+    gathered = [torch.zeros(world * sb, dtype=torch.uint8, device=dev) for _ in range(sets)]
+    local_pts = [[torch.zeros(32 * cap, dtype=torch.uint8, device=dev) for _ in range(sets)] for _ in range(world)]
+    cloud = [(torch.zeros(32 * cap * world, dtype=torch.uint8, device=dev), torch.zeros(16 * cap * world, dtype=torch.uint8, device=dev),
+              torch.zeros(4, dtype=torch.int32, device=dev)) for _ in range(sets)]
+    collected = [torch.cuda.Event() for _ in range(sets)]
+    used = [False] * sets
+    poses = [oracle.affine_from_components(np.array((6.0 + 0.5 * k, -4.0 + 1.1 * k, 0.1 * k), np.float32), np.array((0.0, 0.05 * k, 0.4 * k), np.float32))
+             for k in range(frames)]
+    refs = [oracle.trace_frame(s, [(0, gv, gt, oracle.IDENTITY_AFFINE), (1, bv, bt, A)], use_bvh=True) for A in poses]
+    assert len({r["points"].shape[0] for r in refs}) > 2
+    for f, A in enumerate(poses):
+        b = f % sets
+        for rank, tr in enumerate(trs):
+            if used[b]:
+                tr.waitEvent(collected[b].cuda_event)            # the slot's previous tenant has been rebuilt into its cloud
+            slot = gathered[b].data_ptr() + rank * sb
+            tr.setOutputBuffers(local_pts[rank][b].data_ptr(), slot + shards.HEADER, slot, cap)
+            tr.updateGeometryTransform("face", A)
+            assert tr.commitScene() == 0
+            tr.traceSceneAsync(f)
+            tr.orderAfterLastFrame(collect.cuda_stream)           # this frame only: the two before it are still in flight
+        pts, hts, n = cloud[b]
+        trs[0].expandGatheredHitsOn(collect.cuda_stream, gathered[b].data_ptr(), world, cap, pts.data_ptr(), hts.data_ptr(), n.data_ptr())
+        collected[b].record(collect)
+        used[b] = True
+        if f % sets == sets - 1:                                   # frames f-2 .. f are the sets' tenants
+            collect.synchronize()
+            for k in range(f - sets + 1, f + 1):
+                pts, hts, n = cloud[k % sets]
+                cnt = int(n[0].item())
+                assert cnt == refs[k]["points"].shape[0], (k, cnt)
+                got_h = hts.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4)
+                got_p = pts.cpu().numpy()[:32 * cnt].reshape(cnt, 32)
+                order = np.argsort(got_h[:, 0], kind="stable")     # the gathered cloud is sector-major: rank 0's records, then rank 1's
+                assert np.array_equal(got_h[order], refs[k]["hits"]) and np.array_equal(got_p[order], refs[k]["points"])
+                half = int((got_h[:, 0] % s.H < s.H // 2).sum())
+                assert np.all(got_h[:half, 0] % s.H < s.H // 2) and np.all(got_h[half:, 0] % s.H >= s.H // 2)
+    for tr in trs:
+        tr.synchronize()
+        tr.close()

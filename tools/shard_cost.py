@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from lidarshooter_amd import capi, shards
 import bench
-sensor, meshes = bench.build_workload("syn128x1m")
+sensor, meshes = bench.build_workload(os.environ.get("W", "syn128x1m"))
 dev = torch.device("cuda", 0)
 dm = [(n, torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev), torch.from_numpy(np.ascontiguousarray(t, np.uint32).view(np.int32)).to(dev), v.shape[0], t.shape[0]) for n, v, t in meshes]
 tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], int(sensor["h_count"]), sensor["Rinv"], sensor["t"])
