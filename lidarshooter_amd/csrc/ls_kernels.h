@@ -129,6 +129,7 @@ struct GeomBatch {
     uint32_t list_first[kGeomsPerLaunch + 1];    // group culling: first entry of geometry i in the survivor list
     uint32_t cull_first[kGeomsPerLaunch + 1];    // group culling: first k_cull workgroup of geometry i; [n] = k_cull's grid
     uint32_t seg_cap[kGeomsPerLaunch];           // group culling: entries of each of geometry i's kCullSegs list segments
+    uint32_t seg_blocks[kGeomsPerLaunch];        // group culling: k_project workgroups per list segment in this launch
     uint32_t cull_rounds;                        // group culling: k_cull's groups per workgroup / 256
     GeomSource g[kGeomsPerLaunch];
 };

@@ -319,7 +319,10 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     // CULLED: the groups of kCullGroup sorted triangles that survived k_cull sit in kCullSegs segments of this
     // geometry's part of cull_list, each packed to its front (count in the segment's counter); workgroup b of the
     // geometry works on segment b % kCullSegs, position b / kCullSegs; a wave takes 64 / kCullGroup survivors, so its
-    // lanes are dense; workgroups behind a segment's survivors have nothing to do
+    // lanes are dense; workgroups behind a segment's survivors have nothing to do.  The grid holds batch.seg_blocks[gi]
+    // workgroups per segment -- room for half of the groups to survive, not for all: at 10 M triangles three quarters
+    // of a worst-case grid were workgroups that found nothing, 120 000 waves to launch and retire -- and a wave whose
+    // segment holds more than that comes round again (the loop at the end)
     constexpr uint32_t kPerWave = 64u / kCullGroup;
     uint32_t n_live = 0, seg = 0, seg_block = 0;
     if (CULLED) {
@@ -334,14 +337,15 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     //      (rocprofv3: the waves of this kernel spend half their lifetime in s_waitcnt; eight vector loads per wave)
     uint32_t k = 0xFFFFFFFFu;
     bool live_wave = true;
+    uint32_t rank = 0, live_waves = 0;   // CULLED: this wave among its segment's, and how many the segment needs
     if (CULLED) {
-        const uint32_t rank = seg_block * (kBlock / 64) + w;   // this wave among the segment's waves
+        rank = seg_block * (kBlock / 64) + w;
         if (COUNT && rank == 0 && lane == 0) atomicAdd(&stats[1], (unsigned long long)n_live);   // counts[2]: surviving groups
         live_wave = rank * kPerWave < n_live;              // the survivors' last workgroup is partly filled
         // a wave's groups are taken at a stride of the number of live waves: a segment's list follows the mesh order, and
         // the cells a group expands to vary by orders of magnitude with its distance from the sensor -- consecutive groups
         // would make a few waves next to the sensor walk ten times the cells of the others (and the kernel wait for them)
-        const uint32_t live_waves = (n_live + kPerWave - 1u) / kPerWave;
+        live_waves = (n_live + kPerWave - 1u) / kPerWave;
         const uint32_t e = pp.spread ? (lane / kCullGroup) * live_waves + rank : rank * kPerWave + lane / kCullGroup;
         if (live_wave && e < n_live)
             k = cull_list[batch.list_first[gi] + seg * batch.seg_cap[gi] + e] * kCullGroup + (lane % kCullGroup);
@@ -361,15 +365,18 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         }
     }
     float raw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // the three corners as uploaded (mesh space)
-    if (k < src.ntris) {
-        const uint32_t a = src.idx[3 * (size_t)k + 0], b = src.idx[3 * (size_t)k + 1], c = src.idx[3 * (size_t)k + 2];
-        const float *pa = reinterpret_cast<const float *>(src.verts + (size_t)a * src.stride);
-        const float *pb = reinterpret_cast<const float *>(src.verts + (size_t)b * src.stride);
-        const float *pc = reinterpret_cast<const float *>(src.verts + (size_t)c * src.stride);
-        raw[0] = pa[0]; raw[1] = pa[1]; raw[2] = pa[2];
-        raw[3] = pb[0]; raw[4] = pb[1]; raw[5] = pb[2];
-        raw[6] = pc[0]; raw[7] = pc[1]; raw[8] = pc[2];
-    }
+    auto load_corners = [&]() {
+        if (k < src.ntris) {
+            const uint32_t a = src.idx[3 * (size_t)k + 0], b = src.idx[3 * (size_t)k + 1], c = src.idx[3 * (size_t)k + 2];
+            const float *pa = reinterpret_cast<const float *>(src.verts + (size_t)a * src.stride);
+            const float *pb = reinterpret_cast<const float *>(src.verts + (size_t)b * src.stride);
+            const float *pc = reinterpret_cast<const float *>(src.verts + (size_t)c * src.stride);
+            raw[0] = pa[0]; raw[1] = pa[1]; raw[2] = pa[2];
+            raw[3] = pb[0]; raw[4] = pb[1]; raw[5] = pb[2];
+            raw[6] = pc[0]; raw[7] = pc[1]; raw[8] = pc[2];
+        }
+    };
+    load_corners();
     ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
     if (LDS_TABLES) {
         const uint32_t V = pp.tb.V;
@@ -387,6 +394,8 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     TL_MARK(tl_1);   // tables staged
     TL_LOADS_LANDED(raw, best);
     TL_MARK(tl_2);
+    uint32_t total = 0;
+    for (;;) {   // (once, except for a CULLED wave whose segment holds more survivors than the grid has room for)
     uint32_t cells = 0, slot = 0;
     if (k < src.ntris) {
         V3 v0, v1, v2;
@@ -455,7 +464,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     TL_MARK(tl_3);   // footprints done
     // wave-level inclusive scan of the cell counts
     const uint32_t incl = wave_inclusive_scan(cells);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const uint32_t n_slots = (uint32_t)__popcll(__ballot(cells != 0));
     if (cells) s_pref[w][slot] = incl - cells;
     wave_lds_fence();
@@ -482,6 +491,13 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         wave_lds_fence();
     }
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
+    if (!CULLED) break;
+    rank += batch.seg_blocks[gi] * (kBlock / 64);   // the segment's next wave-load that nobody else takes
+    if (rank * kPerWave >= n_live) break;
+    const uint32_t e = pp.spread ? (lane / kCullGroup) * live_waves + rank : rank * kPerWave + lane / kCullGroup;
+    k = e < n_live ? cull_list[batch.list_first[gi] + seg * batch.seg_cap[gi] + e] * kCullGroup + (lane % kCullGroup) : 0xFFFFFFFFu;
+    load_corners();
+    }
     TL_MARK(tl_4);
     TL_END(block_idx, w, lane, total);
 }
@@ -778,9 +794,10 @@ __device__ __forceinline__ bool chan_query(const ChanQuery &cq, float tan_lo, fl
 // two-term vectors: the first-order half width is  hx |g.x + sx g.z| + hy |g.y + sy g.z| + hz |g.z|,  a dozen
 // operations instead of three transformed edge vectors and their radial / tangential projections.  Second order:
 // |R| <= (ez eps + (|z'| + ez) 2 eps^2) / rho  for eps = (er + et) / rho < 1/4  with the box's radial + tangential and
-// vertical half extents; both are bounded by the box's radius  rad = nrm (hx (1 + |sx|) + hy (1 + |sy|) + hz)
-// (er + et <= sqrt 2 rad, ez <= rad), and the bound is monotone in them.  The same radius bounds the reach of the box
-// seen from above (azimuth-sector test of a shard).  Everything is a bound with slack: approximate rsq / products are fine.
+// vertical half extents.  ez = sum |row 3 of L . e_i| is cheap and kept exact (a flat patch of ground has next to none);
+// er + et <= sqrt 2 rad with the box's radius  rad = nrm (hx (1 + |sx|) + hy (1 + |sy|) + hz),  nrm = the largest
+// singular value of L (1 for a rigid pose; from the host), and the bound is monotone in it.  The same radius bounds the
+// reach of the box seen from above (azimuth-sector test of a shard).  Everything is a bound with slack: approximate rsq / products are fine.
 template <bool LUT>
 __device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, const ChanQuery &cq, const LinearMap &m, float4 b0, float4 b1)
 {
@@ -800,6 +817,9 @@ __device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, cons
     const float gy = fmaf(m.l[1], ax, fmaf(m.l[4], ay, m.l[7] * inv_rho));
     const float gz = fmaf(m.l[2], ax, fmaf(m.l[5], ay, m.l[8] * inv_rho));
     const float w = fmaf(hx, fabsf(fmaf(sx, gz, gx)), fmaf(hy, fabsf(fmaf(sy, gz, gy)), hz * fabsf(gz)));
+    // vertical half extent of the box in the sensor frame (exact to rounding: a flat patch of ground has next to none,
+    // and it multiplies the larger of the two second-order terms), and its radius
+    const float ez = fmaf(hx, fabsf(fmaf(sx, m.l[8], m.l[6])), fmaf(hy, fabsf(fmaf(sy, m.l[8], m.l[7])), hz * fabsf(m.l[8]))) * 1.00001f;
     const float rad = m.nrm * fmaf(hx, 1.0f + fabsf(sx), fmaf(hy, 1.0f + fabsf(sy), hz)) * 1.00001f;
     bool out_of_sector = false;
     if (pp.sector_on) {   // uniform
@@ -810,7 +830,7 @@ __device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, cons
     }
     const float eps = 1.4142137f * rad * inv_rho;
     const bool near_axis = !(eps < 0.25f);   // next to the vertical axis: no first-order bound
-    const float rem = fmaf(rad, eps, (fabsf(cz) + rad) * 2.0f * eps * eps) * inv_rho;
+    const float rem = fmaf(ez, eps, (fabsf(cz) + ez) * 2.0f * eps * eps) * inv_rho;
     const float half = fmaf(w + rem, 1.0001f, 3e-6f * (fabsf(fc) + 1e-3f));   // rounding of the two dozen products above
     const bool some_channel = chan_query<LUT>(cq, fc - half, fc + half);
     return unbounded | on_axis | (!out_of_sector & (near_axis | some_channel));
@@ -1224,6 +1244,8 @@ uint32_t project_tris_per_wave(uint32_t ntris)
 }
 
 namespace {
+uint32_t cull_grid_pct() { static const uint32_t v = (uint32_t)std::min(100, std::max(1, lsi::tune_int("LS_PROJECT_CULL_GRID_PCT", 50))); return v; }
+
 // workgroups of k_cull that are resident at once: 8 per CU (four waves each, ~9 KB of LDS)
 uint32_t cull_resident_workgroups()
 {
@@ -1243,19 +1265,29 @@ LinearMap linear_map(const GeomSource &src)
     if (src.xform == 0) {
         for (int i = 0; i < 9; ++i) m.l[i] = (i % 4 == 0) ? 1.f : 0.f;
         m.o[0] = m.o[1] = m.o[2] = 0.f;
-        m.nrm = 1.7320509f;
+        m.nrm = 1.00001f;
         return m;
     }
     const Affine &a = src.m;
-    double sq = 0.0;
     for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 3; ++j)
             m.l[3 * i + j] = a.rinv[3 * i] * a.a[j] + a.rinv[3 * i + 1] * a.a[4 + j] + a.rinv[3 * i + 2] * a.a[8 + j];
-            sq += (double)m.l[3 * i + j] * (double)m.l[3 * i + j];
-        }
         m.o[i] = a.rinv[3 * i] * (a.a[3] - a.t[0]) + a.rinv[3 * i + 1] * (a.a[7] - a.t[1]) + a.rinv[3 * i + 2] * (a.a[11] - a.t[2]);
     }
-    m.nrm = (float)(std::sqrt(sq) * 1.00001);
+    // an upper bound of the largest singular value of L: the largest absolute row sum of L^T L bounds its largest eigenvalue
+    // (exactly 1 for a rigid pose, where L^T L is the identity); it only scales a radius that enters second-order terms and
+    // the sector reach
+    double top = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        double row = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            double sij = 0.0;
+            for (int k = 0; k < 3; ++k) sij += (double)m.l[3 * k + i] * (double)m.l[3 * k + j];
+            row += std::fabs(sij);
+        }
+        top = std::max(top, row);
+    }
+    m.nrm = (float)(std::sqrt(top) * 1.00001);
     return m;
 }
 
@@ -1288,7 +1320,10 @@ bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch
         batch.cull_first[batch.n] = cull_blocks;
         batch.seg_cap[batch.n] = seg_cap;
         batch.g[batch.n] = src;
-        blocks += kCullSegs * (seg_cap / kGroupsPerWorkgroup);
+        // k_project's workgroups per segment: room for cull_grid_pct() % of the groups to survive (a wave loops when more do)
+        const uint32_t seg_blocks = std::max(1u, (uint32_t)(((unsigned long long)(seg_cap / kGroupsPerWorkgroup) * cull_grid_pct() + 99u) / 100u));
+        batch.seg_blocks[batch.n] = seg_blocks;
+        blocks += kCullSegs * seg_blocks;
         entries += kCullSegs * seg_cap;
         cull_blocks += cull_wgs;
         ++batch.n;

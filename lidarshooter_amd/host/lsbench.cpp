@@ -57,7 +57,7 @@ int upload(DeviceMesh& m, const void* verts, size_t vbytes, const uint32_t* tris
 
 namespace {
 std::string config, group_mode = "sharded";
-std::vector<std::pair<std::string, std::string>> mesh_files;
+std::vector<std::pair<std::string, std::string>> mesh_files, raw_files;
 int synV = 0, synH = 0, gridX = 0, gridY = 0, frames = 200, warmup = 50, pipeline = 0, engine = 0, ranks = 0;
 int run(int rank, int world, const std::string& id_path, int result_fd);
 }  // namespace
@@ -69,6 +69,7 @@ int main(int argc, char** argv)
         auto need = [&](int n) { if (i + n >= argc) { std::fprintf(stderr, "%s: missing value\n", a.c_str()); std::exit(2); } };
         if (a == "--config") { need(1); config = argv[++i]; }
         else if (a == "--mesh") { need(1); const std::string v = argv[++i]; const auto eq = v.find('='); mesh_files.push_back({v.substr(0, eq), v.substr(eq + 1)}); }
+        else if (a == "--mesh-raw") { need(1); const std::string v = argv[++i]; const auto eq = v.find('='); raw_files.push_back({v.substr(0, eq), v.substr(eq + 1)}); }
         else if (a == "--syn") { need(2); synV = std::atoi(argv[++i]); synH = std::atoi(argv[++i]); }
         else if (a == "--grid") { need(2); gridX = std::atoi(argv[++i]); gridY = std::atoi(argv[++i]); }
         else if (a == "--frames") { need(1); frames = std::atoi(argv[++i]); }
@@ -161,7 +162,8 @@ int run(int rank, int world, const std::string& id_path, int result_fd)
     std::vector<float> syn_vertical;
     if (synV > 0 && synH > 1) {
         syn_vertical.resize(synV);
-        for (int v = 0; v < synV; ++v) syn_vertical[v] = 15.0f - static_cast<float>(v) * (40.0f / static_cast<float>(synV > 1 ? synV - 1 : 1));
+        // lidarshooter_amd/synth.py syn_vertical: float64 arithmetic, then one rounding to float32 (bit-identical channel angles)
+        for (int v = 0; v < synV; ++v) syn_vertical[v] = static_cast<float>(15.0 - static_cast<double>(v) * (40.0 / static_cast<double>(synV > 1 ? synV - 1 : 1)));
         sd.vertical_deg = syn_vertical.data();
         sd.n_vertical = static_cast<uint32_t>(synV);
         sd.h_begin = 0.0f;
@@ -186,6 +188,30 @@ int run(int rank, int world, const std::string& id_path, int result_fd)
         m.n_verts = pm.cloud.width * pm.cloud.height;
         m.n_tris = static_cast<uint32_t>(pm.polygons.size());
         if (upload(m, pm.cloud.data.data(), pm.cloud.data.size(), idx.data(), idx.size() * 4)) return 2;
+        meshes.push_back(m);
+    }
+    // raw dumps written by tools/dump_mesh.py: "LSMESH1\0", uint32 n_verts, uint32 n_tris, float32 xyz[n_verts], uint32 idx[3 n_tris]
+    // -- BASELINE.md's synthetic meshes bit for bit as lidarshooter_amd/synth.py makes them (numpy's generator and its
+    // vectorised sin / cos are not reproducible from C++; --grid below is a look-alike with its own noise)
+    for (const auto& rf : raw_files) {
+        FILE* f = std::fopen(rf.second.c_str(), "rb");
+        char magic[8];
+        uint32_t nv = 0, nt = 0;
+        if (!f || std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "LSMESH1", 8) != 0 || std::fread(&nv, 4, 1, f) != 1 ||
+            std::fread(&nt, 4, 1, f) != 1) {
+            std::fprintf(stderr, "cannot read raw mesh %s\n", rf.second.c_str());
+            return 2;
+        }
+        std::vector<float> v(static_cast<size_t>(nv) * 3);
+        std::vector<uint32_t> t(static_cast<size_t>(nt) * 3);
+        const bool ok = std::fread(v.data(), 4, v.size(), f) == v.size() && std::fread(t.data(), 4, t.size(), f) == t.size();
+        std::fclose(f);
+        if (!ok) { std::fprintf(stderr, "raw mesh %s is truncated\n", rf.second.c_str()); return 2; }
+        DeviceMesh m;
+        m.name = rf.first;
+        m.n_verts = nv;
+        m.n_tris = nt;
+        if (upload(m, v.data(), v.size() * 4, t.data(), t.size() * 4)) return 2;
         meshes.push_back(m);
     }
     if (gridX > 0 && gridY > 0) {

@@ -233,3 +233,33 @@ def test_cull_stress_poses(oracle, capi, sensors):
     assert max(n_hits) > 50000 and len(set(n_hits)) > 3
     on.close()
     off.close()
+
+
+def test_cull_when_nearly_everything_survives(oracle, capi, sensors):
+    """A 540 000-triangle cylinder wall 10 m around the sensor, as tall as its field of view: every group of four triangles
+    subtends more than the ring spacing, so the survivor list is nearly the whole mesh -- more than the culled launch's grid
+    has workgroups for (it is sized for half of the groups to survive), and its waves come round again for the rest.  Also
+    as a shard.  Against the BVH engine."""
+    from lidarshooter_amd import synth
+    g, t = synth.grid_mesh(900, 300, half=1.0, seed=11, relief=0.0, noise=0.0)
+    s = _syn_sensor(oracle, sensors, V=128, H=512)
+    rng = np.random.default_rng(3)
+    ang = np.pi * g[:, 0].astype(np.float64) * (1.0 - 1e-4)          # the seam stays open by a hair: no coincident vertices
+    rad = 10.0 + rng.uniform(-0.05, 0.05, g.shape[0])
+    v = np.stack([float(s.t[0]) + rad * np.cos(ang), float(s.t[1]) + rad * np.sin(ang),
+                  float(s.t[2]) - 1.0 + 3.6 * g[:, 1].astype(np.float64)], axis=1).astype(np.float32)
+    pr, bvh = make_tracer(capi, s, "projection"), make_tracer(capi, s, "bvh")
+    pr.setOption(capi.LS_OPT_BLOCK_CULL, 1)
+    pr.setOption(capi.LS_OPT_COUNT_VISITS, 1)
+    for tr in (pr, bvh):
+        tr.addGeometry("wall", v.shape[0], t.shape[0])
+        tr.updateGeometry("wall", oracle.IDENTITY_AFFINE, v, t)
+    _same(_frame(pr), _frame(bvh))
+    groups = (t.shape[0] + 3) // 4
+    assert pr.visitStats()[2] > 0.6 * groups, "the scene is meant to keep most groups alive"
+    pr.setOption(capi.LS_OPT_COUNT_VISITS, 0)
+    for tr in (pr, bvh):
+        tr.setShard(100, 200)
+    _same(_frame(pr), _frame(bvh))
+    pr.close()
+    bvh.close()

@@ -967,6 +967,32 @@ def test_lsbench_cpp_harness(oracle, sensors, meshes, uid, expected, mode):
     assert rec["hits_sha256"] == hashlib.sha256(np.ascontiguousarray(ref["hits"], np.uint32).tobytes()).hexdigest()
 
 
+def test_lsbench_raw_mesh_is_the_python_mesh(oracle, sensors, tmp_path):
+    """lsbench --mesh-raw: the C++ harness traces a mesh of lidarshooter_amd/synth.py bit for bit (tools/dump_mesh.py writes
+    it out; numpy's generator cannot be reproduced from C++) -- its cloud hashes to the oracle's for the same arrays, which is
+    what makes lsbench's SYN-1M numbers comparable with bench.py's (--grid is a look-alike)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import DATA, ROOT
+    from lidarshooter_amd import synth
+    raw = str(tmp_path / "grid.lsmesh")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dump_mesh.py"), "grid:400x300", raw], check=True, capture_output=True)
+    exe = os.path.join(ROOT, "lidarshooter_amd", "lsbench")
+    out = subprocess.run([exe, "--config", os.path.join(DATA, "config", "hesai-pandar-XT-32-lidar_0001.json"), "--syn", "64", "512",
+                          "--mesh-raw", "grid=" + raw, "--frames", "40", "--warmup", "5", "--pipeline", "2"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    v, t = synth.grid_mesh(400, 300)
+    base = sensors["0001"]
+    s = oracle.Sensor(uid="syn", vertical=synth.syn_vertical(64), h_begin=np.float32(0.0), h_end=np.float32(360.0), h_count=512,
+                      R=base.R, Rinv=base.Rinv, t=base.t)
+    ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True)
+    assert rec["triangles"] == t.shape[0] and rec["points_last_frame"] == ref["points"].shape[0]
+    assert rec["points_sha256"] == hashlib.sha256(ref["points"].tobytes()).hexdigest()
+
+
 def test_edge_cases(oracle, capi, sensors, engine):
     """Degenerate inputs: one-triangle scene (a BVH with no internal node), coincident triangles in two
     geometries (equal t: lowest geomID wins), a geometry with zero triangles next to a real one, a

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the BVH-engine headline frame -> gpurun_out/final/<tag>_bvh_kernel_stats.csv (GPU box, repo root)
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_${TAG}_bvh
 mkdir -p "$OUT" "$REPO/gpurun_out/final"

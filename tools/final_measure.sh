@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, in one go (GPU box, repo root):  bash tools/final_measure.sh r02
-TAG=${1:-r02}
+# Everything profiles/ holds for a round, in one go (GPU box, repo root):  bash tools/final_measure.sh r03
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
 mkdir -p gpurun_out/final
@@ -10,12 +10,13 @@ python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m > gpurun_out
 python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m --no-cull > gpurun_out/final/bench_${TAG}_projection_10m_nocull.json 2>> gpurun_out/final/bench.err
 python bench.py --no-cpu-baseline --no-dropin --workload cfg5 > gpurun_out/final/bench_${TAG}_projection_cfg5.json 2>> gpurun_out/final/bench.err
 python bench.py --no-cpu-baseline --workload xt32 > gpurun_out/final/bench_${TAG}_projection_xt32.json 2>> gpurun_out/final/bench.err
+python tools/dump_mesh.py syn1m /tmp/syn1m.lsmesh   # lsbench traces bench.py's SYN-1M bit for bit (its --grid is a look-alike)
 for p in 0 1 2; do
-  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --grid 1000 500 --frames 2000 --warmup 200 --pipeline $p
+  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 2000 --warmup 200 --pipeline $p
 done > gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --mesh ground=tests/golden/data/mesh/ground.stl --mesh face=tests/golden/data/mesh/ben.stl --frames 5000 --warmup 200 --pipeline 1 >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 for g in sharded interleaved; do
-  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --grid 1000 500 --frames 1000 --warmup 100 --ranks 1 --group $g
+  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 1000 --warmup 100 --ranks 1 --group $g
 done >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 python tools/dropin_bench.py 50 > gpurun_out/final/dropin_${TAG}.json 2>> gpurun_out/final/bench.err
 bash tools_profile.sh ${TAG} > gpurun_out/final/profile.log 2>&1
