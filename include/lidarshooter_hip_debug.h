@@ -32,6 +32,10 @@ int ls_debug_download_scene(ls_tracer *tr, float *verts_xyz, uint32_t *tri_idx);
  *   triangle record: float v0[3]; uint32 gid; float e1[3]; float NgC; float e2[3]; uint32 pad */
 int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records);
 
+/* The build path's radix sort on its own (ls_sort.hip): sorts n (key, value) pairs by their 30-bit keys in place (host
+ * arrays; stable: equal keys keep their input order). */
+int ls_debug_sort_pairs(ls_tracer *tr, uint32_t *keys, uint32_t *vals, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

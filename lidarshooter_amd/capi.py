@@ -42,7 +42,7 @@ SYMBOLS = (
 )
 # include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
 DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",
-                 "ls_debug_download_bvh")
+                 "ls_debug_download_bvh", "ls_debug_sort_pairs")
 
 
 class SensorDesc(C.Structure):
@@ -152,6 +152,7 @@ def load() -> C.CDLL:
     L.ls_debug_scene_size.argtypes = [vp, u32p, u32p, u32p, u32p]
     L.ls_debug_download_scene.argtypes = [vp, vp, vp]
     L.ls_debug_download_bvh.argtypes = [vp, vp, vp]
+    L.ls_debug_sort_pairs.argtypes = [vp, vp, vp, u32]
     _lib = L
     return L
 
@@ -385,6 +386,12 @@ class Tracer:
         self._check(self.L.ls_debug_trace_bruteforce(self.h, _f32p(t), gid.ctypes.data_as(C.POINTER(C.c_uint32))),
                     "ls_debug_trace_bruteforce")
         return t, gid
+
+    def sortPairs(self, keys: np.ndarray, vals: np.ndarray):
+        """The build path's radix sort on its own: -> (sorted keys, values); stable, 30-bit keys."""
+        k, v = np.ascontiguousarray(keys, np.uint32).copy(), np.ascontiguousarray(vals, np.uint32).copy()
+        self._check(self.L.ls_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, k.shape[0]), "ls_debug_sort_pairs")
+        return k, v
 
     def sceneSize(self):
         v = [C.c_uint32() for _ in range(4)]

@@ -85,4 +85,28 @@ int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records)
     return LS_OK;
 }
 
+int ls_debug_sort_pairs(ls_tracer *tr, uint32_t *keys, uint32_t *vals, uint32_t n)
+{
+    LS_ENTER(tr);
+    if ((!keys || !vals) && n) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
+    if (!n) return LS_OK;
+    uint32_t *d = nullptr;
+    void *temp = nullptr;
+    const size_t tb = ls::sort_temp_bytes(n);
+    LS_HIP(hipMalloc(reinterpret_cast<void **>(&d), (size_t)n * 16));
+    hipError_t e = hipMalloc(&temp, tb);
+    if (e == hipSuccess) e = hipMemcpy(d, keys, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, vals, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ls::launch_sort(tr->stream, temp, tb, d, d + 2 * (size_t)n, d + n, d + 3 * (size_t)n, n);
+        e = hipStreamSynchronize(tr->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(keys, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(vals, d + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    (void)hipFree(temp);
+    if (e != hipSuccess) return fail(tr, LS_ERR_HIP, hipGetErrorString(e));
+    return LS_OK;
+}
+
 }  // extern "C"

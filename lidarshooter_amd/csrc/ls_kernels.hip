@@ -21,7 +21,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace ls {
 
@@ -981,26 +980,6 @@ void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint
     if (!ntris) return;
     hipLaunchKernelGGL(k_morton, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, ntris, d_maxabs_bits,
                        keys, vals);
-}
-
-// rocprim's default configuration falls back to a merge sort up to 2^20 items (10 merge passes
-// at 1M triangles); 30-bit keys sort in 4 onesweep radix passes instead.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::default_config, 32768>;
-
-size_t sort_temp_bytes(uint32_t n)
-{
-    size_t bytes = 0;
-    uint32_t *p = nullptr;
-    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, p, p, p, p, (size_t)n, 0u, 30u);
-    return bytes;
-}
-
-void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out,
-                 uint32_t *vals_in, uint32_t *vals_out, uint32_t n)
-{
-    if (!n) return;
-    (void)rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 30u, s);
 }
 
 void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,

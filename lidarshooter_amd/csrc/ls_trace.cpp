@@ -86,7 +86,26 @@ int pick_slot_streams(ls_tracer *tr)
     constexpr int kCandidates = 8;
     constexpr unsigned long long kTicks = 20000;   // 200 us
     hipStream_t cand[kCandidates] = {};
-    for (auto &c : cand) LS_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    // Experiment (LS_EXPERIMENTAL builds, LS_CU_MASK_MODE): the three frames in flight on disjoint thirds of the CUs
+    // (hipExtStreamCreateWithCUMask), 1 = every third CU, 2 = contiguous thirds -- side by side instead of interleaving
+    // phases on every CU.  Candidate c takes third c % 3; the three streams chosen below must hold three different thirds.
+    const int mask_mode = tune_int("LS_CU_MASK_MODE", 0);
+    int third_of[kCandidates];
+    {
+        int n_cu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, tr->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        for (int c = 0; c < kCandidates; ++c) {
+            third_of[c] = mask_mode ? c % 3 : -1 - c;
+            if (!mask_mode) { LS_HIP(hipStreamCreateWithFlags(&cand[c], hipStreamNonBlocking)); continue; }
+            std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+            for (int i = 0; i < n_cu; ++i) {
+                const bool mine = mask_mode == 1 ? i % 3 == c % 3 : (i * 3) / n_cu == c % 3;
+                if (mine) mask[(size_t)i / 32] |= 1u << (i % 32);
+            }
+            LS_HIP(hipExtStreamCreateWithCUMask(&cand[c], (uint32_t)mask.size(), mask.data()));
+        }
+    }
     hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
     LS_HIP(hipEventCreate(&e0));
     LS_HIP(hipEventCreate(&ea));
@@ -115,6 +134,7 @@ int pick_slot_streams(ls_tracer *tr)
     int chosen[3] = {0, -1, -1}, n = 1;
     for (int c = 1; c < kCandidates && n < 3; ++c) {
         bool ok = true;
+        for (int k = 0; k < n && ok; ++k) ok = third_of[chosen[k]] != third_of[c];
         for (int k = 0; k < n && ok; ++k) {
             double us;
             if ((rc = pair_us(cand[chosen[k]], cand[c], us))) return rc;

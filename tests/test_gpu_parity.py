@@ -261,6 +261,29 @@ def test_bvh_structure(oracle, capi, sensors, meshes):
     tr.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 2047, 2048, 2049, 100003, (2 << 20) + 77])
+def test_build_sort_is_a_stable_radix_sort(capi, sensors, n):
+    """ls_sort.hip (the hand-written sort of the (re)build path) against numpy's stable argsort: 30-bit keys with the
+    heavy ties a Morton order has (few distinct values in the top digits), tile edges (2 048-key tiles up to 2 M pairs,
+    8 192 above), ragged tails; equal keys keep their input order."""
+    rng = np.random.default_rng(n)
+    tr = make_tracer(capi, sensors["0000"])
+    for kind in ("random", "ties", "sorted", "one_value"):
+        if kind == "random":
+            keys = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+        elif kind == "ties":
+            keys = (rng.integers(0, 7, n, dtype=np.uint32) << 24) | (rng.integers(0, 3, n, dtype=np.uint32) << 9)
+        elif kind == "sorted":
+            keys = np.sort(rng.integers(0, 1 << 30, n, dtype=np.uint32))[::-1].copy()
+        else:
+            keys = np.full(n, 0x2AAAAAAA, np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        k, v = tr.sortPairs(keys, vals)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(k, keys[order]) and np.array_equal(v, vals[order]), kind
+    tr.close()
+
+
 def test_raygen_kernel(oracle, capi, sensors):
     # LidarDevice::allRaysGPU (LidarDeviceKernels.cu:25-126) vs the libm tables of the CPU path
     import torch
