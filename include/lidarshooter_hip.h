@@ -179,6 +179,17 @@ int ls_trace_scene(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
  * stream when the call returns -- unless LS_OPT_PIPELINE keeps several frames in flight (see there). */
 int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
 
+/* traceScene for a caller whose cloud lives in ordinary host memory (PointCloud2::data, EmbreeTracer.cpp:297-367), in two
+ * steps that overlap the device, the PCIe link and the host:
+ *   ls_trace_scene_begin   launches the frame and returns as soon as the HIT COUNT is known -- the pack pass is still
+ *                          running -- so that the caller can size its cloud (data.resize(32 * n_points)) meanwhile;
+ *   ls_trace_scene_expand  writes the n_points 32-byte records (XYZIRBytes.cpp:24-40) to dst_points32 with the library's
+ *                          worker threads: the first half of the cloud while the second half is still crossing PCIe as
+ *                          16-byte compact records.  Returns when the cloud is complete.
+ * Same results as ls_trace_scene + ls_expand_points; -1 / zero points on an empty scene.  One frame in flight. */
+int ls_trace_scene_begin(ls_tracer *tr, uint32_t frame_index, uint32_t *n_points);
+int ls_trace_scene_expand(ls_tracer *tr, void *dst_points32);
+
 /* ---- ITracer::getGeometryCount (ITracer.hpp:101) */
 long ls_geometry_count(ls_tracer *tr);
 

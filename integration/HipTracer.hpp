@@ -142,17 +142,24 @@ public:
         auto cloud = getTraceCloud();
         getSensorConfig()->initMessage(cloud, static_cast<int>(_frameIndex));
         getSensorConfig()->reset();
-        ls_frame frame;
-        const int rc = ls_trace_scene(_handle, _frameIndex, &frame);
+        // two steps: the hit count comes back while the points are still being packed on the device; the cloud is sized
+        // meanwhile, then filled -- its first half while the second half is still crossing PCIe
+        std::uint32_t n_points = 0;
+        const int rc = ls_trace_scene_begin(_handle, _frameIndex, &n_points);
         if (rc < -1) {
             cloud->data.clear();
             throw TraceException(__FILE__, ls_last_error(_handle), rc);
         }
         // no clear() first: shrinking costs nothing and growing value-initialises only the difference
-        const std::size_t bytes = static_cast<std::size_t>(frame.n_points) * 32u;
-        cloud->data.resize(bytes);
-        if (bytes != 0) ls_expand_points(cloud->data.data(), frame.compact16, frame.n_points);
-        cloud->width = frame.n_points;   // EmbreeTracer.cpp:364; height 1, row_step 0 from initMessage
+        cloud->data.resize(static_cast<std::size_t>(n_points) * 32u);
+        if (rc >= 0) {
+            const int erc = ls_trace_scene_expand(_handle, cloud->data.data());
+            if (erc < 0) {
+                cloud->data.clear();
+                throw TraceException(__FILE__, ls_last_error(_handle), erc);
+            }
+        }
+        cloud->width = n_points;   // EmbreeTracer.cpp:364; height 1, row_step 0 from initMessage
         return rc;
     }
 

@@ -38,7 +38,7 @@ SYMBOLS = (
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
     "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
-    "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type", "ls_tracer_order_after_last_frame", "ls_tracer_wait_event",
+    "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type", "ls_tracer_order_after_last_frame", "ls_tracer_wait_event", "ls_trace_scene_begin", "ls_trace_scene_expand",
 )
 # include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
 DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",
@@ -118,6 +118,8 @@ def load() -> C.CDLL:
     L.ls_commit_scene.argtypes = [vp]
     L.ls_trace_scene.argtypes = [vp, u32, C.POINTER(Frame)]
     L.ls_trace_scene_async.argtypes = [vp, u32, C.POINTER(Frame)]
+    L.ls_trace_scene_begin.argtypes = [vp, u32, u32p]
+    L.ls_trace_scene_expand.argtypes = [vp, vp]
     L.ls_geometry_count.argtypes = [vp]
     L.ls_geometry_count.restype = C.c_long
     L.ls_geometry_id.argtypes = [vp, C.c_char_p]
@@ -272,6 +274,17 @@ class Tracer:
             hits = np.zeros(0, HIT_DTYPE)
         self.last_frame = fr
         return rc, pts, hits
+
+    def traceSceneTwoStep(self, frame_index: int = 0):
+        """ls_trace_scene_begin + ls_trace_scene_expand into a numpy buffer: -> (rc, points uint8[n,32])"""
+        n = C.c_uint32()
+        rc = self.L.ls_trace_scene_begin(self.h, frame_index, C.byref(n))
+        if rc < -1:
+            self._check(rc, "ls_trace_scene_begin")
+        pts = np.empty((int(n.value), 32), np.uint8)
+        if rc >= 0:
+            self._check(self.L.ls_trace_scene_expand(self.h, pts.ctypes.data), "ls_trace_scene_expand")
+        return rc, pts
 
     def traceSceneAsync(self, frame_index: int = 0) -> Frame:
         fr = Frame()

@@ -153,6 +153,9 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_status), 16) != hipSuccess) return bail(LS_ERR_HIP);
     *tr->h_status = 0u;
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_progress), sizeof(ls::HostProgress)) != hipSuccess) return bail(LS_ERR_HIP);
+    std::memset(tr->h_progress, 0, sizeof(ls::HostProgress));
+
     tr->slot_tri_first.assign(1, 0u);
     *out = tr;
     return LS_OK;
@@ -241,6 +244,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     if (tr->h_hits) (void)hipHostFree(tr->h_hits);
     if (tr->h_n_points) (void)hipHostFree(tr->h_n_points);
     if (tr->h_status) (void)hipHostFree(tr->h_status);
+    if (tr->h_progress) (void)hipHostFree(tr->h_progress);
     for (auto &r : tr->trec)
         for (auto &e : r.ev)
             if (e) (void)hipEventDestroy(e);

@@ -4,6 +4,7 @@
 #include "ls_host_pool.h"
 
 #include <algorithm>
+#include <emmintrin.h>
 #include <cstdlib>
 #include <functional>
 
@@ -25,6 +26,42 @@ void parallel_copy(void *dst, const void *src, size_t bytes)
 
 int host_pool_threads() { return HostPool::get().threads(); }
 
+// XYZIRBytes.cpp:24-40: x@0 y@4 z@8 0@12 intensity@16 ring@20 0@24..31; intensity is the constant 64.0 (EmbreeTracer.cpp:343).
+// 16-byte records (x, y, z, ring) in, 32-byte records out; the destination is written once and not read again by this
+// code, so the stores bypass the cache when both sides are 16-byte aligned (no read-for-ownership of 8 MB per frame)
+void expand_points_range(uint8_t *dst_points32, const uint8_t *compact16, size_t cnt)
+{
+    const float intensity = 64.0f;
+    uint32_t ibits;
+    std::memcpy(&ibits, &intensity, 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(compact16);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(dst_points32);
+    if ((reinterpret_cast<uintptr_t>(dst_points32) & 15u) == 0 && (reinterpret_cast<uintptr_t>(compact16) & 15u) == 0) {
+        const __m128i keep_xyz = _mm_set_epi32(0, -1, -1, -1), keep_ring = _mm_set_epi32(0, 0, -1, 0);
+        const __m128i intensity_lane = _mm_set_epi32(0, 0, 0, (int)ibits);
+        for (size_t k = 0; k < cnt; ++k) {
+            const __m128i v = _mm_load_si128(reinterpret_cast<const __m128i *>(src + 4 * k));          // x y z ring
+            const __m128i ring = _mm_and_si128(_mm_shuffle_epi32(v, _MM_SHUFFLE(0, 0, 3, 0)), keep_ring);   // 0 ring 0 0
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + 8 * k), _mm_and_si128(v, keep_xyz));   // x y z 0
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + 8 * k + 4), _mm_or_si128(ring, intensity_lane));   // 64.0 ring 0 0
+        }
+        _mm_sfence();
+        return;
+    }
+    for (size_t k = 0; k < cnt; ++k) {
+        dst[8 * k + 0] = src[4 * k + 0];
+        dst[8 * k + 1] = src[4 * k + 1];
+        dst[8 * k + 2] = src[4 * k + 2];
+        dst[8 * k + 3] = 0u;
+        dst[8 * k + 4] = ibits;
+        dst[8 * k + 5] = src[4 * k + 3];
+        dst[8 * k + 6] = 0u;
+        dst[8 * k + 7] = 0u;
+    }
+}
+
+void pool_run(size_t n, const std::function<void(size_t)> &fn) { HostPool::get().run(n, fn); }
+
 }  // namespace lsi
 
 using namespace lsi;
@@ -34,26 +71,10 @@ extern "C" {
 int ls_expand_points(void *dst_points32, const void *compact16, uint32_t n_points)
 {
     if ((!dst_points32 || !compact16) && n_points) return LS_ERR_INVALID_ARGUMENT;
-    // XYZIRBytes.cpp:24-40: x@0 y@4 z@8 0@12 intensity@16 ring@20 0@24..31; intensity is the constant 64.0 (EmbreeTracer.cpp:343)
-    constexpr size_t kPer = 16384;   // points per work item: 256 KB read, 512 KB written
-    const size_t n = n_points, items = (n + kPer - 1) / kPer;
-    const float intensity = 64.0f;
-    uint32_t ibits;
-    std::memcpy(&ibits, &intensity, 4);
+    const size_t n = n_points, items = (n + kExpandItem - 1) / kExpandItem;
     const std::function<void(size_t)> work = [&](size_t i) {
-        const uint32_t *src = static_cast<const uint32_t *>(compact16) + 4 * i * kPer;
-        uint32_t *dst = static_cast<uint32_t *>(dst_points32) + 8 * i * kPer;
-        const size_t cnt = std::min(kPer, n - i * kPer);
-        for (size_t k = 0; k < cnt; ++k) {
-            dst[8 * k + 0] = src[4 * k + 0];
-            dst[8 * k + 1] = src[4 * k + 1];
-            dst[8 * k + 2] = src[4 * k + 2];
-            dst[8 * k + 3] = 0u;
-            dst[8 * k + 4] = ibits;
-            dst[8 * k + 5] = src[4 * k + 3];
-            dst[8 * k + 6] = 0u;
-            dst[8 * k + 7] = 0u;
-        }
+        expand_points_range(static_cast<uint8_t *>(dst_points32) + 32 * i * kExpandItem, static_cast<const uint8_t *>(compact16) + 16 * i * kExpandItem,
+                            std::min(kExpandItem, n - i * kExpandItem));
     };
     HostPool::get().run(items, work);
     return LS_OK;

@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -192,6 +193,14 @@ struct ls_tracer {
     int opt_upload_mode = 1;     // LS_OPT_UPLOAD_MODE
     int opt_debug_fault = 0;     // LS_OPT_DEBUG_FAULT (one frame)
     uint32_t *h_status = nullptr;   // sticky device status word in pinned host memory (bit 0: chained prefix gave up)
+    // ls_trace_scene_begin / ls_trace_scene_expand: the device tells the host how far the frame is (ls::HostProgress)
+    ls::HostProgress *h_progress = nullptr;   // pinned host memory
+    uint32_t progress_epoch = 0;
+    bool progress_req = false;                // set by ls_trace_scene_begin around its trace_locked call
+    bool progress_active = false;             // the frame begun last reports through h_progress (else it is complete already)
+    bool begin_open = false;                  // a begun frame waits for its ls_trace_scene_expand
+    uint32_t begin_points = 0, begin_first = 0, begin_blocks = 0;
+    uint32_t pack_split = 0, pack_split_blocks = 0;   // ray block at which the pack pass's second launch starts, and the raster it was made for
     int concurrent_streams = 0;     // LS_OPT_PIPELINE = 2 calibration result (0 = not run yet)
 
     // options / measurement
@@ -272,6 +281,9 @@ int commit_locked(ls_tracer *tr);
 // ls_host_pool.cpp
 void parallel_copy(void *dst, const void *src, size_t bytes);
 int host_pool_threads();
+constexpr size_t kExpandItem = 16384;   // points per work item of an expansion: 256 KB read, 512 KB written
+void expand_points_range(uint8_t *dst_points32, const uint8_t *compact16, size_t count);
+void pool_run(size_t n, const std::function<void(size_t)> &fn);   // fn(0) .. fn(n-1) on the worker threads and the caller
 
 }  // namespace lsi
 

@@ -206,13 +206,32 @@ void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTab
                             const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
                             uint32_t *gid_out, uint32_t *spill, unsigned long long *visit_counts /* nullptr = do not count */);
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts);
+// Progress of a synchronous frame whose compact points go straight to pinned host memory (ls_trace_scene_begin /
+// ls_trace_scene_expand): the device publishes, with system-scope release, (1) the frame's hit count as the pack pass
+// starts (its first workgroup adds up the finish pass's block counts), together with the number of points the ray blocks
+// before `split` hold -- the caller sizes its cloud while the points are being packed --, then, in stream order behind
+// each of the pack pass's two launches (ray blocks before / from `split`), (2) "the first part has arrived" and (3) "all
+// have": the host expands the first part of the cloud while the second is still crossing PCIe.  The split that would have halved the POINTS comes back too (the
+// upper rings of a LiDAR mostly see sky): the next frame uses it.  One 64-byte line per group of words.
+struct HostProgress {
+    uint32_t total, n_first, even_split, total_epoch, pad0[12];   // even_split: the ray block at which the points halve
+    uint32_t half_epoch, pad1[15];
+    uint32_t all_epoch, pad2[15];
+};
+struct ProgressArgs {
+    HostProgress *host;   // pinned host memory; nullptr: no progress reporting
+    uint32_t epoch;       // this frame's tag (never 0)
+    uint32_t split;       // the pack pass's second launch starts at this ray block (the first one packs n_first points)
+};
+
 // compact != 0: points are written as 16-byte records (x, y, z, ring) instead of the 32-byte PointCloud2 layout
 void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,
                  const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact = 0);
 // projection engine: pack straight from the closest-hit keys (also re-arms keys, counters, queue)
 void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
                       const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
-                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact = 0);
+                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact = 0,
+                      const ProgressArgs *progress = nullptr);
 // projection engine: per-geometry streaming kernel, big-footprint kernel, resolve (+ row counts)
 size_t project_big_item_bytes();
 void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,

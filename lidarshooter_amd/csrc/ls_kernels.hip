@@ -18,6 +18,7 @@
 #include "ls_device.h"
 #include "ls_tuning.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -717,8 +718,12 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
                                                  const uint32_t *__restrict__ block_counts,
                                                  uint32_t *__restrict__ next_block_counts, uint32_t *__restrict__ big_count,
                                                  GeomTable gt, float4 *__restrict__ points, uint4 *__restrict__ hits,
-                                                 uint32_t *__restrict__ n_points, uint32_t compact)
+                                                 uint32_t *__restrict__ n_points, uint32_t compact, uint32_t block0, uint32_t n_blocks,
+                                                 ProgressArgs pg)
 {
+    // (block0, n_blocks: the launch covers ray blocks [block0, block0 + gridDim.x) of n_blocks -- a synchronous frame that
+    // reports its progress to the host packs its two halves in two launches, ls_trace_scene_expand)
+    const uint32_t block = blockIdx.x + block0;
     __shared__ uint32_t s_part[kBlock / 64];
     __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t nq = tb.V * tb.naz;
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     // every load of the kernel is issued up front -- the ray's key (or t / gid), its table entries, the first geometry
     // slot, then the counts of the blocks before this one -- so that the kernel is one memory round trip deep, not four
     // (it is a few microseconds long: round trips are what it consists of)
-    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t q = block * kBlock + threadIdx.x;
     uint32_t gid = kInvalid;
     float t = -1.0f;
     unsigned long long key = ~0ull;
@@ -748,7 +753,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     if (gt.n) { first0 = gt.tri_first[0]; geom0 = gt.geom_ids[0]; shift0 = gt.prim_shift[0]; }
 
     uint32_t acc = 0;
-    for (uint32_t r = threadIdx.x; r < blockIdx.x; r += kBlock) acc += block_counts[r];
+    for (uint32_t r = threadIdx.x; r < block; r += kBlock) acc += block_counts[r];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
 
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
             gid = (uint32_t)key;
             t = __uint_as_float((uint32_t)(key >> 32));
         }
-        if (threadIdx.x == 0) next_block_counts[blockIdx.x] = 0u;
+        if (threadIdx.x == 0) next_block_counts[block] = 0u;
         if (q == 0) big_count[0] = 0u;                                             // queue length
         if (q < kCullCounters) big_count[kCullCountAt + q * 16u] = 0u;             // group-cull survivor counts (one per list segment)
     }
@@ -768,28 +773,75 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     __syncthreads();
     uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     for (uint32_t k = 0; k < w; ++k) base += s_wave[k];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_points = base + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (!hit) return;
-    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    const uint32_t dst = base + rank;
+    if (block == n_blocks - 1 && threadIdx.x == 0) *n_points = base + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (hit) {
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t dst = base + rank;
 
-    // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
-    if (compact) {
-        // host-visible compact form (LS_OPT_HOST_OUTPUT = 2): 16 bytes cross PCIe, ls_expand_points rebuilds the record
-        points[dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * ctv, __int_as_float((int)v));
-    } else {
-        points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * ctv, 0.0f);
-        points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+        // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
+        if (compact) {
+            // host-visible compact form (LS_OPT_HOST_OUTPUT = 2): 16 bytes cross PCIe, ls_expand_points rebuilds the record
+            points[dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * ctv, __int_as_float((int)v));
+        } else {
+            points[2 * (size_t)dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * ctv, 0.0f);
+            points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v), 0.0f, 0.0f);
+        }
+        // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
+        uint32_t lo = 0, hi = gt.n;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
+        }
+        const uint32_t first = lo ? gt.tri_first[lo] : first0, geom = lo ? gt.geom_ids[lo] : geom0, shift = lo ? gt.prim_shift[lo] : shift0;
+        hits[dst] = make_uint4(v * tb.H + h, geom, (gid - first) >> shift, __float_as_uint(t));
     }
-    // (geomID, primID) from the global triangle id: last geometry slot whose first id <= gid
-    uint32_t lo = 0, hi = gt.n;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
+    if (!FROM_KEYS || !pg.host || block != 0u) return;
+    // ---- ls_trace_scene_begin: the frame's very first pack workgroup tells the host how many points there will be, how
+    //      many of them the launch before `split` packs, and where the points halve (the next frame's split).  Thread t
+    //      owns a contiguous chunk of the block counts: its sum, an exclusive scan of the 256 sums, then the one thread
+    //      whose chunk holds the half-way point walks it.  (No "last workgroup of the finish pass" detection: 2 048
+    //      atomics on one counter are 22 us.)
+    __shared__ uint32_t s_scan[kBlock / 64], s_first[kBlock / 64], s_even;
+    const uint32_t chunk = (n_blocks + kBlock - 1u) / kBlock;
+    const uint32_t c0 = min(threadIdx.x * chunk, n_blocks), c1 = min(c0 + chunk, n_blocks);
+    uint32_t mine = 0, mine_first = 0;
+    for (uint32_t i = c0; i < c1; ++i) {
+        const uint32_t c = block_counts[i];
+        mine += c;
+        if (i < pg.split) mine_first += c;
     }
-    const uint32_t first = lo ? gt.tri_first[lo] : first0, geom = lo ? gt.geom_ids[lo] : geom0, shift = lo ? gt.prim_shift[lo] : shift0;
-    hits[dst] = make_uint4(v * tb.H + h, geom, (gid - first) >> shift, __float_as_uint(t));
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine_first += __shfl_xor(mine_first, off);
+    if (threadIdx.x == 0) s_even = n_blocks;
+    __syncthreads();
+    if (lane == 63u) s_scan[w] = incl;
+    if (lane == 0) s_first[w] = mine_first;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (uint32_t k = 0; k < w; ++k) before += s_scan[k];
+    const uint32_t total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    if (mine && 2u * before < total && 2u * (before + mine) >= total) {   // exactly one thread (total > 0)
+        uint32_t run = before, at = c0;
+        while (at < c1 && 2u * run < total) run += block_counts[at++];
+        s_even = at;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&pg.host->total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pg.host->n_first, s_first[0] + s_first[1] + s_first[2] + s_first[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pg.host->even_split, s_even, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pg.host->total_epoch, pg.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
+
+// one word for the host, in stream order (ls_trace_scene_expand polls it)
+__global__ void k_signal(uint32_t *word, uint32_t value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // Debug view of the projection engine's result: dense per-ray (t, global triangle id) arrays from
 // the packed hit records (ls_debug_dense_hits); k_dense_clear first, then one thread per record.
@@ -1086,18 +1138,39 @@ void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid,
     hipLaunchKernelGGL(k_pack<false>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid,
                        static_cast<unsigned long long *>(nullptr), block_counts, static_cast<uint32_t *>(nullptr),
                        static_cast<uint32_t *>(nullptr), gt, reinterpret_cast<float4 *>(points32),
-                       reinterpret_cast<uint4 *>(hits), n_points, compact);
+                       reinterpret_cast<uint4 *>(hits), n_points, compact, 0u, blocks_for(nq), ProgressArgs{nullptr, 0u, 0u});
 }
 
 void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
                       const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
-                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact)
+                      const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact,
+                      const ProgressArgs *progress)
 {
     const uint32_t nq = tb.V * tb.naz;
     if (!nq) return;
-    hipLaunchKernelGGL(k_pack<true>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts,
-                       next_block_counts, big_count, gt, reinterpret_cast<float4 *>(points32),
-                       reinterpret_cast<uint4 *>(hits), n_points, compact);
+    const uint32_t nb = blocks_for(nq);
+    auto launch = [&](uint32_t block0, uint32_t count) {
+        hipLaunchKernelGGL(k_pack<true>, dim3(count), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts, next_block_counts, big_count, gt,
+                           reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points, compact, block0, nb,
+                           progress ? *progress : ProgressArgs{nullptr, 0u, 0u});
+    };
+    if (!progress || !progress->host) { launch(0u, nb); return; }
+    // two launches, each followed by a word for the host: a kernel's writes to pinned host memory are complete when the
+    // kernel is, so the word that follows it in the stream says "these records have arrived" without a fence per wave
+    // (a system-scope fence in every workgroup made the pack pass wait for PCIe round trips: 0.2 ms instead of 0.08)
+    // (a stream write-value packet where the runtime takes it -- cheaper on the host than a launch --, else a one-lane kernel)
+    auto signal = [&](uint32_t *word) {
+        static bool use_packet = true;
+        if (use_packet && hipStreamWriteValue32(s, word, progress->epoch, 0) == hipSuccess) return;
+        use_packet = false;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, s, word, progress->epoch);
+    };
+    const uint32_t first = std::min(progress->split, nb);
+    if (first) launch(0u, first);
+    signal(&progress->host->half_epoch);
+    if (nb > first) launch(first, nb - first);
+    signal(&progress->host->all_epoch);
 }
 
 // One wave that does nothing for `ticks` of the 100 MHz wall clock: ls_tracer.cpp uses it to find out which

@@ -3,6 +3,8 @@
 #include "ls_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 
 namespace lsi {
@@ -322,6 +324,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         return fail(tr, LS_ERR_OUT_OF_RANGE, "external output buffers smaller than the shard's ray count");
 
     hipStream_t s = tr->stream;   // three-stream mode switches to the frame's own stream below
+    bool progress = false;
     const ls::SensorTables tb = tables(tr);
     uint8_t *d_points = tr->ext_points ? static_cast<uint8_t *>(tr->ext_points) : tr->points.p;
     void *d_hits = tr->ext_points ? tr->ext_hits : static_cast<void *>(tr->hits.p);
@@ -345,6 +348,17 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         const uint32_t n_blocks = (shard_rays(tr) + 255u) / 256u;
         const bool pipelined = tr->opt_pipeline == 1 && !tr->opt_count && !tr->opt_timing;
         const bool multi = tr->opt_pipeline == 2 && !tr->opt_count && !tr->opt_timing;
+        // ls_trace_scene_begin: the finish and pack passes report their progress to the host (one frame in flight only)
+        ls::ProgressArgs pg{nullptr, 0u, 0u};
+        if (tr->progress_req && hv && compact && !pipelined && !multi && !tr->opt_count && !tr->opt_timing) {
+            if (++tr->progress_epoch == 0u) tr->progress_epoch = 1u;
+            // the pack pass's two launches split where the POINTS halved last frame (the upper rings mostly see sky);
+            // a frame without a hint, or with another raster, splits the ray blocks in the middle
+            if (tr->pack_split == 0u || tr->pack_split >= n_blocks || tr->pack_split_blocks != n_blocks) tr->pack_split = n_blocks / 2u;
+            tr->pack_split_blocks = n_blocks;
+            pg = {tr->h_progress, tr->progress_epoch, tr->pack_split};
+            progress = true;
+        }
         if (!pipelined && !multi && (rc = flush_pipeline(tr))) return rc;
         {   // spread runs balance the cells per wave (shorter kernel: 23.6 -> 21.2 us alone) but touch more cache lines,
             // which costs more than it gains once three frames overlap (16.9 -> 17.2 us per frame): LS_PROJECT_SPREAD overrides
@@ -480,7 +494,8 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             if (!ride) mark(tr, 8);
             ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
             mark(tr, 9);
-            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n, compact);
+            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n, compact,
+                                 progress ? &pg : nullptr);
             mark(tr, 10);
             if (multi) {
                 // no event per frame: a flush (or a mesh copy) records one per stream and orders the handle's stream after it
@@ -558,6 +573,13 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     out->d_n_points = d_n;
     if (!readback) return LS_OK;
 
+    if (hv && progress) {
+        // ls_trace_scene_begin polls the device's progress words instead of waiting for the stream
+        tr->progress_active = true;
+        tr->begin_blocks = (shard_rays(tr) + 255u) / 256u;
+        out->compact16 = tr->h_points;
+        return LS_OK;
+    }
     if (hv) {
         LS_HIP(hipStreamSynchronize(s));   // the only host wait of the frame
         if ((rc = check_device_status(tr))) return rc;
@@ -599,6 +621,91 @@ int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out)
 {
     LS_ENTER(tr);
     return trace_locked(tr, frame_index, out, false);
+}
+
+namespace {
+// spin on a progress word of the frame in flight (the device releases it with system scope); a frame takes tens of
+// microseconds, so this is a busy wait -- with a ceiling of seconds behind which the stream is waited for instead
+bool wait_epoch(const uint32_t *word, uint32_t epoch)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == epoch) return true;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) return false;
+    }
+}
+}  // namespace
+
+int ls_trace_scene_begin(ls_tracer *tr, uint32_t frame_index, uint32_t *n_points)
+{
+    LS_ENTER(tr);
+    if (!n_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null output");
+    *n_points = 0;
+    tr->begin_open = false;
+    tr->progress_active = false;
+    if (tr->ext_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "ls_trace_scene_begin delivers to host memory: reset ls_tracer_set_output_buffers first");
+    // compact points in pinned host memory, whatever LS_OPT_HOST_OUTPUT says for ls_trace_scene; no hit records
+    const int host_output = tr->opt_host_output, readback_hits = tr->opt_readback_hits;
+    tr->opt_host_output = 2;
+    tr->opt_readback_hits = 0;
+    tr->progress_req = true;
+    ls_frame f;
+    const int rc = trace_locked(tr, frame_index, &f, true);
+    tr->progress_req = false;
+    tr->opt_host_output = host_output;
+    tr->opt_readback_hits = readback_hits;
+    if (rc < 0) { tr->progress_active = false; return rc; }   // (-1: empty scene, zero points)
+    if (tr->progress_active) {
+        if (!wait_epoch(&tr->h_progress->total_epoch, tr->progress_epoch)) {
+            LS_HIP(hipStreamSynchronize(tr->stream));
+            tr->progress_active = false;
+            return fail(tr, LS_ERR_HIP, "the frame's hit count never reached the host");
+        }
+        tr->begin_points = __atomic_load_n(&tr->h_progress->total, __ATOMIC_RELAXED);
+        tr->begin_first = tr->pack_split ? std::min(__atomic_load_n(&tr->h_progress->n_first, __ATOMIC_RELAXED), tr->begin_points) : 0u;
+        tr->pack_split = __atomic_load_n(&tr->h_progress->even_split, __ATOMIC_RELAXED);   // the next frame's split
+    } else {
+        tr->begin_points = f.n_points;   // (BVH engine, frames in flight, external buffers ...: the frame is complete already)
+    }
+    tr->begin_open = true;
+    *n_points = tr->begin_points;
+    return LS_OK;
+}
+
+int ls_trace_scene_expand(ls_tracer *tr, void *dst_points32)
+{
+    LS_ENTER(tr);
+    if (!tr->begin_open) return fail(tr, LS_ERR_NOT_COMMITTED, "no frame begun (ls_trace_scene_begin)");
+    tr->begin_open = false;
+    const uint32_t n = tr->begin_points;
+    if (n && !dst_points32) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null destination");
+    uint8_t *dst = static_cast<uint8_t *>(dst_points32);
+    if (!tr->progress_active) return n ? ls_expand_points(dst, tr->h_points, n) : LS_OK;
+    tr->progress_active = false;
+    const ls::HostProgress *hp = tr->h_progress;
+    const uint32_t epoch = tr->progress_epoch;
+    // One job for the worker threads, started NOW -- their wake-up runs under the pack pass --: the items of the first
+    // half of the ray blocks wait for "the first half has arrived", the others for "all have" (n_first came with the hit
+    // count); the first half is expanded while the second half is still crossing PCIe
+    const uint32_t n_first = tr->begin_first;
+    const size_t items_first = (n_first + kExpandItem - 1) / kExpandItem, items_rest = ((size_t)(n - n_first) + kExpandItem - 1) / kExpandItem;
+    std::atomic<bool> ok{true};
+    const uint8_t *src = tr->h_points;
+    const std::function<void(size_t)> work = [&](size_t i) {
+        const bool first = i < items_first;
+        if (!wait_epoch(first ? &hp->half_epoch : &hp->all_epoch, epoch)) { ok.store(false); return; }
+        const size_t at = first ? i * kExpandItem : (size_t)n_first + (i - items_first) * kExpandItem;
+        const size_t end = first ? (size_t)n_first : (size_t)n;
+        expand_points_range(dst + 32 * at, src + 16 * at, std::min(kExpandItem, end - at));
+    };
+    pool_run(items_first + items_rest, work);
+    if (!n && !wait_epoch(&hp->all_epoch, epoch)) ok.store(false);   // (nothing to expand: still the frame's end)
+    if (!ok.load()) {
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        return fail(tr, LS_ERR_HIP, "the frame's progress words never reached the host");
+    }
+    return check_device_status(tr);
 }
 
 int ls_tracer_synchronize(ls_tracer *tr)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import make_tracer
+from test_gpu_parity import _syn_sensor
 
 pytestmark = pytest.mark.gpu
 
@@ -420,3 +421,59 @@ def test_bvh_instanced_stress(oracle, capi, sensors):
     assert instanced >= n_cases - 2    # (a drawn matrix may exceed the conditioning limit: that scene takes the classic path)
     bvh.close()
     prj.close()
+
+
+@pytest.mark.parametrize("engine_name", ["projection", "bvh"])
+def test_two_step_trace_equals_one_step(oracle, capi, sensors, meshes, engine_name):
+    """ls_trace_scene_begin / ls_trace_scene_expand (the hit count first, then the cloud expanded into the caller's memory
+    half by half as it arrives) deliver exactly ls_trace_scene's points: the XT-32 scenes while a mesh moves, the empty
+    scene, and -- BVH engine -- the fallback that completes the frame in the first step."""
+    s = sensors["0001"]
+    tr = make_tracer(capi, s, engine_name)
+    rc, pts = tr.traceSceneTwoStep(0)
+    assert rc == -1 and pts.shape == (0, 32)                 # nothing committed: OptixTracer.cpp:280-288
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.addGeometry("face", *[a.shape[0] for a in meshes["ben"]])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    for k in range(5):
+        A = oracle.affine_from_components(np.array((0.6 * k, -0.4 * k, 0.05 * k), np.float32), np.array((0.0, 0.0, 0.2 * k), np.float32))
+        tr.updateGeometryTransform("face", A)
+        assert tr.commitScene() == 0
+        rc, pts = tr.traceSceneTwoStep(k)
+        ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)])
+        assert rc == 0 and np.array_equal(pts, ref["points"])
+        rc1, pts1, _ = tr.traceScene(k)                       # the one-step call still works in between
+        assert rc1 == 0 and np.array_equal(pts1, ref["points"])
+    # an expand without a begin is refused; a begin may be followed by another begin (the first frame is dropped)
+    assert tr.L.ls_trace_scene_expand(tr.h, None) < 0
+    import ctypes as C
+    n = C.c_uint32()
+    assert tr.L.ls_trace_scene_begin(tr.h, 7, C.byref(n)) == 0 and n.value == ref["points"].shape[0]
+    rc, pts = tr.traceSceneTwoStep(8)
+    assert rc == 0 and np.array_equal(pts, ref["points"])
+    tr.close()
+
+
+def test_two_step_trace_headline_size(oracle, capi, sensors):
+    """The same at 128 x 4096 rays over 240 000 triangles (2 048 ray blocks: the first 1 024 are expanded while the rest
+    arrive), several frames back to back, against the BVH oracle; odd destination alignment takes the plain-store path."""
+    from lidarshooter_amd import synth
+    v, t = synth.grid_mesh(400, 300)
+    s = _syn_sensor(oracle, sensors, V=128, H=4096)
+    tr = make_tracer(capi, s, "projection")
+    tr.addGeometry("grid", v.shape[0], t.shape[0])
+    tr.updateGeometry("grid", oracle.IDENTITY_AFFINE, v, t)
+    assert tr.commitScene() == 0
+    ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True)
+    for k in range(6):
+        rc, pts = tr.traceSceneTwoStep(k)
+        assert rc == 0 and np.array_equal(pts, ref["points"])
+    import ctypes as C
+    n = C.c_uint32()
+    assert tr.L.ls_trace_scene_begin(tr.h, 9, C.byref(n)) == 0
+    buf = np.zeros(int(n.value) * 32 + 64, np.uint8)
+    off = 4 if buf.ctypes.data % 16 == 0 else (16 - buf.ctypes.data % 16) + 4   # 4 bytes past a 16-byte boundary
+    assert tr.L.ls_trace_scene_expand(tr.h, buf.ctypes.data + off) == 0
+    assert np.array_equal(buf[off:off + int(n.value) * 32].reshape(-1, 32), ref["points"])
+    tr.close()
