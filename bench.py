@@ -587,8 +587,12 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
     n_node, n_tri, wave_trips, max_trips = tr.visitStats()
     tr.setOption(capi.LS_OPT_COUNT_VISITS, 0)
     shard_rays = tr.getTotalRays()
+    points_sha = None
     if count_words is not None:
         n_hits = int(count_words[0][:4].view(torch.int32).item())
+        if single:   # the frame's cloud (32-byte points, ray-index order): lsbench prints the same hash for the same scene
+            import hashlib
+            points_sha = hashlib.sha256(out_bufs[0][64:64 + 32 * n_hits].cpu().numpy().tobytes()).hexdigest()
     else:   # C group: the slot's count word is the group's; the shard's dense result says how many of its rays hit
         n_hits = int((tr.denseHits()[1] != 0xFFFFFFFF).sum())
     info = tr.sceneSize()
@@ -848,6 +852,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                    "timed_ms_total": float(sum(window_ms))},
         "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         "hits_per_frame_rank0": n_hits,
+        "points_sha256": points_sha,
         # N > 1: points of the whole frame as rebuilt from the gathered slots on rank 0 (= the 1-GPU hit count)
         "gathered_points_rank0": None if single else (int(grp.download(args.steps - 1)[0].shape[0]) if cgroup else int(cloud_n[0].item())),
         "rehearsal_gloo_shared_gpu": True if rehearsal else None,

@@ -21,6 +21,20 @@ done >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 python tools/dropin_bench.py 50 > gpurun_out/final/dropin_${TAG}.json 2>> gpurun_out/final/bench.err
 bash tools_profile.sh ${TAG} > gpurun_out/final/profile.log 2>&1
 python tools/prof_summary.py gpurun_out/prof_${TAG} gpurun_out/final/${TAG}_projection > gpurun_out/final/prof_summary.log 2>&1
+python3 - gpurun_out/prof_${TAG}/stats_one gpurun_out/final/${TAG}_projection_kernel_stats_one_in_flight.csv <<'PY'
+import csv, glob, os, sys
+sys.path.insert(0, "tools")
+from prof_summary import short
+rows = []
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*_kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "ls::" in r["Name"]:
+            rows.append([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+with open(sys.argv[2], "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    w.writerows(rows)
+PY
 cp gpurun_out/prof_${TAG}/bench_stats.json gpurun_out/final/${TAG}_projection_bench_under_rocprof.json   # prof_summary also wrote ${TAG}_projection_kernel_isolated.json (dispatches that ran alone vs overlapped)
 BENCH_ARGS="--engine bvh --no-dropin" bash tools_pmc.sh ${TAG}_bvh "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/final/pmc_bvh.log 2>&1
 bash tools/bvh_stats.sh ${TAG} > gpurun_out/final/bvh_stats.log 2>&1
@@ -30,5 +44,13 @@ cp gpurun_out/final/${TAG}_projection_hbm.json gpurun_out/final/${TAG}_bvh_hbm.j
 python bench.py > gpurun_out/final/${TAG}_projection_bench.json 2>> gpurun_out/final/bench.err
 python bench.py --engine bvh --no-dropin > gpurun_out/final/${TAG}_bvh_bench.json 2>> gpurun_out/final/bench.err
 python bench.py --engine bvh --no-dropin --no-cpu-baseline --classic-bvh > gpurun_out/final/bench_${TAG}_bvh_classic.json 2>> gpurun_out/final/bench.err
+# SYN-10M: kernel averages of the culled stage (k_cull + k_project), what it reads and keeps, its HBM-side traffic
+W=syn128x10m bash tools/rocprof_kernels.sh ${TAG}_10m tools/shard_cost.py 2 1 > gpurun_out/final/${TAG}_projection_10m_kernels.txt 2>&1
+cp gpurun_out/rp_${TAG}_10m/${TAG}_10m_kernel_stats.csv gpurun_out/final/${TAG}_projection_10m_kernel_stats.csv
+python tools/cull_stats.py syn128x10m 1 >> gpurun_out/final/${TAG}_projection_10m_kernels.txt 2>> gpurun_out/final/bench.err
+W=syn128x10m bash tools/pmc_tool.sh ${TAG}_10m "FETCH_SIZE" "WRITE_SIZE" -- tools/shard_cost.py 2 1 > gpurun_out/final/${TAG}_projection_10m_pmc.txt 2>&1
+# BVH engine: a full rebuild of SYN-1M every frame (instanced and classic): the build kernels, the hand-written sort among them
+bash tools/rocprof_kernels.sh ${TAG}_rebuild tools/rebuild_cost.py > gpurun_out/final/${TAG}_bvh_rebuild_kernels.txt 2>&1
+tail -2 gpurun_out/rp_${TAG}_rebuild/stdout.log >> gpurun_out/final/${TAG}_bvh_rebuild_kernels.txt
 ls gpurun_out/final
 tail -3 gpurun_out/final/bench.err
