@@ -46,7 +46,7 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
     const bool want = cull_enabled(tr, g) && g.has_verts && g.has_idx && ls::project_tris_per_wave(g.n_tris) == 64u;
     if (!want) return LS_OK;
     if (!g.order_stale && !g.bounds_stale) return LS_OK;
-    // frames in flight on the slot streams read d_idx_sorted / d_perm / d_boxes
+    // frames in flight on the slot streams read d_idx_sorted / d_perm / d_boxes / d_corners
     int rc;
     if ((rc = flush_pipeline(tr))) return rc;
     ++tr->main_epoch;
@@ -54,6 +54,7 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
     if (!g.d_perm) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_perm), (size_t)nt * 4));
     if (!g.d_idx_sorted) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx_sorted), (size_t)nt * 12));
     if (!g.d_boxes) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_boxes), ls::project_box_entries(nt) * 32));   // group bounds, then block bounds
+    if (!g.d_corners) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_corners), (size_t)nt * 48));
     if (g.order_stale) {
         if ((rc = ensure(tr, tr->keys_a, nt))) return rc;
         if ((rc = ensure(tr, tr->keys_b, nt))) return rc;
@@ -69,6 +70,7 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
     }
     if (g.bounds_stale) {
         ls::launch_group_bounds(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.d_idx_sorted, nt, g.d_boxes);
+        ls::launch_corners(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.d_idx_sorted, g.d_perm, nt, g.d_corners);
         g.bounds_stale = false;
     }
     LS_HIP(hipGetLastError());

@@ -50,7 +50,7 @@ struct Geometry {
     // group culling (projection engine, meshes with 64 triangles per wave): Morton order of the triangles, the
     // indices in that order, a mesh-space bound (sheared box) per kCullGroup sorted triangles
     uint32_t *d_perm = nullptr, *d_idx_sorted = nullptr;
-    float4 *d_boxes = nullptr;
+    float4 *d_boxes = nullptr, *d_corners = nullptr;
     bool order_stale = true;    // the topology changed since d_perm / d_idx_sorted were made
     bool bounds_stale = true;   // vertices (may have) changed since d_boxes were made
     bool blas_dirty = true;     // BVH engine, instanced mode: vertices or topology changed since this geometry's hierarchy was built

@@ -118,6 +118,10 @@ struct GeomSource {
     // mesh-space sheared-box bound of sorted triangles [kCullGroup g, kCullGroup (g+1)).  nullptr: no culling.
     const uint32_t *perm;
     const float4 *boxes;
+    // corners[3k .. 3k+2] = the three corners of sorted triangle k as uploaded, 16 bytes each, perm[k] in the first one's
+    // fourth word (k_corners, with the bounds): a surviving group's 4 triangles are 192 contiguous bytes, one memory round
+    // trip from the survivor list instead of the index -> vertex chain's two
+    const float4 *corners;
 };
 
 // the geometries of one k_project launch (kernel argument: no upload)
@@ -273,6 +277,8 @@ void launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uin
 // per vertex upload: mesh-space sheared-box bound of every kCullGroup sorted triangles (2 float4 per group), followed
 // in the same array by the bound of every kCullBlockGroups groups (project_box_entries() float4 pairs in all)
 void launch_group_bounds(hipStream_t s, const uint8_t *verts, uint32_t stride, const uint32_t *idx_sorted, uint32_t ntris, float4 *boxes);
+void launch_corners(hipStream_t s, const uint8_t *verts, uint32_t stride, const uint32_t *idx_sorted, const uint32_t *perm, uint32_t ntris,
+                    float4 *corners);   // 3 * ntris entries
 size_t project_box_entries(uint32_t ntris);
 void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats);
 // per ray: gather the queued big-footprint triangles, then hits per 256-ray block

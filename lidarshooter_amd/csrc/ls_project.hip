@@ -325,9 +325,18 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     // segment holds more than that comes round again (the loop at the end)
     constexpr uint32_t kPerWave = 64u / kCullGroup;
     uint32_t n_live = 0, seg = 0, seg_block = 0;
+    uint32_t rank = 0, first_entry = 0;   // CULLED: this wave among its segment's; its lanes' list entry, read ahead
+    const uint32_t *seg_list = nullptr;
     if (CULLED) {
         seg = block % kCullSegs;
         seg_block = block / kCullSegs;
+        rank = seg_block * (kBlock / 64) + w;
+        // the lanes' list entry goes out TOGETHER with the segment's count, not behind it: whether the entry is a survivor
+        // of this frame (position < count) is known when both have arrived -- one memory round trip less in a chain of
+        // dependent ones (count -> entry -> corners), which is what this kernel's waves spend their time in.  Positions
+        // behind the count hold survivors of earlier frames or nothing: read (inside the segment), never used
+        seg_list = cull_list + batch.list_first[gi] + (size_t)seg * batch.seg_cap[gi];
+        first_entry = seg_list[min(rank * kPerWave + lane / kCullGroup, batch.seg_cap[gi] - 1u)];
         n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)big_count[kCullCountAt + (gi * kCullSegs + seg) * 16u]);
         if (seg_block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
     }
@@ -337,18 +346,12 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     //      (rocprofv3: the waves of this kernel spend half their lifetime in s_waitcnt; eight vector loads per wave)
     uint32_t k = 0xFFFFFFFFu;
     bool live_wave = true;
-    uint32_t rank = 0, live_waves = 0;   // CULLED: this wave among its segment's, and how many the segment needs
     if (CULLED) {
-        rank = seg_block * (kBlock / 64) + w;
         if (COUNT && rank == 0 && lane == 0) atomicAdd(&stats[1], (unsigned long long)n_live);   // counts[2]: surviving groups
         live_wave = rank * kPerWave < n_live;              // the survivors' last workgroup is partly filled
-        // a wave's groups are taken at a stride of the number of live waves: a segment's list follows the mesh order, and
-        // the cells a group expands to vary by orders of magnitude with its distance from the sensor -- consecutive groups
-        // would make a few waves next to the sensor walk ten times the cells of the others (and the kernel wait for them)
-        live_waves = (n_live + kPerWave - 1u) / kPerWave;
-        const uint32_t e = pp.spread ? (lane / kCullGroup) * live_waves + rank : rank * kPerWave + lane / kCullGroup;
-        if (live_wave && e < n_live)
-            k = cull_list[batch.list_first[gi] + seg * batch.seg_cap[gi] + e] * kCullGroup + (lane % kCullGroup);
+        // (a wave takes consecutive survivors; taking them at a stride of the number of live waves, as the unculled path's
+        // spread runs do, was within noise at 10 M triangles and would put the count in front of the entry load again)
+        if (rank * kPerWave + lane / kCullGroup < n_live) k = first_entry * kCullGroup + (lane % kCullGroup);
     } else {
         // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
         // join the cell tests): its footprints are large, and the cells are what takes the time
@@ -365,8 +368,18 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         }
     }
     float raw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // the three corners as uploaded (mesh space)
+    uint32_t tri_id = 0;   // CULLED: the triangle's number in the caller's order (perm[k], stored with the corners)
     auto load_corners = [&]() {
         if (k < src.ntris) {
+            if (CULLED) {
+                const float4 *c = src.corners + 3 * (size_t)k;
+                const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+                raw[0] = c0.x; raw[1] = c0.y; raw[2] = c0.z;
+                raw[3] = c1.x; raw[4] = c1.y; raw[5] = c1.z;
+                raw[6] = c2.x; raw[7] = c2.y; raw[8] = c2.z;
+                tri_id = __float_as_uint(c0.w);
+                return;
+            }
             const uint32_t a = src.idx[3 * (size_t)k + 0], b = src.idx[3 * (size_t)k + 1], c = src.idx[3 * (size_t)k + 2];
             const float *pa = reinterpret_cast<const float *>(src.verts + (size_t)a * src.stride);
             const float *pb = reinterpret_cast<const float *>(src.verts + (size_t)b * src.stride);
@@ -429,7 +442,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         if (cells) {
             const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
             const float NgC = dot_fma(cross_fma(e2, e1), v0);
-            const uint32_t gid = src.gid_first + (src.perm ? src.perm[k] : k);   // perm: Morton-sorted position -> triangle
+            const uint32_t gid = src.gid_first + (CULLED ? tri_id : k);   // (only culled geometries are kept in another order than the caller's)
             bool queued = false;
             if (cells > pp.big_cells) {
                 const uint32_t slot = atomicAdd(big_count, 1u);
@@ -494,8 +507,8 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     if (!CULLED) break;
     rank += batch.seg_blocks[gi] * (kBlock / 64);   // the segment's next wave-load that nobody else takes
     if (rank * kPerWave >= n_live) break;
-    const uint32_t e = pp.spread ? (lane / kCullGroup) * live_waves + rank : rank * kPerWave + lane / kCullGroup;
-    k = e < n_live ? cull_list[batch.list_first[gi] + seg * batch.seg_cap[gi] + e] * kCullGroup + (lane % kCullGroup) : 0xFFFFFFFFu;
+    const uint32_t e = rank * kPerWave + lane / kCullGroup;
+    k = e < n_live ? seg_list[e] * kCullGroup + (lane % kCullGroup) : 0xFFFFFFFFu;
     load_corners();
     }
     TL_MARK(tl_4);
@@ -649,6 +662,22 @@ __device__ __forceinline__ bool box_extent_bad(const float *lo, const float *hi)
 {
     return !(lo[0] <= hi[0]) || !(lo[1] <= hi[1]) || !(lo[2] <= hi[2]) || !(hi[0] - lo[0] < INFINITY) || !(hi[1] - lo[1] < INFINITY) ||
            !(hi[2] - lo[2] < INFINITY);
+}
+
+// one lane per sorted triangle: its three corners as uploaded, 16 bytes each, and in the spare word of the first the
+// triangle's number in the caller's order -- what k_project<CULLED> reads for a surviving group (GeomSource::corners)
+__global__ __launch_bounds__(kBlock) void k_corners(const uint8_t *__restrict__ verts, uint32_t stride, const uint32_t *__restrict__ idx_sorted,
+                                                    const uint32_t *__restrict__ perm, uint32_t ntris, float4 *__restrict__ corners)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ntris) return;
+    const uint32_t a = idx_sorted[3 * (size_t)k + 0], b = idx_sorted[3 * (size_t)k + 1], c = idx_sorted[3 * (size_t)k + 2];
+    const float *pa = reinterpret_cast<const float *>(verts + (size_t)a * stride);
+    const float *pb = reinterpret_cast<const float *>(verts + (size_t)b * stride);
+    const float *pc = reinterpret_cast<const float *>(verts + (size_t)c * stride);
+    corners[3 * (size_t)k + 0] = make_float4(pa[0], pa[1], pa[2], __uint_as_float(perm[k]));
+    corners[3 * (size_t)k + 1] = make_float4(pb[0], pb[1], pb[2], 0.0f);
+    corners[3 * (size_t)k + 2] = make_float4(pc[0], pc[1], pc[2], 0.0f);
 }
 
 // one lane per group of kCullGroup sorted triangles: bounds[2g] = (cx, cy, cz, hx), bounds[2g+1] = (hy, hz, sx, sy); the 64
@@ -1477,6 +1506,13 @@ void launch_group_bounds(hipStream_t s, const uint8_t *verts, uint32_t stride, c
     const uint32_t groups = (ntris + kCullGroup - 1) / kCullGroup;
     hipLaunchKernelGGL(k_group_bounds, dim3((groups + kBlock - 1) / kBlock), dim3(kBlock), 0, s, verts, stride, idx_sorted, ntris, boxes,
                        boxes + 2 * (size_t)groups);
+}
+
+void launch_corners(hipStream_t s, const uint8_t *verts, uint32_t stride, const uint32_t *idx_sorted, const uint32_t *perm, uint32_t ntris,
+                    float4 *corners)
+{
+    if (!ntris) return;
+    hipLaunchKernelGGL(k_corners, dim3((ntris + kBlock - 1) / kBlock), dim3(kBlock), 0, s, verts, stride, idx_sorted, perm, ntris, corners);
 }
 
 void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPackArgs &fa, unsigned long long *stats)

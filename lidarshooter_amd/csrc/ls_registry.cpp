@@ -214,8 +214,9 @@ void free_geometry(Geometry &g)
     if (g.d_perm) (void)hipFree(g.d_perm);
     if (g.d_idx_sorted) (void)hipFree(g.d_idx_sorted);
     if (g.d_boxes) (void)hipFree(g.d_boxes);
+    if (g.d_corners) (void)hipFree(g.d_corners);
     g.d_perm = g.d_idx_sorted = nullptr;
-    g.d_boxes = nullptr;
+    g.d_boxes = g.d_corners = nullptr;
     if (g.ev_stage_v) (void)hipEventDestroy(g.ev_stage_v);
     if (g.ev_stage_i) (void)hipEventDestroy(g.ev_stage_i);
     g.d_raw = nullptr;

@@ -430,10 +430,11 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             std::memcpy(src.m.rinv, tr->rinv, sizeof(src.m.rinv));
             std::memcpy(src.m.t, tr->t, sizeof(src.m.t));
             // block culling data is current (prepare_blocks ran at the commit) unless an update came in since
-            const bool culled = cull_enabled(tr, ge) && ge.d_boxes && !ge.order_stale && !ge.bounds_stale &&
+            const bool culled = cull_enabled(tr, ge) && ge.d_boxes && ge.d_corners && !ge.order_stale && !ge.bounds_stale &&
                                 ls::project_tris_per_wave(ge.n_tris) == 64u;
             src.perm = culled ? ge.d_perm : nullptr;
             src.boxes = culled ? ge.d_boxes : nullptr;
+            src.corners = culled ? ge.d_corners : nullptr;
             if (culled) src.idx = ge.d_idx_sorted;
             any_culled = any_culled || culled;
             srcs.push_back(src);
