@@ -240,65 +240,190 @@ __global__ __launch_bounds__(kBlock) void k_range_top(RangeTree rt, float4 *__re
     }
 }
 
+// delta(i, j): length of the common prefix of leaf keys i and j (equal keys: extended by the indices), -1 outside [0, L).
+__device__ __forceinline__ int delta_of(int i, uint32_t ki, int j, uint32_t kj)
+{
+    const uint32_t x = ki ^ kj;
+    return x ? __clz(x) : 32 + __clz((uint32_t)i ^ (uint32_t)j);
+}
+
+// A workgroup keeps the keys of the leaves within kKeyWindow of its own 256 in LDS.  A lane's two searches (Karras' range
+// end and split) run on that copy; the lane whose node reaches beyond it -- one node in five hundred -- gives up (far) and
+// the WAVE repeats its searches on global memory, 64 probes at a time (coop_search): three or four memory round trips for
+// the root of a million leaves where the lane alone needed forty, one after the other (38 of this kernel's 68 us were the
+// chains of its few long-range nodes: every later probe of a bisection lands near the far end, outside any window).
+constexpr int kKeyWindow = 512;
+struct KeyWindow {
+    const uint32_t *lds;    // keys of leaves [first, first + n)
+    int first, n;
+};
+__device__ __forceinline__ int delta_win(const KeyWindow &kw, int L, int i, uint32_t ki, int j, bool &far)
+{
+    if (j < 0 || j >= L) return -1;
+    const uint32_t at = (uint32_t)(j - kw.first);
+    if (at >= (uint32_t)kw.n) { far = true; return -1; }
+    return delta_of(i, ki, j, kw.lds[at]);
+}
+
+// the largest t in [lo, hi) with delta(i, i + t d) > thresh, given that it holds at lo, fails at hi and is monotone in
+// between; all 64 lanes of the wave work on the one node (arguments uniform)
+__device__ __forceinline__ int coop_search(const uint32_t *__restrict__ keys, uint32_t g, int L, int i, uint32_t ki, int d, int thresh,
+                                           int lo, int hi, uint32_t lane)
+{
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) / 64;
+        const int t = lo + ((int)lane + 1) * step;
+        bool p = false;
+        if (t < hi) {
+            const int j = i + t * d;
+            p = j >= 0 && j < L && delta_of(i, ki, j, keys[(size_t)j * g]) > thresh;
+        }
+        const int c = (int)__popcll(__ballot(p));   // monotone: the lanes that hold are the first c
+        hi = min(hi, lo + (c + 1) * step);
+        lo = lo + c * step;
+    }
+    return lo;
+}
+
+// bounds of leaves [l, r] from the aligned-range tree: level v contributes entry a_v = ceil(l / 2^v) if that is odd and
+// entry e_v - 1, e_v = floor((r + 1) / 2^v), if e_v is odd, as long as a_v < e_v
+__device__ __forceinline__ Box coop_range_box(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t r, uint32_t lane)
+{
+    Box b = box_empty();
+    const uint32_t lev = lane >> 1;
+    if (lev < rt.levels) {
+        const uint32_t a = (l + (1u << lev) - 1u) >> lev, e = (r + 1u) >> lev;
+        const bool take = a < e && ((lane & 1u) ? (e & 1u) : (a & 1u));
+        if (take) b = load_box(boxes, rt.offset[lev] + ((lane & 1u) ? e - 1u : a));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = fminf(b.lo[k], __shfl_xor(b.lo[k], off));
+            b.hi[k] = fmaxf(b.hi[k], __shfl_xor(b.hi[k], off));
+        }
+    }
+    return b;
+}
+
+// the same for one lane's node, both children at once: [l, gamma] and [gamma + 1, r].  The four loads of a level go out
+// before the previous level's four are merged (unconditionally -- entry 0 when there is nothing to take -- so that the
+// number of loads in flight is known to the compiler and it can wait for all but the newest)
+__device__ __forceinline__ void range_box_pair(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t gamma, uint32_t r,
+                                               Box &bl, Box &br)
+{
+    bl = box_empty();
+    br = box_empty();
+    float4 p[8];
+    bool had[4] = {false, false, false, false};
+    for (uint32_t lev = 0;; ++lev) {
+        const uint32_t round_up = (1u << lev) - 1u;
+        const uint32_t a0 = (l + round_up) >> lev, e0 = (gamma + 1u) >> lev, a1 = (gamma + 1u + round_up) >> lev, e1 = (r + 1u) >> lev;
+        const bool act0 = lev < rt.levels && a0 < e0, act1 = lev < rt.levels && a1 < e1;
+        const bool has[4] = {act0 && (a0 & 1u), act0 && (e0 & 1u), act1 && (a1 & 1u), act1 && (e1 & 1u)};
+        const uint32_t base = act0 || act1 ? rt.offset[lev] : 0u;
+        const uint32_t at[4] = {has[0] ? base + a0 : 0u, has[1] ? base + e0 - 1u : 0u, has[2] ? base + a1 : 0u, has[3] ? base + e1 - 1u : 0u};
+        float4 q[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { q[2 * k] = boxes[2 * (size_t)at[k]]; q[2 * k + 1] = boxes[2 * (size_t)at[k] + 1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (had[k]) {
+                Box &b = k < 2 ? bl : br;
+                b.lo[0] = fminf(b.lo[0], p[2 * k].x); b.lo[1] = fminf(b.lo[1], p[2 * k].y); b.lo[2] = fminf(b.lo[2], p[2 * k].z);
+                b.hi[0] = fmaxf(b.hi[0], p[2 * k + 1].x); b.hi[1] = fmaxf(b.hi[1], p[2 * k + 1].y); b.hi[2] = fmaxf(b.hi[2], p[2 * k + 1].z);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) had[k] = has[k];
+        if (!act0 && !act1) break;   // (this level loaded nothing that counts; the previous one's loads have been merged)
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Radix-tree hierarchy (Karras 2012) over the leaf keys, one thread per internal node i:
 // the thread finds its node's leaf range [l,r] and split from the keys alone and takes the boxes of
 // its two children [l,split] and [split+1,r] from the aligned-range tree -- no bottom-up pass, no
 // atomics, no cross-workgroup hand-off.  The left child precedes the right one in Morton order.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int delta(const uint32_t *__restrict__ keys, uint32_t g, int L, int i, uint32_t ki, int j)
-{
-    if (j < 0 || j >= L) return -1;
-    const uint32_t x = ki ^ keys[(size_t)j * g];
-    return x ? __clz(x) : 32 + __clz((uint32_t)i ^ (uint32_t)j);
-}
-
-__device__ __forceinline__ Box range_box(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t r)
-{
-    Box b = box_empty();
-    uint32_t a = l, e = r + 1u, lev = 0;
-    while (a < e) {
-        if (a & 1u) { const Box c = load_box(boxes, rt.offset[lev] + a); box_merge(b, c); ++a; }
-        if (e & 1u) { --e; const Box c = load_box(boxes, rt.offset[lev] + e); box_merge(b, c); }
-        a >>= 1; e >>= 1; ++lev;
-    }
-    return b;
-}
-
 __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict__ keys, uint32_t L_, uint32_t g,
                                                       RangeTree rt, const float4 *__restrict__ boxes,
                                                       FatNode *__restrict__ nodes)
 {
     const int L = (int)L_;
+    __shared__ uint32_t s_keys[kBlock + 2 * kKeyWindow];
+    __shared__ float4 s_out[kBlock / 64][256];
+    const KeyWindow kw = {s_keys, (int)(blockIdx.x * kBlock) - kKeyWindow, (int)(kBlock + 2 * kKeyWindow)};
+    for (int a = (int)threadIdx.x; a < kw.n; a += (int)kBlock) {
+        const int j = kw.first + a;
+        s_keys[a] = (j >= 0 && j < L) ? keys[(size_t)j * g] : 0u;
+    }
+    __syncthreads();
     const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (i >= L - 1) return;
-
-    const uint32_t ki = keys[(size_t)i * g];
-    const int d = delta(keys, g, L, i, ki, i + 1) > delta(keys, g, L, i, ki, i - 1) ? 1 : -1;
-    const int dmin = delta(keys, g, L, i, ki, i - d);
-    int lmax = 2;
-    while (delta(keys, g, L, i, ki, i + lmax * d) > dmin) lmax <<= 1;
-    int len = 0;
-    for (int t = lmax >> 1; t >= 1; t >>= 1)
-        if (delta(keys, g, L, i, ki, i + (len + t) * d) > dmin) len += t;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool node = i < L - 1;
+    const uint32_t ki = s_keys[threadIdx.x + kKeyWindow];
+    bool far = false;
+    int d = 1, dmin = -1, len = 0, s = 0;
+    if (node) {
+        d = delta_win(kw, L, i, ki, i + 1, far) > delta_win(kw, L, i, ki, i - 1, far) ? 1 : -1;   // (both inside the window)
+        dmin = delta_win(kw, L, i, ki, i - d, far);
+        int lmax = 2;
+        while (delta_win(kw, L, i, ki, i + lmax * d, far) > dmin) lmax <<= 1;
+        for (int t = lmax >> 1; t >= 1; t >>= 1)
+            if (delta_win(kw, L, i, ki, i + (len + t) * d, far) > dmin) len += t;
+        if (!far) {
+            const int dnode = delta_win(kw, L, i, ki, i + len * d, far);
+            int t = len;
+            do {
+                t = (t + 1) >> 1;
+                if (delta_win(kw, L, i, ki, i + (s + t) * d, far) > dnode) s += t;
+            } while (t > 1);
+        }
+    }
+    Box bl = box_empty(), br = box_empty();
+    // the wave's far nodes, one after the other, all lanes on each
+    for (unsigned long long todo = __ballot(node && far); todo; todo &= todo - 1ull) {
+        const int f = __builtin_ctzll(todo);
+        const int fi = __builtin_amdgcn_readlane(i, f), fd = __builtin_amdgcn_readlane(d, f), fdmin = __builtin_amdgcn_readlane(dmin, f);
+        const uint32_t fki = (uint32_t)__builtin_amdgcn_readlane((int)ki, f);
+        const int reach = fd > 0 ? L - 1 - fi : fi;   // the last t with i + t d inside [0, L)
+        const int flen = coop_search(keys, g, L, fi, fki, fd, fdmin, 1, reach + 1, lane);
+        const int fj = fi + flen * fd;
+        const int fdnode = delta_of(fi, fki, fj, keys[(size_t)fj * g]);
+        const int fs = coop_search(keys, g, L, fi, fki, fd, fdnode, 0, flen, lane);
+        const int fgamma = fi + fs * fd + min(fd, 0), fl = min(fi, fj), fr = max(fi, fj);
+        const Box cl = coop_range_box(rt, boxes, (uint32_t)fl, (uint32_t)fgamma, lane);
+        const Box cr = coop_range_box(rt, boxes, (uint32_t)fgamma + 1u, (uint32_t)fr, lane);
+        if ((int)lane == f) { len = flen; s = fs; bl = cl; br = cr; }
+    }
     const int j = i + len * d;
-    const int dnode = delta(keys, g, L, i, ki, j);
-    int s = 0, t = len;
-    do {
-        t = (t + 1) >> 1;
-        if (delta(keys, g, L, i, ki, i + (s + t) * d) > dnode) s += t;
-    } while (t > 1);
     const int gamma = i + s * d + min(d, 0);
     const int l = min(i, j), r = max(i, j);
     const uint32_t left = (l == gamma) ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
     const uint32_t right = (r == gamma + 1) ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-    const Box bl = range_box(rt, boxes, (uint32_t)l, (uint32_t)gamma);
-    const Box br = range_box(rt, boxes, (uint32_t)gamma + 1u, (uint32_t)r);
-    float4 *nd = nodes[i].q;
-    nd[0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
-    nd[1] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __uint_as_float(right));
-    nd[2] = make_float4(br.lo[0], br.lo[1], br.lo[2], 0.0f);
-    nd[3] = make_float4(br.hi[0], br.hi[1], br.hi[2], 0.0f);
+    if (node && !far) range_box_pair(rt, boxes, (uint32_t)l, (uint32_t)gamma, (uint32_t)r, bl, br);
+    // the wave's 64 nodes are 4 KB in a row: through LDS, so that every store instruction writes 1 KB contiguous (a lane
+    // storing its own node's four quarters writes 16 bytes of 64 different lines each time)
+    float4 *mine = s_out[threadIdx.x >> 6];
+    if (node) {
+        mine[4 * lane + 0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
+        mine[4 * lane + 1] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __uint_as_float(right));
+        mine[4 * lane + 2] = make_float4(br.lo[0], br.lo[1], br.lo[2], 0.0f);
+        mine[4 * lane + 3] = make_float4(br.hi[0], br.hi[1], br.hi[2], 0.0f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int wave_first = i - (int)lane;   // the wave's first node
+    float4 *out = reinterpret_cast<float4 *>(nodes + wave_first);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = k * 64 + (int)lane;   // quarter q of the wave's 256
+        if (wave_first + (q >> 2) < L - 1) out[q] = mine[q];
+    }
 }
 
 // ------------------------------------------------------------------------------------------

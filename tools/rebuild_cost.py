@@ -24,7 +24,7 @@ for instanced in (1, 0):
         for n, dv, dt in keep:
             tr.updateGeometryDeviceShared(n, capi.IDENTITY_AFFINE, dv.data_ptr(), 12, dt.data_ptr())   # new indices: a rebuild
         tr.commitScene()
-        tr.traceSceneAsync(f)
+        if not os.environ.get("RB_NOTRACE"): tr.traceSceneAsync(f)   # (ablation builds that leave the hierarchy unusable must not be traversed)
     tr.synchronize()
     t0 = time.perf_counter()
     for f in range(frames):
