@@ -158,7 +158,6 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
     tr->last_commit_built = any;
     if (any) {
         if ((rc = ensure(tr, tr->inst_verts, (size_t)tr->n_verts * 3))) return rc;
-        if ((rc = ensure(tr, tr->inst_tris, (size_t)tr->n_tris * 3))) return rc;
         if ((rc = ensure(tr, tr->keys_a, tr->n_tris))) return rc;
         if ((rc = ensure(tr, tr->keys_b, tr->n_tris))) return rc;
         if ((rc = ensure(tr, tr->vals_a, tr->n_tris))) return rc;
@@ -178,11 +177,10 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             const ls_tracer::LayoutEntry &le = tr->layout[i];
             const ls_tracer::InstSlot &sl = tr->inst_layout[i];
             float *verts = tr->inst_verts.p + 3 * (size_t)le.vfirst;
-            uint32_t *tris = tr->inst_tris.p + 3 * (size_t)le.tfirst;
+            const uint32_t *tris = ge.idx();   // mesh-local indices are what a per-geometry hierarchy wants: no rebased copy
             uint32_t *ka = tr->keys_a.p + le.tfirst, *kb = tr->keys_b.p + le.tfirst, *va = tr->vals_a.p + le.tfirst, *vb = tr->vals_b.p + le.tfirst;
             // identity transform: the packed copy holds the vertices as uploaded (1 * x + 0 * y + 0 * z + 0 is x)
             ls::launch_transform(s, ge.raw(), ge.stride, ge.n_verts, kIdA, kIdR, kZero, verts, tr->d_inst_maxabs + i);
-            ls::launch_rebase(s, ge.idx(), ge.n_tris * 3, 0u, tris);
             // vertices alone changed and the geometry's sorted keys are still in place: a refit (same order, same
             // topology, every box recomputed) -- what the classic path does with LS_OPT_BVH_REFIT
             const bool refit = tr->opt_bvh_refit && !ge.blas_topo_dirty && ge.blas_sorted_epoch == tr->key_scratch_epoch;

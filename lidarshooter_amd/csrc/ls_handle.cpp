@@ -225,7 +225,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     }
     release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
     release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
-    release(tr->inst_verts); release(tr->inst_tris); release(tr->treelet);
+    release(tr->inst_verts); release(tr->treelet);
     if (tr->d_inst_maxabs) (void)hipFree(tr->d_inst_maxabs);
     release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
     release(tr->row_counts); release(tr->points); release(tr->hits);

@@ -177,7 +177,6 @@ struct ls_tracer {
     std::vector<InstSlot> inst_layout;   // per layout entry
     uint32_t inst_leaf_size = 0;
     lsi::DevBuf<float> inst_verts;    // packed mesh-space vertices of all geometries (build input)
-    lsi::DevBuf<uint32_t> inst_tris;  // their indices, rebased
     uint32_t *d_inst_maxabs = nullptr;   // kGeomsPerLaunch words
     lsi::DevBuf<ls::FatNode> treelet; // one-geometry scenes: the top of that hierarchy, breadth-first (k_trace_inst stages it in LDS)
     bool treelet_valid = false;
