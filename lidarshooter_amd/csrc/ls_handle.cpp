@@ -126,6 +126,7 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
     fill_tables(tr, tab);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_tables), tab.size() * 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMemcpy(tr->d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(LS_ERR_HIP);
+    tr->host_tables = tab;
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_maxabs), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);

@@ -60,6 +60,40 @@ void expand_points_range(uint8_t *dst_points32, const uint8_t *compact16, size_t
     }
 }
 
+// (ray, t) -> point: LidarDevice.cpp:310-316's direction factors from the tables, EmbreeTracer.cpp:341-345's xyz = t * dir,
+// in k_pack's operation order (t * (sin_theta * cos_phi): two roundings; this file is compiled with -ffp-contract=off).
+// The records come in ascending ray order, so the channel is tracked, not divided out per point.
+void expand_hits_range(uint8_t *dst_points32, const uint8_t *hits8, size_t cnt, const float *sin_theta, const float *cos_theta,
+                       const float *cs_phi, uint32_t H)
+{
+    if (!cnt) return;
+    const float intensity = 64.0f;
+    uint32_t ibits;
+    std::memcpy(&ibits, &intensity, 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(hits8);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(dst_points32);
+    uint32_t v = src[0] / H;
+    uint64_t row_end = ((uint64_t)v + 1u) * H;
+    float st = sin_theta[v], ct = cos_theta[v];
+    const bool aligned = (reinterpret_cast<uintptr_t>(dst_points32) & 15u) == 0;
+    for (size_t k = 0; k < cnt; ++k) {
+        const uint32_t ray = src[2 * k];
+        while (ray >= row_end) { ++v; row_end += H; st = sin_theta[v]; ct = cos_theta[v]; }
+        const uint32_t h = ray - (uint32_t)(row_end - H);
+        float t;
+        std::memcpy(&t, &src[2 * k + 1], 4);
+        const float x = t * (st * cs_phi[2 * (size_t)h]), y = t * (st * cs_phi[2 * (size_t)h + 1]), z = t * ct;
+        if (aligned) {
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + 8 * k), _mm_castps_si128(_mm_set_ps(0.0f, z, y, x)));
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + 8 * k + 4), _mm_set_epi32(0, 0, (int)v, (int)ibits));
+        } else {
+            std::memcpy(&dst[8 * k + 0], &x, 4); std::memcpy(&dst[8 * k + 1], &y, 4); std::memcpy(&dst[8 * k + 2], &z, 4);
+            dst[8 * k + 3] = 0u; dst[8 * k + 4] = ibits; dst[8 * k + 5] = v; dst[8 * k + 6] = 0u; dst[8 * k + 7] = 0u;
+        }
+    }
+    if (aligned) _mm_sfence();
+}
+
 void pool_run(size_t n, const std::function<void(size_t)> &fn) { HostPool::get().run(n, fn); }
 
 }  // namespace lsi

@@ -83,6 +83,7 @@ struct ls_tracer {
     uint32_t V = 0, H = 0;
     float rinv[9], t[3];
     float *d_tables = nullptr;  // sin_theta[V] cos_theta[V] sin_phi[H] cos_phi[H] ... (fill_tables)
+    std::vector<float> host_tables;   // the same words on the host (ls_trace_scene_expand rebuilds points from (ray, t) records)
     float lut_t0 = 0.0f, lut_scale = 0.0f;   // k_cull's channel look-up table (ProjectParams::chan_lut)
     bool lut_ok = false;
     uint32_t az0 = 0, naz = 0;
@@ -282,6 +283,10 @@ void parallel_copy(void *dst, const void *src, size_t bytes);
 int host_pool_threads();
 constexpr size_t kExpandItem = 16384;   // points per work item of an expansion: 256 KB read, 512 KB written
 void expand_points_range(uint8_t *dst_points32, const uint8_t *compact16, size_t count);
+// 8-byte (ray, t) records in ascending ray order -> 32-byte points: xyz = t * direction from the factor tables, the float
+// operations of k_pack in the same order
+void expand_hits_range(uint8_t *dst_points32, const uint8_t *hits8, size_t count, const float *sin_theta, const float *cos_theta,
+                       const float *cs_phi, uint32_t H);
 void pool_run(size_t n, const std::function<void(size_t)> &fn);   // fn(0) .. fn(n-1) on the worker threads and the caller
 
 }  // namespace lsi

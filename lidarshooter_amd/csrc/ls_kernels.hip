@@ -940,7 +940,11 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         const uint32_t dst = base + rank;
 
         // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
-        if (compact) {
+        if (compact == 2u) {
+            // ls_trace_scene_begin: 8 bytes cross PCIe, (ray, t); ls_trace_scene_expand rebuilds the point from the host's
+            // copy of the factor tables with the operations below
+            reinterpret_cast<uint2 *>(points)[dst] = make_uint2(v * tb.H + h, __float_as_uint(t));
+        } else if (compact) {
             // host-visible compact form (LS_OPT_HOST_OUTPUT = 2): 16 bytes cross PCIe, ls_expand_points rebuilds the record
             points[dst] = make_float4(t * (st * cs.x), t * (st * cs.y), t * ctv, __int_as_float((int)v));
         } else {

@@ -495,8 +495,9 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             if (!ride) mark(tr, 8);
             ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
             mark(tr, 9);
-            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n, compact,
-                                 progress ? &pg : nullptr);
+            // (a frame that reports its progress sends 8-byte (ray, t) records: ls_trace_scene_expand rebuilds the points)
+            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n,
+                                 progress ? 2u : compact, progress ? &pg : nullptr);
             mark(tr, 10);
             if (multi) {
                 // no event per frame: a flush (or a mesh copy) records one per stream and orders the handle's stream after it
@@ -578,7 +579,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         // ls_trace_scene_begin polls the device's progress words instead of waiting for the stream
         tr->progress_active = true;
         tr->begin_blocks = (shard_rays(tr) + 255u) / 256u;
-        out->compact16 = tr->h_points;
+        out->compact16 = nullptr;   // ((ray, t) records, for ls_trace_scene_expand only)
         return LS_OK;
     }
     if (hv) {
@@ -693,12 +694,14 @@ int ls_trace_scene_expand(ls_tracer *tr, void *dst_points32)
     const size_t items_first = (n_first + kExpandItem - 1) / kExpandItem, items_rest = ((size_t)(n - n_first) + kExpandItem - 1) / kExpandItem;
     std::atomic<bool> ok{true};
     const uint8_t *src = tr->h_points;
+    const uint32_t V = tr->V, H = tr->H;
+    const float *sin_theta = tr->host_tables.data(), *cos_theta = sin_theta + V, *cs_phi = sin_theta + 2 * (size_t)V + 2 * (size_t)H + 3 * (size_t)V;
     const std::function<void(size_t)> work = [&](size_t i) {
         const bool first = i < items_first;
         if (!wait_epoch(first ? &hp->half_epoch : &hp->all_epoch, epoch)) { ok.store(false); return; }
         const size_t at = first ? i * kExpandItem : (size_t)n_first + (i - items_first) * kExpandItem;
         const size_t end = first ? (size_t)n_first : (size_t)n;
-        expand_points_range(dst + 32 * at, src + 16 * at, std::min(kExpandItem, end - at));
+        expand_hits_range(dst + 32 * at, src + 8 * at, std::min(kExpandItem, end - at), sin_theta, cos_theta, cs_phi, H);
     };
     pool_run(items_first + items_rest, work);
     if (!n && !wait_epoch(&hp->all_epoch, epoch)) ok.store(false);   // (nothing to expand: still the frame's end)
