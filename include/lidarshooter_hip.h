@@ -185,7 +185,9 @@ int ls_trace_scene_async(ls_tracer *tr, uint32_t frame_index, ls_frame *out);
  *                          running -- so that the caller can size its cloud (data.resize(32 * n_points)) meanwhile;
  *   ls_trace_scene_expand  writes the n_points 32-byte records (XYZIRBytes.cpp:24-40) to dst_points32 with the library's
  *                          worker threads: the first half of the cloud while the second half is still crossing PCIe as
- *                          16-byte compact records.  Returns when the cloud is complete.
+ *                          8-byte (ray, t) records, from which the host rebuilds xyz = t * direction with the factor
+ *                          tables and the operation order of the device (the same bits).  Returns when the cloud is
+ *                          complete.
  * Same results as ls_trace_scene + ls_expand_points; -1 / zero points on an empty scene.  One frame in flight. */
 int ls_trace_scene_begin(ls_tracer *tr, uint32_t frame_index, uint32_t *n_points);
 int ls_trace_scene_expand(ls_tracer *tr, void *dst_points32);
