@@ -36,6 +36,11 @@ int ls_debug_download_bvh(ls_tracer *tr, void *nodes, void *tri_records);
  * arrays; stable: equal keys keep their input order). */
 int ls_debug_sort_pairs(ls_tracer *tr, uint32_t *keys, uint32_t *vals, uint32_t n);
 
+/* The host half of ls_trace_scene_expand on its own (no device, no handle): n 8-byte (ray, t) records in ascending ray
+ * order -> n 32-byte points, from factor tables sin_theta[V], cos_theta[V] and interleaved (cos_phi, sin_phi)[H]. */
+int ls_debug_expand_hits(void *dst_points32, const void *hits8, uint32_t n, const float *sin_theta, const float *cos_theta,
+                         const float *cs_phi, uint32_t V, uint32_t H);
+
 #ifdef __cplusplus
 }
 #endif

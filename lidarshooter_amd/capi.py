@@ -42,7 +42,7 @@ SYMBOLS = (
 )
 # include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
 DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",
-                 "ls_debug_download_bvh", "ls_debug_sort_pairs")
+                 "ls_debug_download_bvh", "ls_debug_sort_pairs", "ls_debug_expand_hits")
 
 
 class SensorDesc(C.Structure):
@@ -155,6 +155,7 @@ def load() -> C.CDLL:
     L.ls_debug_download_scene.argtypes = [vp, vp, vp]
     L.ls_debug_download_bvh.argtypes = [vp, vp, vp]
     L.ls_debug_sort_pairs.argtypes = [vp, vp, vp, u32]
+    L.ls_debug_expand_hits.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32]
     _lib = L
     return L
 

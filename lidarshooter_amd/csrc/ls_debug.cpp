@@ -110,3 +110,13 @@ int ls_debug_sort_pairs(ls_tracer *tr, uint32_t *keys, uint32_t *vals, uint32_t 
 }
 
 }  // extern "C"
+
+int ls_debug_expand_hits(void *dst_points32, const void *hits8, uint32_t n, const float *sin_theta, const float *cos_theta,
+                         const float *cs_phi, uint32_t V, uint32_t H)
+{
+    if (!n) return LS_OK;
+    if (!dst_points32 || !hits8 || !sin_theta || !cos_theta || !cs_phi || !V || !H) return LS_ERR_INVALID_ARGUMENT;
+    lsi::expand_hits_range(static_cast<uint8_t *>(dst_points32), static_cast<const uint8_t *>(hits8), n, sin_theta, cos_theta, cs_phi, V, H);
+    return LS_OK;
+}
+

@@ -64,7 +64,7 @@ void expand_points_range(uint8_t *dst_points32, const uint8_t *compact16, size_t
 // in k_pack's operation order (t * (sin_theta * cos_phi): two roundings; this file is compiled with -ffp-contract=off).
 // The records come in ascending ray order, so the channel is tracked, not divided out per point.
 void expand_hits_range(uint8_t *dst_points32, const uint8_t *hits8, size_t cnt, const float *sin_theta, const float *cos_theta,
-                       const float *cs_phi, uint32_t H)
+                       const float *cs_phi, uint32_t V, uint32_t H)
 {
     if (!cnt) return;
     const float intensity = 64.0f;
@@ -72,14 +72,14 @@ void expand_hits_range(uint8_t *dst_points32, const uint8_t *hits8, size_t cnt, 
     std::memcpy(&ibits, &intensity, 4);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(hits8);
     uint32_t *dst = reinterpret_cast<uint32_t *>(dst_points32);
-    uint32_t v = src[0] / H;
+    uint32_t v = std::min(src[0] / H, V - 1u);   // (a ray number outside the raster cannot come from k_pack; it must not leave the tables either)
     uint64_t row_end = ((uint64_t)v + 1u) * H;
     float st = sin_theta[v], ct = cos_theta[v];
     const bool aligned = (reinterpret_cast<uintptr_t>(dst_points32) & 15u) == 0;
     for (size_t k = 0; k < cnt; ++k) {
         const uint32_t ray = src[2 * k];
-        while (ray >= row_end) { ++v; row_end += H; st = sin_theta[v]; ct = cos_theta[v]; }
-        const uint32_t h = ray - (uint32_t)(row_end - H);
+        while (ray >= row_end && v + 1u < V) { ++v; row_end += H; st = sin_theta[v]; ct = cos_theta[v]; }
+        const uint32_t h = std::min(ray - (uint32_t)(row_end - H), H - 1u);
         float t;
         std::memcpy(&t, &src[2 * k + 1], 4);
         const float x = t * (st * cs_phi[2 * (size_t)h]), y = t * (st * cs_phi[2 * (size_t)h + 1]), z = t * ct;

@@ -286,7 +286,7 @@ void expand_points_range(uint8_t *dst_points32, const uint8_t *compact16, size_t
 // 8-byte (ray, t) records in ascending ray order -> 32-byte points: xyz = t * direction from the factor tables, the float
 // operations of k_pack in the same order
 void expand_hits_range(uint8_t *dst_points32, const uint8_t *hits8, size_t count, const float *sin_theta, const float *cos_theta,
-                       const float *cs_phi, uint32_t H);
+                       const float *cs_phi, uint32_t V, uint32_t H);
 void pool_run(size_t n, const std::function<void(size_t)> &fn);   // fn(0) .. fn(n-1) on the worker threads and the caller
 
 }  // namespace lsi

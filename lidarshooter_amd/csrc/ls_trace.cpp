@@ -701,7 +701,7 @@ int ls_trace_scene_expand(ls_tracer *tr, void *dst_points32)
         if (!wait_epoch(first ? &hp->half_epoch : &hp->all_epoch, epoch)) { ok.store(false); return; }
         const size_t at = first ? i * kExpandItem : (size_t)n_first + (i - items_first) * kExpandItem;
         const size_t end = first ? (size_t)n_first : (size_t)n;
-        expand_hits_range(dst + 32 * at, src + 8 * at, std::min(kExpandItem, end - at), sin_theta, cos_theta, cs_phi, H);
+        expand_hits_range(dst + 32 * at, src + 8 * at, std::min(kExpandItem, end - at), sin_theta, cos_theta, cs_phi, V, H);
     };
     pool_run(items_first + items_rest, work);
     if (!n && !wait_epoch(&hp->all_epoch, epoch)) ok.store(false);   // (nothing to expand: still the frame's end)

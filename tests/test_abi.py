@@ -103,3 +103,39 @@ def test_host_side_helpers_without_a_gpu(capi, oracle):
     dst = np.zeros_like(src)
     assert L.ls_parallel_copy(dst.ctypes.data, src.ctypes.data, src.size) == 0 and np.array_equal(src, dst)
     assert L.ls_expand_points(None, None, 0) == 0 and L.ls_parallel_copy(None, None, 0) == 0
+
+
+def test_host_rebuild_of_points_from_ray_and_t(capi, oracle, sensors):
+    """The host half of ls_trace_scene_expand without a device: 8-byte (ray, t) records -> 32-byte points must be what the
+    oracle's packing makes of the same hits (xyz = t * direction: EmbreeTracer.cpp:341-345 with LidarDevice.cpp:310-316's
+    factors; XYZIRBytes.cpp:24-40's layout) -- aligned and unaligned destinations, rows without hits, a single record."""
+    import numpy as np
+    L = capi.load()
+    s = sensors["0001"]
+    st, ct, sp, cp = oracle.ray_tables(s)
+    V, H = s.V, s.H
+    cs = np.ascontiguousarray(np.stack([cp, sp], axis=1).astype(np.float32))
+    rng = np.random.default_rng(11)
+    for n in (1, 7, min(40001, V * H // 2)):
+        rays = np.sort(rng.choice(V * H, size=n, replace=False)).astype(np.uint32)
+        if n > 100:
+            rays = rays[(rays // H) % 5 != 2]          # whole channels without a hit
+        t = rng.uniform(0.5, 120.0, rays.size).astype(np.float32)
+        rec = np.empty((rays.size, 2), np.uint32)
+        rec[:, 0] = rays
+        rec[:, 1] = t.view(np.uint32)
+        v, h = rays // H, rays % H
+        want = np.zeros((rays.size, 8), np.float32)
+        want[:, 0] = t * (st[v] * cs[h, 0])
+        want[:, 1] = t * (st[v] * cs[h, 1])
+        want[:, 2] = t * ct[v]
+        want[:, 4] = 64.0
+        want[:, 5] = v.astype(np.int32).view(np.float32)
+        for shift in (0, 4):                            # 16-byte aligned (streaming stores) and not
+            buf = np.full(rays.size * 32 + 64, 0xCD, np.uint8)
+            off = (-buf.ctypes.data) % 16 + shift
+            assert L.ls_debug_expand_hits(buf.ctypes.data + off, rec.ctypes.data, rays.size, st.ctypes.data, ct.ctypes.data,
+                                          cs.ctypes.data, V, H) == 0
+            got = buf[off:off + rays.size * 32].view(np.uint32).reshape(-1, 8)
+            assert np.array_equal(got, want.view(np.uint32)), (n, shift)
+    assert L.ls_debug_expand_hits(None, None, 0, None, None, None, V, H) == 0
