@@ -102,6 +102,7 @@ struct ProjectParams {
     int debug;                     // diagnostic: 1 = stop after the vertex loads, 2 = after the footprints
     int spread;                    // big meshes: a wave takes its triangles in runs spread over the whole mesh (balances the cells per
                                    // wave: shorter kernel) instead of one contiguous run (fewer cache lines: better with frames overlapping)
+    uint32_t xcd_remap;            // one geometry, no culling: workgroup -> triangles so that each XCD streams one contiguous eighth
 };
 
 // one geometry as uploaded (xform = 1: vertices still need A / Rinv / t) or the committed scene

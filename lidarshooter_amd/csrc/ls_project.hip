@@ -297,6 +297,9 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 #define TL_HOST_HOOK(s)
 #endif
 
+#ifndef LS_EXP_CORNERS
+#define LS_EXP_CORNERS 0
+#endif
 template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
 __device__ __forceinline__ void project_body(const ProjectParams &pp, const GeomBatch &batch, uint32_t block_idx, ProjectLds &lds,
                                              float *s_chan /* LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm */,
@@ -315,7 +318,16 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     if (MULTI)
         while (gi + 1u < batch.n && block_idx >= batch.block_first[gi + 1u]) ++gi;
     const GeomSource &src = batch.g[gi];
-    const uint32_t block = MULTI ? block_idx - batch.block_first[gi] : block_idx;
+    uint32_t block = MULTI ? block_idx - batch.block_first[gi] : block_idx;
+    if (!MULTI && !CULLED && pp.xcd_remap) {
+        // workgroup ids go round the eight XCDs: every XCD takes one contiguous eighth of the triangles, so that the vertex
+        // lines two neighbouring workgroups share sit in ONE L2 (PMC: 24 MB of vertex lines fetched for 6 MB of vertices).
+        // Only with one frame in flight (trace_locked): there it takes 1.2 us off the frame (26.3 -> 25.1 us, the kernel
+        // 18.4 -> 17.5 us); with three frames in flight eight address streams an eighth of the mesh apart cost 2 us per frame
+        const uint32_t nb = batch.block_first[1];
+        const uint32_t x = block & 7u, i = block >> 3, q = nb >> 3, r = nb & 7u;
+        block = x * q + min(x, r) + i;
+    }
     // CULLED: the groups of kCullGroup sorted triangles that survived k_cull sit in kCullSegs segments of this
     // geometry's part of cull_list, each packed to its front (count in the segment's counter); workgroup b of the
     // geometry works on segment b % kCullSegs, position b / kCullSegs; a wave takes 64 / kCullGroup survivors, so its
@@ -371,7 +383,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     uint32_t tri_id = 0;   // CULLED: the triangle's number in the caller's order (perm[k], stored with the corners)
     auto load_corners = [&]() {
         if (k < src.ntris) {
-            if (CULLED) {
+            if (CULLED || (LS_EXP_CORNERS && src.corners)) {
                 const float4 *c = src.corners + 3 * (size_t)k;
                 const float4 c0 = c[0], c1 = c[1], c2 = c[2];
                 raw[0] = c0.x; raw[1] = c0.y; raw[2] = c0.z;
@@ -442,7 +454,9 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         if (cells) {
             const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
             const float NgC = dot_fma(cross_fma(e2, e1), v0);
-            const uint32_t gid = src.gid_first + (CULLED ? tri_id : k);   // (only culled geometries are kept in another order than the caller's)
+            // (a geometry with culling data is kept in Morton order; when it goes through the unculled launch after all -- more
+            // than kGeomsPerLaunch such geometries -- perm carries the sorted position back to the caller's triangle)
+            const uint32_t gid = src.gid_first + ((CULLED || (LS_EXP_CORNERS && src.corners)) ? tri_id : (src.perm ? src.perm[k] : k));
             bool queued = false;
             if (cells > pp.big_cells) {
                 const uint32_t slot = atomicAdd(big_count, 1u);
@@ -1421,7 +1435,8 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
 
     // ---- geometries with group bounds: k_cull, then a launch whose waves read the survivors
     bool culled_done = false;
-    if (cull_list) {
+    static const int exp_corners_only = lsi::tune_int("LS_NOCULL_CORNERS", 0);
+    if (cull_list && !exp_corners_only) {
         GeomBatch batch;
         uint32_t blocks, entries;
         if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries)) {

@@ -72,6 +72,7 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     pp.big_cells = big_cells;
     pp.debug = debug;
     pp.spread = 1;   // trace_locked clears it for frames that overlap on the three slot streams
+    pp.xcd_remap = 0;
     return pp;
 }
 
@@ -364,6 +365,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             // which costs more than it gains once three frames overlap (16.9 -> 17.2 us per frame): LS_PROJECT_SPREAD overrides
             static const int spread_env = tune_int("LS_PROJECT_SPREAD", -1);
             pp.spread = spread_env >= 0 ? spread_env : (multi ? 0 : 1);
+            pp.xcd_remap = multi ? 0u : 1u;   // (the same trade: good for a frame alone, bad for three at once; ls_project.hip)
         }
         // which set of keys / queue / outputs and which of the three queue counters this frame uses.
         // Rider mode and frames that are not pipelined: pipe_seq counts the pipelined frames; a frame that is

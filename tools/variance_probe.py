@@ -1,0 +1,52 @@
+"""Where the process-to-process spread of the three-stream frame time comes from: the headline frame loop (C++ loop of
+host_capi.cpp) on a tracer that is created, measured and destroyed several times inside ONE process; run the script several
+times for the spread across processes.  usage: variance_probe.py [handles per process] [mode: 2 | 1 | 0]"""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from lidarshooter_amd import capi, hostapi
+import bench
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+sensor, meshes = bench.build_workload("syn128x1m")
+dev = torch.device("cuda", 0)
+HL = hostapi.load()
+f32p = C.POINTER(C.c_float)
+HL.lsh_stream_frames.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(f32p), C.POINTER(C.c_uint), C.c_uint,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+ident = (C.c_float * 12)(*[float(x) for x in capi.IDENTITY_AFFINE])
+V, H = len(sensor["vertical"]), int(sensor["h_count"])
+cap = V * H
+res = []
+for rep in range(reps):
+    tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"])
+    tr.setOption(capi.LS_OPT_ENGINE, 2)
+    keep = []
+    for n, v, t in meshes:
+        dv = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev)
+        dt = torch.from_numpy(np.ascontiguousarray(t, np.uint32).view(np.int32)).to(dev)
+        keep.append((dv, dt))
+        tr.addGeometry(n, v.shape[0], t.shape[0])
+        tr.updateGeometryDeviceShared(n, capi.IDENTITY_AFFINE, dv.data_ptr(), 12, dt.data_ptr())
+    tr.commitScene()
+    tr.setOption(capi.LS_OPT_PIPELINE, mode)
+    outs = [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=dev) for _ in range(3)]
+    names = (C.c_char_p * len(meshes))(*[m[0].encode() for m in meshes])
+    aff = (f32p * len(meshes))(*[C.cast(ident, f32p) for _ in meshes])
+    na = (C.c_uint * len(meshes))(*[1 for _ in meshes])
+    P = (C.c_void_p * 3)(*[b.data_ptr() + 64 for b in outs])
+    Hh = (C.c_void_p * 3)(*[b.data_ptr() + 64 + 32 * cap for b in outs])
+    Cn = (C.c_void_p * 3)(*[b.data_ptr() for b in outs])
+    def run(first, n):
+        assert HL.lsh_stream_frames(tr.h, names, aff, na, len(meshes), P, Hh, Cn, 3, cap, first, n) == 0
+    run(0, 600); tr.synchronize()
+    ws = []
+    for w in range(5):
+        t0 = time.perf_counter(); run(1000 * w, 1000); tr.synchronize(); ws.append((time.perf_counter() - t0) / 1000 * 1e6)
+    res.append(ws)
+    print("handle %d: us per frame, 5 windows of 1000: %s   streams %s" % (rep, " ".join("%.2f" % x for x in ws), tr.info(capi.LS_INFO_CONCURRENT_STREAMS)), flush=True)
+    tr.close()
+    del outs, keep
+    torch.cuda.empty_cache()
+print("PID %d medians: %s" % (os.getpid(), " ".join("%.2f" % float(np.median(w)) for w in res)))
