@@ -297,9 +297,6 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 #define TL_HOST_HOOK(s)
 #endif
 
-#ifndef LS_EXP_CORNERS
-#define LS_EXP_CORNERS 0
-#endif
 template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
 __device__ __forceinline__ void project_body(const ProjectParams &pp, const GeomBatch &batch, uint32_t block_idx, ProjectLds &lds,
                                              float *s_chan /* LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm */,
@@ -383,7 +380,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     uint32_t tri_id = 0;   // CULLED: the triangle's number in the caller's order (perm[k], stored with the corners)
     auto load_corners = [&]() {
         if (k < src.ntris) {
-            if (CULLED || (LS_EXP_CORNERS && src.corners)) {
+            if (CULLED) {
                 const float4 *c = src.corners + 3 * (size_t)k;
                 const float4 c0 = c[0], c1 = c[1], c2 = c[2];
                 raw[0] = c0.x; raw[1] = c0.y; raw[2] = c0.z;
@@ -456,7 +453,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             const float NgC = dot_fma(cross_fma(e2, e1), v0);
             // (a geometry with culling data is kept in Morton order; when it goes through the unculled launch after all -- more
             // than kGeomsPerLaunch such geometries -- perm carries the sorted position back to the caller's triangle)
-            const uint32_t gid = src.gid_first + ((CULLED || (LS_EXP_CORNERS && src.corners)) ? tri_id : (src.perm ? src.perm[k] : k));
+            const uint32_t gid = src.gid_first + (CULLED ? tri_id : (src.perm ? src.perm[k] : k));
             bool queued = false;
             if (cells > pp.big_cells) {
                 const uint32_t slot = atomicAdd(big_count, 1u);
@@ -1435,8 +1432,7 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
 
     // ---- geometries with group bounds: k_cull, then a launch whose waves read the survivors
     bool culled_done = false;
-    static const int exp_corners_only = lsi::tune_int("LS_NOCULL_CORNERS", 0);
-    if (cull_list && !exp_corners_only) {
+    if (cull_list) {
         GeomBatch batch;
         uint32_t blocks, entries;
         if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries)) {
