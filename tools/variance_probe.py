@@ -41,11 +41,13 @@ for rep in range(reps):
     def run(first, n):
         assert HL.lsh_stream_frames(tr.h, names, aff, na, len(meshes), P, Hh, Cn, 3, cap, first, n) == 0
     run(0, 600); tr.synchronize()
-    ws = []
-    for w in range(5):
-        t0 = time.perf_counter(); run(1000 * w, 1000); tr.synchronize(); ws.append((time.perf_counter() - t0) / 1000 * 1e6)
+    ws, enq = [], []
+    K = int(os.environ.get("PROBE_WINDOW", "1000"))   # frames per timed window
+    for w in range(int(os.environ.get("PROBE_WINDOWS", "5"))):
+        t0 = time.perf_counter(); run(K * w, K); t1 = time.perf_counter(); tr.synchronize(); ws.append((time.perf_counter() - t0) / K * 1e6); enq.append((t1 - t0) / K * 1e6)
     res.append(ws)
-    print("handle %d: us per frame, 5 windows of 1000: %s   streams %s" % (rep, " ".join("%.2f" % x for x in ws), tr.info(capi.LS_INFO_CONCURRENT_STREAMS)), flush=True)
+    print("handle %d: host enqueue us per frame: %s" % (rep, " ".join("%.2f" % x for x in enq)))
+    print("handle %d: us per frame per window: %s   streams %s" % (rep, " ".join("%.2f" % x for x in ws), tr.info(capi.LS_INFO_CONCURRENT_STREAMS)), flush=True)
     tr.close()
     del outs, keep
     torch.cuda.empty_cache()
