@@ -477,3 +477,27 @@ def test_two_step_trace_headline_size(oracle, capi, sensors):
     assert tr.L.ls_trace_scene_expand(tr.h, buf.ctypes.data + off) == 0
     assert np.array_equal(buf[off:off + int(n.value) * 32].reshape(-1, 32), ref["points"])
     tr.close()
+
+
+def test_two_step_trace_on_an_azimuth_shard(oracle, capi, sensors, meshes):
+    """The two-step trace on a handle that traces a sector only (ls_tracer_set_shard): the (ray, t) records carry the ray's
+    number on the FULL raster, the host rebuilds the points with the full tables -- the sector's cloud is the full cloud's
+    points whose column lies in the sector, in the same order."""
+    s = sensors["0001"]
+    tr = make_tracer(capi, s, "projection")
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.addGeometry("face", *[a.shape[0] for a in meshes["ben"]])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
+    cols = ref["hits"][:, 0] % s.H
+    seen = 0
+    for first, n in ((0, s.H // 3), (s.H // 3, s.H // 2), (s.H // 3 + s.H // 2, s.H - s.H // 3 - s.H // 2)):
+        tr.setShard(first, n)
+        assert tr.commitScene() == 0
+        rc, pts = tr.traceSceneTwoStep(first)
+        want = ref["points"][(cols >= first) & (cols < first + n)]
+        assert rc == 0 and np.array_equal(pts, want), (first, n, pts.shape, want.shape)
+        seen += pts.shape[0]
+    assert seen == ref["points"].shape[0] and seen > 0
+    tr.close()
