@@ -256,9 +256,13 @@ int ls_tracer_flush(ls_tracer *tr);
  *       three frames in flight the two other frames keep running.
  *   ls_tracer_wait_event  makes everything the handle does from now on (its next frames included, whatever stream
  *       carries them) start after hip_event (a hipEvent_t) has completed -- e.g. the event behind the last reader of an
- *       output buffer that the next frame writes again. */
+ *       output buffer that the next frame writes again.
+ *   ls_tracer_next_frame_waits  the narrow form of the same: only the frame issued NEXT starts after hip_event (with three
+ *       frames in flight that is one wait on that frame's stream instead of three runtime calls; the frames after it are
+ *       not ordered behind the event unless they are behind that frame anyway). */
 int ls_tracer_order_after_last_frame(ls_tracer *tr, void *hip_stream);
 int ls_tracer_wait_event(ls_tracer *tr, void *hip_event);
+int ls_tracer_next_frame_waits(ls_tracer *tr, void *hip_event);
 
 /* Write packed points / hit records into caller-owned device buffers (capacity in records,
  * >= ls_total_rays of the shard) instead of the handle's own; NULL restores the default. */

@@ -56,8 +56,8 @@ struct ls_group {
     int mode = LS_GROUP_SHARDED;
     ls_tracer *tr = nullptr;
     ncclComm_t comm = nullptr;
-    hipStream_t trace_stream = nullptr, comm_stream = nullptr;
-    hipEvent_t ev_traced[kSets] = {}, ev_collected[kSets] = {};
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_collected[kSets] = {};
     bool used[kSets] = {};
     uint32_t capacity = 0, cloud_capacity = 0;
     size_t slot_bytes = 0;
@@ -154,7 +154,6 @@ void ls_group_destroy(ls_group *g)
     if (g->comm_stream) (void)hipStreamSynchronize(g->comm_stream);
     if (g->comm && rccl().CommDestroy) (void)rccl().CommDestroy(g->comm);
     for (int i = 0; i < kSets; ++i) {
-        if (g->ev_traced[i]) (void)hipEventDestroy(g->ev_traced[i]);
         if (g->ev_collected[i]) (void)hipEventDestroy(g->ev_collected[i]);
         (void)hipFree(g->slot[i]);
         (void)hipFree(g->gathered[i]);
@@ -163,7 +162,6 @@ void ls_group_destroy(ls_group *g)
         (void)hipFree(g->cloud_n[i]);
     }
     (void)hipFree(g->local_points);
-    if (g->trace_stream) (void)hipStreamDestroy(g->trace_stream);
     if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
     delete g;
 }
@@ -193,13 +191,9 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
     if (h < 2 || !V) return bail(LS_ERR_INVALID_ARGUMENT);
     const uint32_t H = (uint32_t)h;
     g->full_turn = H;
-    if (hipStreamCreateWithFlags(&g->trace_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(LS_ERR_HIP);
+    if (hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking) != hipSuccess) return bail(LS_ERR_HIP);
     for (int i = 0; i < kSets; ++i)
-        if (hipEventCreateWithFlags(&g->ev_traced[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g->ev_collected[i], hipEventDisableTiming) != hipSuccess)
-            return bail(LS_ERR_HIP);
+        if (hipEventCreateWithFlags(&g->ev_collected[i], hipEventDisableTiming) != hipSuccess) return bail(LS_ERR_HIP);
     g->cloud_capacity = V * H;
     uint32_t first = 0, n = H;
     if (mode == LS_GROUP_SHARDED) {
@@ -228,7 +222,9 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
     g->tr = tr;
     attached = true;
     g->pipeline_before = std::max(0l, ls_get_info(tr, LS_INFO_PIPELINE_MODE));
-    if (ls_tracer_set_stream(tr, g->trace_stream) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
+    // (the tracer stays on its own stream: a frame is handed to the collective stream by ls_tracer_order_after_last_frame, and
+    // a handle on a caller's stream would order every frame's stream after that stream -- two runtime calls per frame)
+    if (ls_tracer_set_stream(tr, nullptr) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
     // three frames in flight per rank (the library falls back to two on one stream when the device does not give it
     // three concurrent streams): the gather + rebuild of frame f overlap the tracing of f+1 and f+2, per frame the
     // collective stream waits for that frame alone (ls_tracer_order_after_last_frame), never for the tracer as a whole
@@ -260,16 +256,14 @@ int ls_group_trace(ls_group *g, uint32_t frame_index)
         return rc == -1 ? -1 : 0;
     }
     // the set's previous frame (three frames ago) must have left its slot: the gather reads it on the other stream
-    if (g->used[b] && ls_tracer_wait_event(g->tr, g->ev_collected[b]) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
+    if (g->used[b] && ls_tracer_next_frame_waits(g->tr, g->ev_collected[b]) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
     if (ls_tracer_set_output_buffers(g->tr, g->local_points, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]),
                                      g->capacity) != LS_OK)
         return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
     const int rc = ls_trace_scene_async(g->tr, frame_index, &f);
     if (rc < -1) return fail(g, rc, ls_last_error(g->tr));
     if (rc == -1) {   // empty scene: nothing was traced, an empty slot travels
-        LSG_HIP(hipMemsetAsync(g->slot[b], 0, 4, g->trace_stream));
-        LSG_HIP(hipEventRecord(g->ev_traced[b], g->trace_stream));
-        LSG_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_traced[b], 0));
+        LSG_HIP(hipMemsetAsync(g->slot[b], 0, 4, g->comm_stream));   // (the collective stream is the slot's only reader; its last gather of this slot is behind it there)
     } else if (ls_tracer_order_after_last_frame(g->tr, g->comm_stream) != LS_OK) {   // this frame's slot is complete for the gather; frames in flight go on
         return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
     }

@@ -738,6 +738,20 @@ int ls_tracer_wait_event(ls_tracer *tr, void *hip_event)
     return LS_OK;
 }
 
+int ls_tracer_next_frame_waits(ls_tracer *tr, void *hip_event)
+{
+    LS_ENTER(tr);
+    if (!hip_event) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null event");
+    // three-stream mode with its streams in place: the next frame runs on slot ms_seq % 3 -- one wait there
+    if (tr->opt_pipeline == 2 && use_projection(tr) && tr->slot_stream[0] && !tr->opt_count && !tr->opt_timing) {
+        LS_HIP(hipStreamWaitEvent(tr->slot_stream[tr->ms_seq % 3u], static_cast<hipEvent_t>(hip_event), 0));
+        return LS_OK;
+    }
+    LS_HIP(hipStreamWaitEvent(tr->stream, static_cast<hipEvent_t>(hip_event), 0));
+    ++tr->main_epoch;
+    return LS_OK;
+}
+
 int ls_tracer_order_after_last_frame(ls_tracer *tr, void *hip_stream)
 {
     LS_ENTER(tr);
