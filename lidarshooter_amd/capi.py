@@ -143,6 +143,7 @@ def load() -> C.CDLL:
     L.ls_tracer_flush.argtypes = [vp]
     L.ls_tracer_order_after_last_frame.argtypes = [vp, vp]
     L.ls_tracer_wait_event.argtypes = [vp, vp]
+    L.ls_tracer_next_frame_waits.argtypes = [vp, vp]
     L.ls_tracer_set_option.argtypes = [vp, i32, i32]
     L.ls_get_timings.argtypes = [vp, f32p]
     L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -352,6 +353,10 @@ class Tracer:
 
     def waitEvent(self, event_ptr: int):
         self._check(self.L.ls_tracer_wait_event(self.h, event_ptr), "ls_tracer_wait_event")
+
+    def nextFrameWaits(self, event_ptr: int):
+        """only the frame issued next starts after the hipEvent_t (one wait on that frame's stream)"""
+        self._check(self.L.ls_tracer_next_frame_waits(self.h, event_ptr), "ls_tracer_next_frame_waits")
 
     def flush(self):
         return self._check(self.L.ls_tracer_flush(self.h), "ls_tracer_flush")

@@ -110,8 +110,8 @@ def test_sharded_path_two_logical_ranks_on_one_device(oracle, capi, sensors, mes
     for f, A in enumerate(poses):
         b = f % sets
         for rank, tr in enumerate(trs):
-            if used[b]:
-                tr.waitEvent(collected[b].cuda_event)            # the slot's previous tenant has been rebuilt into its cloud
+            if used[b]:                                          # the slot's previous tenant has been rebuilt into its cloud
+                (tr.waitEvent if rank == 0 else tr.nextFrameWaits)(collected[b].cuda_event)   # (both forms of the guard)
             slot = gathered[b].data_ptr() + rank * sb
             tr.setOutputBuffers(local_pts[rank][b].data_ptr(), slot + shards.HEADER, slot, cap)
             tr.updateGeometryTransform("face", A)
