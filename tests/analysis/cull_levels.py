@@ -2,7 +2,7 @@
 dropped because no ring of the SYN-128 raster passes between the block's lowest and highest vertex elevation -- the
 optimum any per-block bound can reach.  usage: cull_levels.py [1m|10m]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle as O

@@ -1,7 +1,7 @@
 """Diagnostic: per-ray node-fetch distribution of the bench workload on the BVH the GPU built."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from lidarshooter_amd import capi, hostapi, synth
 from oracle import oracle as O

@@ -1,8 +1,8 @@
-"""Soak: tens of thousands of frames through the paths that hand data between threads, streams and the host -- the two-step
+"""(Test infrastructure: uses the oracle.)  Soak: tens of thousands of frames through the paths that hand data between threads, streams and the host -- the two-step
 trace (host flags, worker pool, rebuild from (ray, t) records), frames in flight in every LS_OPT_PIPELINE mode, mesh poses
 changing every frame -- each checked against the one-step synchronous call on the same handle.  usage: soak.py [seconds]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
