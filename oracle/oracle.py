@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
         L.lso_cloud_to_world.argtypes = [u8p, C.c_uint32, f32p, f32p, f32p, u8p]
         L.lso_tri_intersect.argtypes = [f32p] * 5 + [f32p]
         L.lso_tri_intersect.restype = C.c_int
+        L.lso_set_edge_rule.argtypes = [C.c_int]
+        L.lso_get_edge_rule.restype = C.c_int
         L.lso_trace_bruteforce.argtypes = [f32p, C.c_uint32, f32p, u32p, C.c_uint32, f32p, u32p, C.c_int]
         L.lso_bvh_build.argtypes = [f32p, u32p, C.c_uint32, C.c_int]
         L.lso_bvh_build.restype = C.c_void_p
@@ -69,6 +71,24 @@ def lib() -> C.CDLL:
                                              C.c_uint32, f32p, u32p, u64p, u32p]
         _lib = L
     return _lib
+
+
+class edge_rule:
+    """TEST-ONLY: `with edge_rule(1):` runs the closest-hit test with the packet form of Embree's third edge test
+    (W = absDen - U - V >= 0) instead of the single-ray form (U + V <= absDen); ls_oracle.c:tri_test.  The default (0)
+    is what every parity test, smoke() and bench.py's cpu_baseline use."""
+
+    def __init__(self, rule: int):
+        self.rule = int(rule)
+
+    def __enter__(self):
+        self.prev = lib().lso_get_edge_rule()
+        lib().lso_set_edge_rule(self.rule)
+        return self
+
+    def __exit__(self, *exc):
+        lib().lso_set_edge_rule(self.prev)
+        return False
 
 
 def _p(a: np.ndarray, ty):
