@@ -8,9 +8,12 @@ updateGeometry(every mesh) + commitScene (vertex transform + full BVH rebuild) +
 (ray generation + closest hit + point packing), with the mesh already resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): rays are
-  sharded by azimuth sector, every rank keeps a full BVH replica, and one all-gather of the
-  fixed-capacity hit-record slots per frame (count word in the slot header) collects the cloud.
+  N > 1: one rank per GPU over RCCL, either launched by the driver through torch.distributed.run (RANK / WORLD_SIZE in
+  the environment) or -- when WORLD_SIZE is not set -- by this script itself, which then starts
+  `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process BEFORE anything here touches a
+  GPU and passes the child's one JSON line through.  It never measures fewer GPUs than --gpus asks for.  Rays are
+  sharded by azimuth sector, every rank keeps a scene replica, and one all-gather of the fixed-capacity hit-record
+  slots per frame (count word in the slot header) collects the cloud.
 
 Rank 0 prints ONE JSON line (see README/DESIGN.md for the extra keys).
 """
@@ -78,6 +81,13 @@ def parse_args():
                     help="sharded mode: c (default) = include/lidarshooter_group.h -- the frame loop, the RCCL all-gather and the "
                          "rebuild of the cloud run in C, three frames in flight per rank; torch = torch.distributed issues the "
                          "all-gather (two frames in flight; the path LS_BENCH_REHEARSAL rehearses over gloo)")
+    ap.add_argument("--group-flags", type=int, default=0,
+                    help="sharded mode, C driver: LS_GROUP_FLAG_* of include/lidarshooter_group.h (0 = per-set communicators and streams, "
+                         "every frame one captured HIP graph; 1 = round 3's arrangement: one communicator on a collective stream; 2 = per-set, plain launches)")
+    ap.add_argument("--frame-graph", type=int, default=0, choices=[0, 1],
+                    help="single GPU: LS_OPT_FRAME_GRAPH (the three launches of a frame as one captured HIP graph)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="start the ranks, have them meet (one all-reduce), print how many did, and exit: no GPU work (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the ITracer-adapter (host buffers, PointCloud2) legs")
     ap.add_argument("--cpu-frames", type=int, default=6)
@@ -273,8 +283,36 @@ def cpu_baseline(sensor, meshes, frames, total_rays):
     }
 
 
+def spawn_ranks(args) -> int:
+    """--gpus N without a launcher: start the N ranks as a fresh child process tree (torch.distributed.run) -- nothing in
+    THIS process has touched a GPU yet (importing torch does not; torch.cuda.device_count() does not initialise one on
+    this image either) -- and hand the child's stdout (rank 0's one JSON line) through.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("LS_BENCH_REHEARSAL") == "1"
+    if not rehearsal and not args.spawn_check:
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node shows {n} GPU(s): refusing to measure fewer than asked for", file=sys.stderr)
+            return 2
+    with socket.socket() as so:   # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer mappings need it on this driver
+    env["LS_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before any GPU call), never a silent one-GPU run
+        raise SystemExit(spawn_ranks(args))
     # stdout carries ONE JSON line: whatever native libraries print there (RCCL's version banner at communicator creation)
     # goes to stderr instead -- file descriptor 1 is pointed at stderr, the real stdout is kept for the result line
     sys.stdout.flush()
@@ -283,8 +321,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not say what was measured")
+    if args.spawn_check:
+        # the ranks meet and count themselves; rank 0 reports (gloo under LS_BENCH_REHEARSAL=1 or without a GPU, else RCCL)
+        use_gloo = os.environ.get("LS_BENCH_REHEARSAL") == "1" or not torch.cuda.is_available()
+        if world > 1:
+            if not use_gloo:
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo" if use_gloo else "nccl")
+            one = torch.ones(1, dtype=torch.int64, device="cpu" if use_gloo else f"cuda:{local_rank}")
+            dist.all_reduce(one)
+            seen = int(one.item())
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"spawn_check": True, "n_gpus": world, "ranks_met": seen, "backend": "gloo" if use_gloo else "nccl",
+                                             "spawned_by_bench": os.environ.get("LS_BENCH_SPAWNED") == "1"}) + "\n").encode())
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # LS_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo -- only to rehearse the N > 1 code path on
@@ -362,6 +417,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
     # a dedicated (non-default) stream shared by the tracer's kernels and, through torch, by RCCL's
     # stream dependencies: the all-gather of frame i is ordered after frame i's pack kernel
     stream = torch.cuda.Stream(device)
+    rccl_info = None
     # sharded frames through include/lidarshooter_group.h: frame loop, RCCL all-gather and cloud rebuild in C (RCCL does not
     # take two ranks on one device: the gloo rehearsal on a one-GPU box goes through the torch driver)
     cgroup = (world > 1 or force_group) and not independent and args.multi_driver == "c" and not rehearsal
@@ -391,6 +447,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         count_words = out_bufs
         if pipeline:
             tr.setOption(capi.LS_OPT_PIPELINE, args.pipeline)
+            if args.frame_graph:
+                tr.setOption(capi.LS_OPT_FRAME_GRAPH, 1)
     elif cgroup:
         from lidarshooter_amd import groupapi
         uid = torch.zeros(groupapi.ID_BYTES, dtype=torch.uint8, device=device)
@@ -402,7 +460,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
             uid = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=device)
         if world > 1:
             dist.broadcast(uid, src=0)
-        grp = groupapi.Group(tr, world, rank, groupapi.SHARDED, bytes(uid.cpu().numpy().tobytes()))
+        grp = groupapi.Group(tr, world, rank, groupapi.SHARDED, bytes(uid.cpu().numpy().tobytes()), flags=args.group_flags)
+        rccl_info = grp.rccl()
         count_words = None
     else:
         # N > 1: the travelling slot holds the count word and the 16-byte hit records only (shards.py);
@@ -416,6 +475,26 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         cloud_n = torch.zeros(16, dtype=torch.int32, device=device)
         works = [None, None]
         count_words = slots
+
+    # what the collective library itself says about the job ("no field says how many ranks RCCL saw")
+    rccl_out = None
+    if not single:
+        if rccl_info is None:   # torch driver: torch.distributed's communicator
+            rccl_info = {"version": None if rehearsal else int("%d%02d%02d" % tuple(torch.cuda.nccl.version()[:3])),
+                         "comm_ranks": dist.get_world_size() if world > 1 else 1, "device": dev_index, "communicators": 1,
+                         "per_set_streams": False, "frame_graph_state": 0, "through": "torch.distributed (" + dist.get_backend() + ")" if world > 1 else "none"}
+        else:
+            rccl_info["through"] = "include/lidarshooter_group.h (ncclCommCount / ncclCommCuDevice / ncclGetVersion of the group's own communicator)"
+        mine = {"rank": rank, "hip_device": dev_index, "comm_device": rccl_info.get("device"), "comm_ranks": rccl_info.get("comm_ranks")}
+        every = [mine]
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+        rccl_out = dict(rccl_info)
+        rccl_out.pop("device", None)
+        rccl_out["devices"] = [e["comm_device"] for e in every]
+        rccl_out["comm_ranks_on_every_rank"] = [e["comm_ranks"] for e in every]
+        rccl_out["launched_by"] = "bench.py itself (torch.distributed.run child)" if os.environ.get("LS_BENCH_SPAWNED") == "1" else "the caller's launcher"
 
     # The same four C-ABI calls per frame as below, bound once with their constant arguments: the loop is the
     # host side of the product path, and a per-call numpy conversion / string encode is Python's cost, not its
@@ -848,9 +927,14 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                             + (("; two frames in flight (finish + pack of frame i ride in the launch of frame i+1)"
                                 if args.pipeline == 1 else "; three frames in flight (whole frames rotate over three streams)")
                                if pipeline else ""),
-                   "parallelism": (f"azimuth-sector shards x{world}, scene replica per GPU, one ncclAllGather of hit-record slots per "
-                                   f"frame on a collective stream that waits for that frame alone, cloud rebuilt on every rank; three "
-                                   f"frames in flight per rank; frame loop, collective and rebuild in C (include/lidarshooter_group.h)"
+                   "parallelism": ((f"azimuth-sector shards x{world}, scene replica per GPU, one ncclAllGather of hit-record slots per frame, "
+                                    f"cloud rebuilt on every rank; three frames in flight per rank, each buffer set with a communicator and a "
+                                    f"stream of its own: trace + gather + rebuild of a frame are ONE captured HIP graph launch (poses patched into "
+                                    f"the k_project node); frame loop in C (include/lidarshooter_group.h)"
+                                    if rccl_out and rccl_out.get("per_set_streams") and rccl_out.get("frame_graph_state") == 1 else
+                                    f"azimuth-sector shards x{world}, scene replica per GPU, one ncclAllGather of hit-record slots per "
+                                    f"frame on a collective stream that waits for that frame alone, cloud rebuilt on every rank; three "
+                                    f"frames in flight per rank; frame loop, collective and rebuild in C (include/lidarshooter_group.h)")
                                    if cgroup else
                                    f"azimuth-sector shards x{world}, scene replica per GPU, one async all-gather of "
                                    f"hit-record slots per frame through torch.distributed (overlapped with the next "
@@ -871,6 +955,9 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         # N > 1: points of the whole frame as rebuilt from the gathered slots on rank 0 (= the 1-GPU hit count)
         "gathered_points_rank0": None if single else (int(grp.download(args.steps - 1)[0].shape[0]) if cgroup else int(cloud_n[0].item())),
         "rehearsal_gloo_shared_gpu": True if rehearsal else None,
+        "rccl": rccl_out,
+        "frame_graph": {"state": tr.info(capi.LS_INFO_FRAME_GRAPH_STATE), "captures": tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES),
+                        "replays": tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS), "patches": tr.info(capi.LS_INFO_FRAME_GRAPH_PATCHES)},
         "roofline": dict({
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

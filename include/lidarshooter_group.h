@@ -17,6 +17,15 @@
  *                         and memory latency, not by work: sharding it cannot win what a collective costs; interleaving can.)
  *
  * Frames rotate over three sets of buffers, so the gather + rebuild of frame f overlap the tracing of f+1 and f+2.
+ *
+ * SHARDED, since round 4 ("per-set" mode, the default): the group holds one communicator PER BUFFER SET (the one made
+ * from the id and two duplicates of it: ncclCommSplit, or a second id broadcast over the first), so that everything of a
+ * frame -- the three launches of the trace, ncclAllGather, the rebuild of the cloud -- is consecutive work on ONE stream,
+ * the tracer's stream for that set, with no event and no cross-stream wait; and with LS_OPT_FRAME_GRAPH (switched on by
+ * the group) that work is captured once per set into a HIP graph: a frame is one hipGraphLaunch, the k_project node's
+ * arguments patched first when a pose changed.  The three sets' collectives run on three communicators and three
+ * streams; every rank issues them in the same order.  LS_GROUP_FLAG_ONE_COMMUNICATOR keeps round 3's arrangement (one
+ * communicator on a collective stream of its own, an event per hand-over): nine runtime calls per frame instead of one.
  */
 #ifndef LIDARSHOOTER_GROUP_H
 #define LIDARSHOOTER_GROUP_H
@@ -53,6 +62,13 @@ int ls_group_unique_id(uint8_t id[LS_GROUP_ID_BYTES]);
  * On failure the tracer is left, or put back, as ls_group_destroy leaves it: on its own stream, on the full turn, on
  * its own output buffers -- usable as a single-GPU tracer (the fallback when RCCL is missing: LS_ERR_NO_DEVICE). */
 int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, ls_tracer *tr, ls_group **out);
+/* the same with flags (equal on every rank):
+ *   LS_GROUP_FLAG_ONE_COMMUNICATOR  round 3's arrangement: one communicator, a collective stream, events between the streams
+ *   LS_GROUP_FLAG_NO_GRAPH          per-set mode without LS_OPT_FRAME_GRAPH: five plain enqueues per frame on one stream */
+#define LS_GROUP_FLAG_ONE_COMMUNICATOR 1u
+#define LS_GROUP_FLAG_NO_GRAPH 2u
+int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, uint32_t flags, ls_tracer *tr,
+                         ls_group **out);
 void ls_group_destroy(ls_group *g);
 /* One frame, after the caller's updateGeometry / commitScene on the tracer: nothing in it waits for the device.
  * SHARDED: every rank calls it for every frame.  INTERLEAVED: every rank calls it for every frame too; it returns 1
@@ -67,6 +83,14 @@ int ls_group_cloud(ls_group *g, uint32_t frame_index, ls_frame *out);
  * be NULL); returns the number of points or a negative ls_status.  capacity in points. */
 long ls_group_download_cloud(ls_group *g, uint32_t frame_index, void *points32, void *hits, uint32_t capacity);
 int ls_group_synchronize(ls_group *g);
+/* What RCCL itself says about the group (bench.py's "rccl" object): */
+#define LS_GROUP_INFO_RCCL_VERSION 1   /* ncclGetVersion (e.g. 22707)                                          */
+#define LS_GROUP_INFO_COMM_RANKS 2     /* ncclCommCount of the group's communicator: how many ranks RCCL sees   */
+#define LS_GROUP_INFO_COMM_DEVICE 3    /* ncclCommCuDevice: the HIP device the communicator is bound to          */
+#define LS_GROUP_INFO_COMMUNICATORS 4  /* 3 in per-set mode, 1 otherwise, 0 when INTERLEAVED                      */
+#define LS_GROUP_INFO_PER_SET 5        /* 1: per-set mode (see the top of this header)                            */
+#define LS_GROUP_INFO_FRAME_GRAPH 6    /* the tracer's LS_INFO_FRAME_GRAPH_STATE: 0 off, 1 frames are graph launches, 2 refused */
+long ls_group_info(ls_group *g, int what);
 const char *ls_group_last_error(const ls_group *g);
 
 #ifdef __cplusplus

@@ -316,7 +316,48 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */
+#define LS_OPT_EMIT_POINTS 15   /* ls_trace_scene_async: 1 (default) the pack pass writes the 32-byte points and the 16-byte hit
+                                 *    records; 0: the hit records only (d_points32 stays untouched) -- for a consumer that
+                                 *    rebuilds points from (ray, t) anyway: a sharded group gathers hit records and
+                                 *    ls_expand_gathered_hits rebuilds every rank's points from them (8 MB of writes per
+                                 *    frame less at 524 288 rays).  The synchronous ls_trace_scene always delivers points.  */
+#define LS_OPT_FRAME_GRAPH 14   /* LS_OPT_PIPELINE = 2 (three frames in flight, projection engine): 1 = the launches of a frame
+                                 *    are captured ONCE per stream of the rotation into a HIP graph and every later frame
+                                 *    on that stream is one hipGraphLaunch; the kernel nodes whose arguments changed since
+                                 *    (a pose, an output buffer, the shard) are patched first
+                                 *    (hipGraphExecKernelNodeSetParams); a change of the launch sequence itself (another
+                                 *    set of geometries, culling switched) captures anew.  0 (default): plain launches.
+                                 *    Identical results; host cost per frame 9 -> 6 us for the three launches of a frame,
+                                 *    26 -> 6-8 us for a sharded group frame (tools/micro/graph_launch.hip).  A runtime
+                                 *    that refuses the capture leaves the handle on plain launches
+                                 *    (LS_INFO_FRAME_GRAPH_STATE).                                                        */
 int ls_tracer_set_option(ls_tracer *tr, int option, int value);
+
+/* A frame graph that also holds work of the CALLER's (include/lidarshooter_group.h: the frame's collective and the
+ * rebuild of the gathered cloud), so that the whole frame is one graph launch.  Needs LS_OPT_PIPELINE = 2 and
+ * LS_OPT_FRAME_GRAPH = 1.
+ *   ls_frame_graph_begin   the next ls_trace_scene_async leaves its frame graph open.  `tag` names the caller's part: a
+ *                          graph captured under another tag is captured anew.
+ *   ls_frame_graph_stream  after that ls_trace_scene_async: the stream (a hipStream_t) the frame is on, which of the three
+ *                          streams of the rotation it is (0..2: one graph, hence one set of caller buffers, per slot;
+ *                          LS_FRAME_NO_SLOT for a frame that ran on the handle's own stream: timing / counting frames) and
+ *                          how it is being built: LS_FRAME_EAGER (plain launches: the caller enqueues its own work on the
+ *                          stream as usual), LS_FRAME_CAPTURING (the stream is capturing: the caller enqueues its work on
+ *                          it ONCE, kernels of this library through this library's entry points, and it becomes part of the
+ *                          graph) or LS_FRAME_REPLAYING (the graph exists: the caller enqueues NOTHING except through
+ *                          this library's entry points, which only compare their arguments with the captured ones).
+ *   ls_frame_graph_end     closes the graph and launches it.  Returns 0, or 1 = nothing was launched, the graph was
+ *                          discarded (the launch sequence changed, or the runtime refused the capture): issue the
+ *                          frame again from ls_frame_graph_begin (at most once more).
+ *   ls_frame_graph_reset   destroys the cached graphs (a caller whose captured work dies -- a communicator -- calls it). */
+#define LS_FRAME_NO_SLOT 0xFFFFFFFFu
+#define LS_FRAME_EAGER 0
+#define LS_FRAME_CAPTURING 1
+#define LS_FRAME_REPLAYING 2
+int ls_frame_graph_begin(ls_tracer *tr, uint64_t tag);
+int ls_frame_graph_stream(ls_tracer *tr, void **hip_stream, uint32_t *slot, int *mode);
+int ls_frame_graph_end(ls_tracer *tr);
+int ls_frame_graph_reset(ls_tracer *tr);
 
 /* Rebuild n_points 32-byte PointCloud2 records (XYZIRBytes.cpp:24-40; intensity 64.0, EmbreeTracer.cpp:343) at
  * dst_points32 from the compact records of ls_frame.compact16, with the library's worker threads. */
@@ -337,6 +378,12 @@ int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
 #define LS_INFO_LAST_COMMIT_REFIT 6  /* BVH engine: 1 if the last commitScene refitted instead of rebuilding      */
 #define LS_INFO_BVH_INSTANCED 7      /* BVH engine: 0 classic hierarchy; 1 instanced and the last commit built nothing;
                                       *    2 instanced and the last commit (re)built some geometry's hierarchy        */
+#define LS_INFO_NEXT_SLOT 8           /* LS_OPT_PIPELINE = 2: which of the three streams (0..2) the NEXT frame runs on   */
+#define LS_INFO_FRAME_GRAPH_STATE 9   /* 0 off, 1 on, 2 on but the runtime refused a capture: plain launches since       */
+#define LS_INFO_FRAME_GRAPH_CAPTURES 10 /* frame graphs captured so far                                                  */
+#define LS_INFO_FRAME_GRAPH_REPLAYS 11  /* frames issued as one graph launch                                              */
+#define LS_INFO_FRAME_GRAPH_PATCHES 12  /* kernel nodes patched with new arguments before a replay                        */
+#define LS_INFO_FRAME_GRAPH_LAST_PATCHED 13 /* bit i: launch i of the frame replayed last went out with new arguments     */
 long ls_get_info(ls_tracer *tr, int what);
 
 /* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded

@@ -22,6 +22,10 @@ LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL,
 LS_INFO_LAST_COMMIT_REFIT = 6
 LS_OPT_BVH_INSTANCED = 12
 LS_OPT_UPLOAD_MODE = 13
+LS_OPT_FRAME_GRAPH = 14
+LS_OPT_EMIT_POINTS = 15
+LS_INFO_FRAME_GRAPH_LAST_PATCHED = 13
+LS_INFO_NEXT_SLOT, LS_INFO_FRAME_GRAPH_STATE, LS_INFO_FRAME_GRAPH_CAPTURES, LS_INFO_FRAME_GRAPH_REPLAYS, LS_INFO_FRAME_GRAPH_PATCHES = 8, 9, 10, 11, 12
 LS_GEOMETRY_TYPE_TRIANGLE, LS_GEOMETRY_TYPE_QUAD = 0, 1
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("direction", "<f4", 3), ("tmax", "<f4")])   # Ray.hpp:16-35
 REFHIT_DTYPE = np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("intensity", "<f4"), ("ring", "<i4")])       # Hit.hpp:16-29
@@ -39,6 +43,7 @@ SYMBOLS = (
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
     "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type", "ls_tracer_order_after_last_frame", "ls_tracer_wait_event", "ls_tracer_next_frame_waits", "ls_trace_scene_begin", "ls_trace_scene_expand",
+    "ls_frame_graph_begin", "ls_frame_graph_stream", "ls_frame_graph_end", "ls_frame_graph_reset",
 )
 # include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
 DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",
@@ -144,6 +149,10 @@ def load() -> C.CDLL:
     L.ls_tracer_order_after_last_frame.argtypes = [vp, vp]
     L.ls_tracer_wait_event.argtypes = [vp, vp]
     L.ls_tracer_next_frame_waits.argtypes = [vp, vp]
+    L.ls_frame_graph_begin.argtypes = [vp, C.c_uint64]
+    L.ls_frame_graph_stream.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    L.ls_frame_graph_end.argtypes = [vp]
+    L.ls_frame_graph_reset.argtypes = [vp]
     L.ls_tracer_set_option.argtypes = [vp, i32, i32]
     L.ls_get_timings.argtypes = [vp, f32p]
     L.ls_get_visit_counts.argtypes = [vp, C.POINTER(C.c_uint64)]

@@ -20,6 +20,16 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (the group works without them, with less to report / on the round-3 path)
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     std::string err;
     bool load()
     {
@@ -36,6 +46,15 @@ struct Rccl {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
         if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) { err = "librccl lacks an entry point"; return false; }
+        CommSplit = reinterpret_cast<decltype(CommSplit)>(dlsym(lib, "ncclCommSplit"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+        CommCuDevice = reinterpret_cast<decltype(CommCuDevice)>(dlsym(lib, "ncclCommCuDevice"));
+        GetVersion = reinterpret_cast<decltype(GetVersion)>(dlsym(lib, "ncclGetVersion"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
         return true;
     }
 };
@@ -56,6 +75,16 @@ struct ls_group {
     int mode = LS_GROUP_SHARDED;
     ls_tracer *tr = nullptr;
     ncclComm_t comm = nullptr;
+    // per-set mode (the default): one communicator per buffer set -- comm, then two duplicates of it -- so that the whole of
+    // set b's frame (trace, gather, rebuild) lives on ONE stream, the tracer's slot stream b, and is one graph launch
+    ncclComm_t comm_dup[kSets - 1] = {};
+    bool per_set = false;
+    uint32_t flags = 0;
+    long frame_graph_before = 0;           // the tracer's LS_OPT_FRAME_GRAPH as the group found it
+    bool frame_graph_set = false;          // ... and whether the group changed it
+    uint32_t set_frame[kSets] = {};        // which frame each set holds
+    bool set_valid[kSets] = {};
+    hipStream_t loose[kSets] = {};         // per-set mode: a stream with work the tracer's flush does not know of (empty-scene frames)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_collected[kSets] = {};
     bool used[kSets] = {};
@@ -145,13 +174,20 @@ void ls_group_destroy(ls_group *g)
 {
     if (!g) return;
     if (g->tr) {
-        (void)ls_tracer_synchronize(g->tr);
+        (void)ls_group_synchronize(g);
+        if (g->frame_graph_set) {   // the cached frame graphs hold this group's collectives: they go before the communicators do
+            (void)ls_frame_graph_reset(g->tr);
+            (void)ls_tracer_set_option(g->tr, LS_OPT_FRAME_GRAPH, (int)g->frame_graph_before);
+        }
         (void)ls_tracer_set_output_buffers(g->tr, nullptr, nullptr, nullptr, 0);
+        (void)ls_tracer_set_option(g->tr, LS_OPT_EMIT_POINTS, 1);
         (void)ls_tracer_set_option(g->tr, LS_OPT_PIPELINE, (int)g->pipeline_before);
         (void)ls_tracer_set_stream(g->tr, nullptr);   // back on its own stream before the group's streams go
         if (g->full_turn) (void)ls_tracer_set_shard(g->tr, 0, g->full_turn);
     }
     if (g->comm_stream) (void)hipStreamSynchronize(g->comm_stream);
+    for (ncclComm_t &c : g->comm_dup)
+        if (c && rccl().CommDestroy) { (void)rccl().CommDestroy(c); c = nullptr; }
     if (g->comm && rccl().CommDestroy) (void)rccl().CommDestroy(g->comm);
     for (int i = 0; i < kSets; ++i) {
         if (g->ev_collected[i]) (void)hipEventDestroy(g->ev_collected[i]);
@@ -166,7 +202,37 @@ void ls_group_destroy(ls_group *g)
     delete g;
 }
 
+namespace {
+// a second communicator over the same ranks: ncclCommSplit with one colour where RCCL has it, else a fresh id that
+// rank 0 makes and the first communicator broadcasts.  Collective; nullptr when neither works.
+ncclComm_t duplicate_comm(ls_group *g, hipStream_t s)
+{
+    Rccl &R = rccl();
+    ncclComm_t dup = nullptr;
+    if (R.CommSplit && R.CommSplit(g->comm, 0, (int)g->rank, &dup, nullptr) == ncclSuccess && dup) return dup;
+    dup = nullptr;
+    if (!R.Broadcast) return nullptr;
+    ncclUniqueId u;
+    std::memset(&u, 0, sizeof(u));
+    if (g->rank == 0 && R.GetUniqueId(&u) != ncclSuccess) std::memset(&u, 0, sizeof(u));   // (the others then fail to join, all alike)
+    void *d = nullptr;
+    if (hipMalloc(&d, sizeof(u)) != hipSuccess) return nullptr;
+    bool ok = hipMemcpyAsync(d, &u, sizeof(u), hipMemcpyHostToDevice, s) == hipSuccess &&
+              R.Broadcast(d, d, sizeof(u), ncclUint8, 0, g->comm, s) == ncclSuccess &&
+              hipMemcpyAsync(&u, d, sizeof(u), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(d);
+    if (ok) ok = R.CommInitRank(&dup, (int)g->world, u, (int)g->rank) == ncclSuccess;
+    return ok ? dup : nullptr;
+}
+}  // namespace
+
 int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, ls_tracer *tr, ls_group **out)
+{
+    return ls_group_create_opts(id, world, rank, mode, 0u, tr, out);
+}
+
+int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, uint32_t flags, ls_tracer *tr,
+                         ls_group **out)
 {
     if (!out) return LS_ERR_INVALID_ARGUMENT;
     *out = nullptr;
@@ -176,6 +242,7 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
     g->world = world;
     g->rank = rank;
     g->mode = mode;
+    g->flags = flags;
     // Everything that can fail without the tracer comes first (streams, events, RCCL, the communicator, device memory):
     // until `attached` the caller's tracer has not been touched and a failure leaves it exactly as it was.  Afterwards
     // a failure puts it back on its own stream, on the full turn and on its own output buffers before the group's
@@ -205,7 +272,19 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
         ncclUniqueId u;
         std::memcpy(&u, id, sizeof(u));
         if (rccl().CommInitRank(&g->comm, (int)world, u, (int)rank) != ncclSuccess) return bail(LS_ERR_HIP);
-        if (hipMalloc(reinterpret_cast<void **>(&g->local_points), (size_t)g->capacity * 32) != hipSuccess) return bail(LS_ERR_HIP);
+        // per-set mode: a communicator per buffer set (collective: every rank takes this branch or none does -- the flags
+        // are the caller's and equal on all ranks).  Without the duplicates the group runs round 3's path.
+        if (!(flags & LS_GROUP_FLAG_ONE_COMMUNICATOR)) {
+            bool all = true;
+            for (int i = 0; i < kSets - 1 && all; ++i) all = (g->comm_dup[i] = duplicate_comm(g, g->comm_stream)) != nullptr;
+            if (!all)
+                for (ncclComm_t &c : g->comm_dup)
+                    if (c) { (void)rccl().CommDestroy(c); c = nullptr; }
+            g->per_set = all;
+        }
+        // (the shard's own 32-byte points are never written: LS_OPT_EMIT_POINTS = 0 below -- every rank rebuilds the whole
+        // frame's points from the gathered hit records; the pointer only has to be a valid one)
+        if (hipMalloc(reinterpret_cast<void **>(&g->local_points), 256) != hipSuccess) return bail(LS_ERR_HIP);
         for (int i = 0; i < kSets; ++i) {
             if (hipMalloc(reinterpret_cast<void **>(&g->slot[i]), g->slot_bytes) != hipSuccess ||
                 hipMalloc(reinterpret_cast<void **>(&g->gathered[i]), g->slot_bytes * world) != hipSuccess)
@@ -230,9 +309,84 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
     // collective stream waits for that frame alone (ls_tracer_order_after_last_frame), never for the tracer as a whole
     if (ls_tracer_set_option(tr, LS_OPT_PIPELINE, 2) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
     if (ls_tracer_set_shard(tr, first, n) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_INVALID_ARGUMENT); }
+    if (mode == LS_GROUP_SHARDED && ls_tracer_set_option(tr, LS_OPT_EMIT_POINTS, 0) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
+    // (every rank has the same device and library, so every rank arrives at the same answer here)
+    const bool three_streams = ls_get_info(tr, LS_INFO_PIPELINE_MODE) == 2;
+    g->per_set = g->per_set && three_streams;
+    if (three_streams && (g->per_set || mode == LS_GROUP_INTERLEAVED)) {   // frames as graph launches (INTERLEAVED: the three launches of a frame)
+        g->frame_graph_before = std::max(0l, ls_get_info(tr, LS_INFO_FRAME_GRAPH_STATE)) ? 1 : 0;
+        g->frame_graph_set = true;
+        if (ls_tracer_set_option(tr, LS_OPT_FRAME_GRAPH, (flags & LS_GROUP_FLAG_NO_GRAPH) ? 0 : 1) != LS_OK) {
+            g->err = ls_last_error(tr);
+            return bail(LS_ERR_HIP);
+        }
+    }
     *out = g;
     return LS_OK;
 }
+
+namespace {
+// Per-set mode, one SHARDED frame: the set is the tracer's next slot, so that the frame's launches, its gather (this set's
+// communicator) and the rebuild of the cloud are consecutive work on ONE stream -- no event, no cross-stream wait -- and,
+// with LS_OPT_FRAME_GRAPH, one captured graph per set that every later frame of the set replays with a single
+// hipGraphLaunch (the poses that changed are patched into the k_project node first).  Three frames in flight: the
+// three sets' streams.  Host cost per frame through a one-rank communicator: 39 us (round 3) -> see DESIGN.md section 8.
+int trace_per_set(ls_group *g, uint32_t frame_index)
+{
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const long nb = ls_get_info(g->tr, LS_INFO_NEXT_SLOT);
+        if (nb < 0 || nb >= kSets) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
+        const int b = (int)nb;
+        if (ls_tracer_set_output_buffers(g->tr, g->local_points, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]),
+                                         g->capacity) != LS_OK)
+            return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
+        if (ls_frame_graph_begin(g->tr, reinterpret_cast<uintptr_t>(g)) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
+        ls_frame f;
+        const int rc = ls_trace_scene_async(g->tr, frame_index, &f);
+        if (rc < -1) {
+            (void)ls_frame_graph_end(g->tr);
+            return fail(g, rc, ls_last_error(g->tr));
+        }
+        void *stream_v = nullptr;
+        uint32_t slot = 0;
+        int mode = LS_FRAME_EAGER;
+        if (ls_frame_graph_stream(g->tr, &stream_v, &slot, &mode) != LS_OK || (slot != LS_FRAME_NO_SLOT && (int)slot != b)) {
+            (void)ls_frame_graph_end(g->tr);
+            return fail(g, LS_ERR_HIP, "the tracer's slot rotation and the group's sets disagree");
+        }
+        hipStream_t s = static_cast<hipStream_t>(stream_v);
+        // (a timing / counting frame runs on the handle's own stream, behind everything in flight: its gather and rebuild
+        // follow it there, and the host waits for them below, before set b's stream is used again -- a measurement path)
+        const bool off_rotation = slot == LS_FRAME_NO_SLOT;
+        if (rc == -1) {   // empty scene: nothing was traced (and no graph opened), an empty slot travels
+            LSG_HIP(hipMemsetAsync(g->slot[b], 0, 4, s));
+            g->loose[b] = s;
+        }
+        ncclComm_t comm = b == 0 ? g->comm : g->comm_dup[b - 1];
+        // (replaying: the gather is a node of the graph already; only this library's launches are described again)
+        if (mode != LS_FRAME_REPLAYING) {
+            const ncclResult_t r = rccl().AllGather(g->slot[b], g->gathered[b], g->slot_bytes, ncclUint8, comm, s);
+            if (r != ncclSuccess) {
+                (void)ls_frame_graph_end(g->tr);   // (a capture that holds a failed collective is not worth keeping either)
+                (void)ls_frame_graph_reset(g->tr);
+                return fail(g, LS_ERR_HIP, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+            }
+        }
+        if (ls_expand_gathered_hits_on(g->tr, s, g->gathered[b], g->world, g->capacity, g->cloud_points[b], g->cloud_hits[b], g->cloud_n[b]) != LS_OK) {
+            (void)ls_frame_graph_end(g->tr);
+            return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
+        }
+        const int e = ls_frame_graph_end(g->tr);
+        if (e == 1) continue;   // the graph was given up before anything was launched: once more (captured anew, or plain)
+        if (e != LS_OK) return fail(g, e, ls_last_error(g->tr));
+        if (off_rotation) LSG_HIP(hipStreamSynchronize(s));
+        g->set_frame[b] = frame_index;
+        g->set_valid[b] = true;
+        return rc == -1 ? -1 : 0;
+    }
+    return fail(g, LS_ERR_HIP, "the frame graph was discarded twice in a row");
+}
+}  // namespace
 
 int ls_group_owns_frame(const ls_group *g, uint32_t frame_index)
 {
@@ -249,12 +403,17 @@ int ls_group_trace(ls_group *g, uint32_t frame_index)
     const int b = (int)(seq % kSets);
     ls_frame f;
     if (g->mode == LS_GROUP_INTERLEAVED) {
+        g->set_frame[b] = frame_index;
+        g->set_valid[b] = true;
         if (ls_tracer_set_output_buffers(g->tr, g->cloud_points[b], g->cloud_hits[b], g->cloud_n[b], g->cloud_capacity) != LS_OK)
             return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
         const int rc = ls_trace_scene_async(g->tr, frame_index, &f);
         if (rc < -1) return fail(g, rc, ls_last_error(g->tr));
         return rc == -1 ? -1 : 0;
     }
+    if (g->per_set) return trace_per_set(g, frame_index);
+    g->set_frame[b] = frame_index;
+    g->set_valid[b] = true;
     // the set's previous frame (three frames ago) must have left its slot: the gather reads it on the other stream
     if (g->used[b] && ls_tracer_next_frame_waits(g->tr, g->ev_collected[b]) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
     if (ls_tracer_set_output_buffers(g->tr, g->local_points, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]),
@@ -281,8 +440,10 @@ int ls_group_cloud(ls_group *g, uint32_t frame_index, ls_frame *out)
 {
     if (!g || !out) return LS_ERR_INVALID_ARGUMENT;
     if (!ls_group_owns_frame(g, frame_index)) return fail(g, LS_ERR_OUT_OF_RANGE, "this rank does not hold that frame");
-    const uint32_t seq = g->mode == LS_GROUP_SHARDED ? frame_index : frame_index / g->world;
-    const int b = (int)(seq % kSets);
+    int b = -1;
+    for (int i = 0; i < kSets; ++i)
+        if (g->set_valid[i] && g->set_frame[i] == frame_index) b = i;
+    if (b < 0) return fail(g, LS_ERR_OUT_OF_RANGE, "that frame's buffers have been reused (three frames are kept)");
     std::memset(out, 0, sizeof(*out));
     out->frame = frame_index;
     out->n_rays = g->cloud_capacity;
@@ -312,7 +473,25 @@ int ls_group_synchronize(ls_group *g)
     const int rc = ls_tracer_synchronize(g->tr);
     if (rc != LS_OK) return fail(g, rc, ls_last_error(g->tr));
     LSG_HIP(hipStreamSynchronize(g->comm_stream));
+    for (hipStream_t &s : g->loose)
+        if (s) { LSG_HIP(hipStreamSynchronize(s)); s = nullptr; }
     return LS_OK;
+}
+
+long ls_group_info(ls_group *g, int what)
+{
+    if (!g) return LS_ERR_INVALID_ARGUMENT;
+    Rccl &R = rccl();
+    int v = 0;
+    switch (what) {
+    case LS_GROUP_INFO_RCCL_VERSION: return (R.lib && R.GetVersion && R.GetVersion(&v) == ncclSuccess) ? v : 0;
+    case LS_GROUP_INFO_COMM_RANKS: return (g->comm && R.CommCount && R.CommCount(g->comm, &v) == ncclSuccess) ? v : 0;
+    case LS_GROUP_INFO_COMM_DEVICE: return (g->comm && R.CommCuDevice && R.CommCuDevice(g->comm, &v) == ncclSuccess) ? v : -1;
+    case LS_GROUP_INFO_COMMUNICATORS: return g->comm ? (g->per_set ? kSets : 1) : 0;
+    case LS_GROUP_INFO_PER_SET: return g->per_set ? 1 : 0;
+    case LS_GROUP_INFO_FRAME_GRAPH: return g->tr ? ls_get_info(g->tr, LS_INFO_FRAME_GRAPH_STATE) : 0;
+    default: return fail(g, LS_ERR_INVALID_ARGUMENT, "unknown info key");
+    }
 }
 
 const char *ls_group_last_error(const ls_group *g) { return g ? g->err.c_str() : "null group"; }

@@ -212,6 +212,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     for (auto &kv : tr->geoms) free_geometry(kv.second);
     for (int i = 0; i < 3; ++i)
         if (tr->slot_stream[i]) (void)hipStreamSynchronize(tr->slot_stream[i]);
+    frame_graph_destroy(tr);
     release(tr->best_keys_b); release(tr->big_queue_b); release(tr->points_b); release(tr->hits_b); release(tr->pack_status);
     release(tr->best_keys_c); release(tr->big_queue_c); release(tr->points_c); release(tr->hits_c);
     if (tr->d_n_points_b) (void)hipFree(tr->d_n_points_b);
@@ -319,6 +320,12 @@ long ls_get_info(ls_tracer *tr, int what)
     case LS_INFO_AZIMUTH_COUNT: return (long)tr->H;
     case LS_INFO_LAST_COMMIT_REFIT: return (!tr->bvh_inst && tr->last_commit_refit) ? 1 : 0;
     case LS_INFO_BVH_INSTANCED: return tr->bvh_inst ? (tr->last_commit_built ? 2 : 1) : 0;
+    case LS_INFO_NEXT_SLOT: return tr->opt_pipeline == 2 ? (long)(tr->ms_seq % 3u) : 0;
+    case LS_INFO_FRAME_GRAPH_STATE: return tr->opt_frame_graph ? (tr->fg_broken ? 2 : 1) : 0;
+    case LS_INFO_FRAME_GRAPH_CAPTURES: return (long)tr->fg_captures;
+    case LS_INFO_FRAME_GRAPH_REPLAYS: return (long)tr->fg_replays;
+    case LS_INFO_FRAME_GRAPH_PATCHES: return (long)tr->fg_patches;
+    case LS_INFO_FRAME_GRAPH_LAST_PATCHED: return (long)tr->fg_last_patched;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }
@@ -396,6 +403,22 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
         tr->pipe_seq = 0;
         tr->ms_seq = 0;
         tr->opt_pipeline = value;
+        return LS_OK;
+    }
+    case LS_OPT_EMIT_POINTS:
+        if (value < 0 || value > 1) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_EMIT_POINTS: 0 or 1");
+        tr->opt_emit_points = value;
+        return LS_OK;
+    case LS_OPT_FRAME_GRAPH: {
+        if (value < 0 || value > 1) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_FRAME_GRAPH: 0 or 1");
+        if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open");
+        if (value == tr->opt_frame_graph) return LS_OK;
+        const int rc = flush_pipeline(tr);
+        if (rc) return rc;
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        frame_graph_destroy(tr);
+        tr->fg_broken = false;
+        tr->opt_frame_graph = value;
         return LS_OK;
     }
     case LS_OPT_ENGINE:

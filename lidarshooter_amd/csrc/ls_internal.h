@@ -11,6 +11,7 @@
 
 #include "../../include/lidarshooter_hip.h"
 #include "ls_kernels.h"
+#include "ls_launch.h"
 #include "ls_tuning.h"
 
 #include <hip/hip_runtime.h>
@@ -60,6 +61,15 @@ struct Geometry {
     const void *raw() const { return shared_raw ? shared_raw : d_raw; }
     const uint32_t *idx() const { return shared_idx ? shared_idx : d_idx; }
     float affine[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+};
+
+// LS_OPT_FRAME_GRAPH: the captured launches of one stream of the three-stream rotation
+struct FrameGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t sig = 0;                       // what decides the launch SEQUENCE (trace_locked: frame_signature)
+    std::vector<ls::LaunchRecord> recs;     // the launches as captured (arguments as of the last replay), in order
+    std::vector<hipGraphNode_t> nodes;      // their kernel nodes
 };
 
 template <typename T>
@@ -191,6 +201,7 @@ struct ls_tracer {
     int opt_host_output = 1;     // LS_OPT_HOST_OUTPUT: the pack kernel writes the pinned host buffers itself
     int opt_readback_hits = 1;   // LS_OPT_READBACK_HITS
     int opt_upload_mode = 1;     // LS_OPT_UPLOAD_MODE
+    int opt_emit_points = 1;     // LS_OPT_EMIT_POINTS
     int opt_debug_fault = 0;     // LS_OPT_DEBUG_FAULT (one frame)
     uint32_t *h_status = nullptr;   // sticky device status word in pinned host memory (bit 0: chained prefix gave up)
     // ls_trace_scene_begin / ls_trace_scene_expand: the device tells the host how far the frame is (ls::HostProgress)
@@ -202,6 +213,21 @@ struct ls_tracer {
     uint32_t begin_points = 0, begin_first = 0, begin_blocks = 0;
     uint32_t pack_split = 0, pack_split_blocks = 0;   // ray block at which the pack pass's second launch starts, and the raster it was made for
     int concurrent_streams = 0;     // LS_OPT_PIPELINE = 2 calibration result (0 = not run yet)
+
+    // LS_OPT_FRAME_GRAPH (three-stream mode): one captured graph per slot stream; fg_sink collects the launches of the
+    // frame being built (capture: launched into the capturing stream and recorded; describe: only recorded)
+    int opt_frame_graph = 0;
+    bool fg_broken = false;      // the runtime refused a capture: plain launches from then on
+    bool fg_bracket = false;     // ls_frame_graph_begin: the next frame's graph stays open for the caller's work
+    bool fg_open = false;        // a frame is being captured / described (fg_sink.mode says which)
+    uint64_t fg_tag = 0;
+    uint32_t fg_slot = 0;
+    lsi::FrameGraph fgraph[3];
+    ls::LaunchSink fg_sink;
+    uint64_t fg_captures = 0, fg_replays = 0, fg_patches = 0;
+    uint32_t fg_last_patched = 0;  // bit i: launch i of the frame replayed last went out with new arguments
+    uint32_t last_slot = 0xFFFFFFFFu;   // the frame issued last: its stream of the three-stream rotation (none: it ran on `stream`)
+    hipStream_t last_stream = nullptr;
 
     // options / measurement
     int opt_timing = 0;  // 0 off, 1 every stage, 2 only the trace kernel
@@ -270,6 +296,13 @@ int flush_pipeline(ls_tracer *tr);   // order the handle's stream after every fr
 inline int order_after_projects(ls_tracer *tr) { return flush_pipeline(tr); }
 void mark(ls_tracer *tr, int i, hipEvent_t *ride = nullptr);
 int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback);
+void frame_graph_destroy(ls_tracer *tr);   // every cached graph (nothing may be open)
+// installs the handle's launch sink for the calling thread while an entry point runs (LS_ENTER)
+struct SinkScope {
+    ls::LaunchSink *prev;
+    explicit SinkScope(ls_tracer *tr) : prev(ls::thread_sink()) { ls::thread_sink() = tr->fg_open ? &tr->fg_sink : nullptr; }
+    ~SinkScope() { ls::thread_sink() = prev; }
+};
 // ls_registry.cpp
 void affine_from_components(const float *lin, const float *ang, float *A);
 void free_geometry(Geometry &g);
@@ -295,4 +328,5 @@ void pool_run(size_t n, const std::function<void(size_t)> &fn);   // fn(0) .. fn
 #define LS_ENTER(tr)                                   \
     if (!(tr)) return LS_ERR_INVALID_ARGUMENT;         \
     std::lock_guard<std::mutex> lock_((tr)->mu);       \
+    lsi::SinkScope sink_scope_(tr);                    \
     if (hipSetDevice((tr)->device) != hipSuccess) return lsi::fail((tr), LS_ERR_HIP, "hipSetDevice failed")

@@ -16,6 +16,7 @@
 //                        (OptixTracer.cpp:895-942)
 #include "ls_kernels.h"
 #include "ls_device.h"
+#include "ls_launch.h"
 #include "ls_tuning.h"
 
 #include <algorithm>
@@ -926,7 +927,10 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         }
         if (threadIdx.x == 0) next_block_counts[block] = 0u;
         if (q == 0) big_count[0] = 0u;                                             // queue length
-        if (q < kCullCounters) big_count[kCullCountAt + q * 16u] = 0u;             // group-cull survivor counts (one per list segment)
+        // group-cull survivor counts (one per list segment): all of them, whatever the shard's size -- a shard of 256 rays
+        // or fewer is ONE workgroup, which used to re-arm the first 256 of the 512 counters only
+        if (block == 0u)
+            for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) big_count[kCullCountAt + i * 16u] = 0u;
     }
     const bool hit = gid != kInvalid;
     const unsigned long long m = __ballot(hit);
@@ -940,7 +944,9 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         const uint32_t dst = base + rank;
 
         // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
-        if (compact == 2u) {
+        if (compact == 3u) {
+            // LS_OPT_EMIT_POINTS = 0: hit records only (a sharded group rebuilds the points from the gathered records)
+        } else if (compact == 2u) {
             // ls_trace_scene_begin: 8 bytes cross PCIe, (ray, t); ls_trace_scene_expand rebuilds the point from the host's
             // copy of the factor tables with the operations below
             reinterpret_cast<uint2 *>(points)[dst] = make_uint2(v * tb.H + h, __float_as_uint(t));
@@ -1315,9 +1321,9 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
     if (!nq) return;
     const uint32_t nb = blocks_for(nq);
     auto launch = [&](uint32_t block0, uint32_t count) {
-        hipLaunchKernelGGL(k_pack<true>, dim3(count), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts, next_block_counts, big_count, gt,
-                           reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points, compact, block0, nb,
-                           progress ? *progress : ProgressArgs{nullptr, 0u, 0u});
+        launch_k(k_pack<true>, dim3(count), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts, next_block_counts, big_count, gt,
+                 reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points, compact, block0, nb,
+                 progress ? *progress : ProgressArgs{nullptr, 0u, 0u});
     };
     if (!progress || !progress->host) { launch(0u, nb); return; }
     // two launches, each followed by a word for the host: a kernel's writes to pinned host memory are complete when the
@@ -1371,8 +1377,8 @@ void launch_expand_slots(hipStream_t s, const SensorTables &tb, const uint32_t *
                          uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points)
 {
     if (!world || !cap) return;
-    hipLaunchKernelGGL(k_expand_slots, dim3(blocks_for(world * cap)), dim3(kBlock), 0, s, tb, gathered, world, cap,
-                       slot_words, reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);
+    launch_k(k_expand_slots, dim3(blocks_for(world * cap)), dim3(kBlock), 0, s, tb, gathered, world, cap,
+             slot_words, reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);
 }
 
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz)

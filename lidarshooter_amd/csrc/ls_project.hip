@@ -21,11 +21,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_ext.h>
 #include <cstdio>
 #include <vector>
 #include "ls_kernels.h"
 #include "ls_device.h"
+#include "ls_launch.h"
 #include "ls_tuning.h"
 
 namespace ls {
@@ -1199,7 +1201,9 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     float4 *__restrict__ points = reinterpret_cast<float4 *>(fa.points32);
     uint4 *__restrict__ hits = reinterpret_cast<uint4 *>(fa.hits);
     // EmbreeTracer.cpp:341-345: xyz = tfar*dir, intensity 64.0; ring = channel (LidarDeviceKernels.cu:51)
-    if (fa.compact) {
+    if (fa.compact == 3u) {
+        // LS_OPT_EMIT_POINTS = 0: hit records only
+    } else if (fa.compact) {
         points[dst] = make_float4(t * d.x, t * d.y, t * d.z, __int_as_float((int)v));
     } else {
         points[2 * (size_t)dst] = make_float4(t * d.x, t * d.y, t * d.z, 0.0f);
@@ -1253,8 +1257,8 @@ void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long
         hipLaunchKernelGGL(k_project_finish<true>, grid, dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big),
                            big_capacity, big_count, block_counts, stats);
     else
-        hipLaunchKernelGGL(k_project_finish<false>, grid, dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big),
-                           big_capacity, big_count, block_counts, stats);
+        launch_k(k_project_finish<false>, grid, dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big),
+                 big_capacity, big_count, block_counts, stats);
 }
 
 size_t project_big_item_bytes() { return sizeof(BigItem); }
@@ -1417,7 +1421,7 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         ev_start = nullptr;   // the first k_project launch of the frame starts the clock, the last one stops it
 #define LS_LAUNCH(C, L, M, K) do { \
             if (timed) hipExtLaunchKernelGGL((k_project<C, L, M, K>), grid, dim3(kBlock), (L) ? (uint32_t)lds : 0u, s, e0, ev_stop, 0u, pp, batch, best, bq, big_capacity, big_count, stats, list); \
-            else hipLaunchKernelGGL((k_project<C, L, M, K>), grid, dim3(kBlock), (L) ? lds : 0, s, pp, batch, best, bq, big_capacity, big_count, stats, list); } while (0)
+            else launch_k(k_project<C, L, M, K>, grid, dim3(kBlock), (L) ? (uint32_t)lds : 0u, s, pp, batch, best, bq, big_capacity, big_count, stats, list); } while (0)
 #define LS_LAUNCH_K(C, L, M) do { if (culled) LS_LAUNCH(C, L, M, true); else LS_LAUNCH(C, L, M, false); } while (0)
         if (lt) {
             if (stats) { if (multi) LS_LAUNCH_K(true, true, true); else LS_LAUNCH_K(true, true, false); }
@@ -1434,10 +1438,12 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
     bool culled_done = false;
     if (cull_list) {
         GeomBatch batch;
+        std::memset(static_cast<void *>(&batch), 0, sizeof(batch));
         uint32_t blocks, entries;
         if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries)) {
             const dim3 cgrid(batch.cull_first[batch.n]);
             CullBatch cb;
+            std::memset(static_cast<void *>(&cb), 0, sizeof(cb));   // (argument bytes are compared frame to frame by the frame graph)
             cb.n = batch.n;
             cb.rounds = batch.cull_rounds;
             for (uint32_t i = 0; i < batch.n; ++i) {
@@ -1455,7 +1461,7 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
             // (ev_start: the cull pass belongs to the timed stage, the clock starts with it)
 #define LS_CULL(L, C, U) do { \
                 if (ev_start) hipExtLaunchKernelGGL((k_cull<L, C, U>), cgrid, dim3(kBlock), clds, s, ev_start, nullptr, 0u, pp, cb, cull_list, counts, stats); \
-                else hipLaunchKernelGGL((k_cull<L, C, U>), cgrid, dim3(kBlock), clds, s, pp, cb, cull_list, counts, stats); } while (0)
+                else launch_k(k_cull<L, C, U>, cgrid, dim3(kBlock), clds, s, pp, cb, cull_list, counts, stats); } while (0)
             if (lut) { if (stats) LS_CULL(true, true, true); else LS_CULL(true, false, true); }
             else if (lt) { if (stats) LS_CULL(true, true, false); else LS_CULL(true, false, false); }
             else { if (stats) LS_CULL(false, true, false); else LS_CULL(false, false, false); }
@@ -1469,6 +1475,7 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
     uint32_t at = 0;
     while (at < n_srcs) {
         GeomBatch batch;
+        std::memset(static_cast<void *>(&batch), 0, sizeof(batch));   // (unused entries and padding: the frame graph compares argument bytes)
         batch.n = 0;
         uint32_t blocks = 0;
         for (; at < n_srcs && batch.n < (uint32_t)kGeomsPerLaunch; ++at) {

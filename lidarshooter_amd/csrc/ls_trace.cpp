@@ -12,6 +12,7 @@ namespace lsi {
 ls::SensorTables tables(const ls_tracer *tr)
 {
     ls::SensorTables tb;
+    std::memset(static_cast<void *>(&tb), 0, sizeof(tb));   // (padding too: the frame graph compares argument bytes)
     tb.sin_theta = tr->d_tables;
     tb.cos_theta = tr->d_tables + tr->V;
     tb.sin_phi = tr->d_tables + 2 * (size_t)tr->V;
@@ -27,6 +28,7 @@ ls::SensorTables tables(const ls_tracer *tr)
 ls::GeomTable geom_table(const ls_tracer *tr)
 {
     ls::GeomTable gt;
+    std::memset(static_cast<void *>(&gt), 0, sizeof(gt));
     gt.n = (uint32_t)tr->slot_geom_ids.size();
     gt.tri_first = tr->geom_table.p;
     gt.geom_ids = tr->geom_table.p + gt.n + 1;
@@ -37,6 +39,7 @@ ls::GeomTable geom_table(const ls_tracer *tr)
 ls::ProjectParams project_params(const ls_tracer *tr)
 {
     ls::ProjectParams pp;
+    std::memset(static_cast<void *>(&pp), 0, sizeof(pp));
     pp.tb = tables(tr);
     pp.chan_tan_up = tr->d_tables + 2 * (size_t)tr->V + 2 * (size_t)tr->H;
     pp.chan_tan_dn = pp.chan_tan_up + tr->V;
@@ -266,6 +269,7 @@ int ensure_outputs(ls_tracer *tr)
 
 int flush_pipeline(ls_tracer *tr)
 {
+    if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open (ls_frame_graph_begin without ls_frame_graph_end)");
     for (int i = 0; i < 3; ++i)
         if (tr->slot_pending[i]) {   // three-stream mode: no per-frame event; the one recorded now covers the stream's frames
             LS_HIP(hipEventRecord(tr->ev_done[i], tr->slot_stream[i]));
@@ -311,13 +315,222 @@ void mark(ls_tracer *tr, int i, hipEvent_t *ride)
     if (i == 10 || (tr->opt_timing == 2 && i == 8)) tr->trec_open = false;
 }
 
-int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
+
+}  // namespace lsi
+
+namespace ls {
+LaunchSink *&thread_sink()
+{
+    static thread_local LaunchSink *sink = nullptr;
+    return sink;
+}
+}  // namespace ls
+
+namespace lsi {
+
+// ---------------------------------------------------------------------------------------------------------------
+// LS_OPT_FRAME_GRAPH: a frame of the three-stream rotation as ONE graph launch (ls_launch.h).  Nearest reference shape:
+// the one-trace-per-frame loop of MeshProjector.cpp:446-464; the reference has no counterpart (its OptiX path pays a
+// cudaMalloc, two uploads and a device-wide wait per frame, OptixTracer.cpp:277-358).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kFrameRetry = 1000;   // trace_once -> trace_locked: the frame graph was discarded, issue the frame again
+
+void frame_graph_free(FrameGraph &fg)
+{
+    if (fg.exec) (void)hipGraphExecDestroy(fg.exec);
+    if (fg.graph) (void)hipGraphDestroy(fg.graph);
+    fg.exec = nullptr;
+    fg.graph = nullptr;
+    fg.recs.clear();
+    fg.nodes.clear();
+    fg.sig = 0;
+}
+
+// what decides the SEQUENCE of launches of a frame (their arguments may change from frame to frame: those are patched)
+uint64_t frame_signature(const ls_tracer *tr, const std::vector<ls::GeomSource> &srcs, uint32_t slot)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix(tr->fg_bracket ? tr->fg_tag | 1ull : 0ull);
+    mix(slot);
+    mix(tr->V);
+    mix(shard_rays(tr) ? 1u : 0u);
+    mix(srcs.size());
+    for (const ls::GeomSource &g : srcs) mix(((uint64_t)(g.ntris ? 1u : 0u) << 1) | (g.boxes ? 1u : 0u));
+    return h ? h : 1ull;
+}
+
+// begin building the frame of `slot` on its stream: describe against the cached graph, or capture a new one
+int frame_graph_open(ls_tracer *tr, uint32_t slot, hipStream_t s, uint64_t sig)
+{
+    FrameGraph &fg = tr->fgraph[slot];
+    if (fg.exec && fg.sig != sig) frame_graph_free(fg);
+    ls::LaunchSink &sk = tr->fg_sink;
+    sk.n = 0;
+    sk.stream = s;
+    tr->fg_slot = slot;
+    if (fg.exec) {
+        sk.mode = ls::LaunchSink::kDescribe;
+    } else {
+        LS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        sk.mode = ls::LaunchSink::kCapture;
+        fg.sig = sig;
+    }
+    tr->fg_open = true;
+    ls::thread_sink() = &sk;
+    return LS_OK;
+}
+
+// the kernel nodes of `graph` in an order that respects its edges (our launches sit on one stream: each depends on the
+// one before, so any topological order lists them as they were issued, whatever a captured library call added around them)
+int kernel_nodes_in_order(ls_tracer *tr, hipGraph_t graph, std::vector<hipGraphNode_t> &out)
+{
+    size_t n = 0, ne = 0;
+    LS_HIP(hipGraphGetNodes(graph, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) LS_HIP(hipGraphGetNodes(graph, nodes.data(), &n));
+    LS_HIP(hipGraphGetEdges(graph, nullptr, nullptr, &ne));
+    std::vector<hipGraphNode_t> from(ne), to(ne);
+    if (ne) LS_HIP(hipGraphGetEdges(graph, from.data(), to.data(), &ne));
+    std::vector<uint32_t> indeg(n, 0);
+    auto index_of = [&](hipGraphNode_t x) { for (size_t i = 0; i < n; ++i) if (nodes[i] == x) return i; return n; };
+    std::vector<size_t> fi(ne), ti(ne);
+    for (size_t e = 0; e < ne; ++e) {
+        fi[e] = index_of(from[e]);
+        ti[e] = index_of(to[e]);
+        if (fi[e] == n || ti[e] == n) return fail(tr, LS_ERR_HIP, "frame graph: an edge names an unknown node");
+        ++indeg[ti[e]];
+    }
+    std::vector<size_t> ready, order;
+    for (size_t i = 0; i < n; ++i) if (!indeg[i]) ready.push_back(i);
+    while (!ready.empty()) {
+        const size_t i = ready.back();
+        ready.pop_back();
+        order.push_back(i);
+        for (size_t e = 0; e < ne; ++e) if (fi[e] == i && --indeg[ti[e]] == 0) ready.push_back(ti[e]);
+    }
+    if (order.size() != n) return fail(tr, LS_ERR_HIP, "frame graph: the captured graph has a cycle");
+    out.clear();
+    for (size_t i : order) {
+        hipGraphNodeType ty;
+        LS_HIP(hipGraphNodeGetType(nodes[i], &ty));
+        if (ty == hipGraphNodeTypeKernel) out.push_back(nodes[i]);
+    }
+    return LS_OK;
+}
+
+bool same_launch(const ls::LaunchRecord &a, const ls::LaunchRecord &b)
+{
+    return a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.grid.z == b.grid.z && a.block.x == b.block.x && a.block.y == b.block.y &&
+           a.block.z == b.block.z && a.shmem == b.shmem && a.n_args == b.n_args && a.blob.size() == b.blob.size() &&
+           std::memcmp(a.arg_off, b.arg_off, sizeof(uint32_t) * (a.n_args + 1)) == 0 &&
+           (a.blob.empty() || std::memcmp(a.blob.data(), b.blob.data(), a.blob.size()) == 0);
+}
+
+// the frame graph is given up for this frame (and, when `broken`, for good): nothing was launched, the rotation steps back
+int frame_graph_discard(ls_tracer *tr, FrameGraph &fg, bool broken)
+{
+    frame_graph_free(fg);
+    if (broken) tr->fg_broken = true;
+    if (tr->ms_seq) --tr->ms_seq;   // (trace_once counted the frame when its launches were recorded)
+    return kFrameRetry;
+}
+
+// close the frame being built and launch it: LS_OK, kFrameRetry (nothing launched, issue it again) or an error
+int frame_graph_close(ls_tracer *tr)
+{
+    FrameGraph &fg = tr->fgraph[tr->fg_slot];
+    ls::LaunchSink &sk = tr->fg_sink;
+    hipStream_t s = sk.stream;
+    const int mode = sk.mode;
+    sk.mode = ls::LaunchSink::kOff;
+    tr->fg_open = false;
+    ls::thread_sink() = nullptr;
+    if (mode == ls::LaunchSink::kCapture) {
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (e != hipSuccess || !graph) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            tr->err = std::string("frame graph: the capture failed (") + hipGetErrorString(e) + "); plain launches from now on";
+            return frame_graph_discard(tr, fg, true);
+        }
+        fg.graph = graph;
+        if (hipGraphInstantiate(&fg.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            fg.exec = nullptr;
+            tr->err = "frame graph: hipGraphInstantiate failed; plain launches from now on";
+            return frame_graph_discard(tr, fg, true);
+        }
+        std::vector<hipGraphNode_t> kn;
+        if (kernel_nodes_in_order(tr, graph, kn) != LS_OK) return frame_graph_discard(tr, fg, true);
+        fg.nodes.clear();
+        size_t at = 0;
+        for (size_t i = 0; i < sk.n; ++i) {
+            hipGraphNode_t found = nullptr;
+            for (; at < kn.size() && !found; ++at) {
+                hipKernelNodeParams p;
+                if (hipGraphKernelNodeGetParams(kn[at], &p) == hipSuccess && p.func == sk.recs[i].func) found = kn[at];
+            }
+            if (!found) {
+                tr->err = "frame graph: a launch has no kernel node in the captured graph; plain launches from now on";
+                return frame_graph_discard(tr, fg, true);
+            }
+            fg.nodes.push_back(found);
+        }
+        fg.recs.assign(sk.recs.begin(), sk.recs.begin() + (ptrdiff_t)sk.n);
+        ++tr->fg_captures;
+    } else {
+        bool same_sequence = sk.n == fg.recs.size();
+        for (size_t i = 0; same_sequence && i < sk.n; ++i) same_sequence = sk.recs[i].func == fg.recs[i].func;
+        if (!same_sequence) return frame_graph_discard(tr, fg, false);   // (the signature missed something: capture anew)
+        tr->fg_last_patched = 0;
+        for (size_t i = 0; i < sk.n; ++i) {
+            ls::LaunchRecord &now = sk.recs[i];
+            if (same_launch(now, fg.recs[i])) continue;
+            tr->fg_last_patched |= 1u << (i < 31 ? i : 31);
+            void *argv[16];
+            for (uint32_t a = 0; a < now.n_args; ++a) argv[a] = now.blob.data() + now.arg_off[a];
+            hipKernelNodeParams p;
+            std::memset(&p, 0, sizeof(p));
+            p.func = const_cast<void *>(now.func);
+            p.gridDim = now.grid;
+            p.blockDim = now.block;
+            p.sharedMemBytes = now.shmem;
+            p.kernelParams = argv;
+            p.extra = nullptr;
+            if (hipGraphExecKernelNodeSetParams(fg.exec, fg.nodes[i], &p) != hipSuccess) {
+                (void)hipGetLastError();
+                return frame_graph_discard(tr, fg, false);
+            }
+            std::swap(fg.recs[i], now);   // (the sink's record is rewritten by the next frame anyway)
+            ++tr->fg_patches;
+        }
+    }
+    LS_HIP(hipGraphLaunch(fg.exec, s));
+    ++tr->fg_replays;
+    return LS_OK;
+}
+
+}  // namespace
+
+void frame_graph_destroy(ls_tracer *tr)
+{
+    for (FrameGraph &fg : tr->fgraph) frame_graph_free(fg);
+}
+
+namespace {
+int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
 {
     if (!out) return fail(tr, LS_ERR_INVALID_ARGUMENT, "null frame");
     std::memset(out, 0, sizeof(*out));
     out->frame = frame;
     out->n_rays = shard_rays(tr);
     tr->traced = false;
+    tr->last_slot = 0xFFFFFFFFu;
+    tr->last_stream = tr->stream;
     if (!tr->committed || tr->n_tris == 0) return -1;  // OptixTracer.cpp:280-288: cleared cloud, -1
     int rc;
     if ((rc = ensure_outputs(tr))) return rc;
@@ -333,7 +546,9 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     // synchronous call with the library's own outputs: the pack kernel writes the pinned host buffers itself
     const bool hv = readback && tr->opt_host_output && !tr->ext_points;
     if (hv && (rc = ensure_host_buffers(tr, shard_rays(tr)))) return rc;
-    const uint32_t compact = hv && tr->opt_host_output == 2 ? 1u : 0u;
+    // (3: no point records at all -- LS_OPT_EMIT_POINTS = 0, asynchronous frames only)
+    if (readback && !tr->opt_emit_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_EMIT_POINTS = 0: the synchronous call delivers points; switch it on first");
+    const uint32_t compact = hv && tr->opt_host_output == 2 ? 1u : (!tr->opt_emit_points ? 3u : 0u);
     auto host_targets = [&]() {
         if (!hv) return;
         d_points = tr->h_points;
@@ -396,6 +611,8 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             const bool dep = tr->slot_epoch[slot] != tr->main_epoch || tr->stream != tr->own_stream;
             if (dep) LS_HIP(hipEventRecord(tr->ev_main, s));
             s = tr->slot_stream[slot];
+            tr->last_slot = slot;
+            tr->last_stream = s;
             if (dep) LS_HIP(hipStreamWaitEvent(s, tr->ev_main, 0));
             tr->slot_epoch[slot] = tr->main_epoch;
         }
@@ -421,6 +638,7 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             if (it == tr->geoms.end()) return fail(tr, LS_ERR_NOT_COMMITTED, "geometry removed since the last commit");
             const Geometry &ge = it->second;
             ls::GeomSource src;
+            std::memset(static_cast<void *>(&src), 0, sizeof(src));   // (padding too: the frame graph compares argument bytes)
             src.verts = static_cast<const uint8_t *>(ge.raw());
             src.stride = ge.stride;
             src.idx = ge.idx();
@@ -490,6 +708,9 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             ++tr->pipe_seq;
             if (readback && (rc = flush_pipeline(tr))) return rc;
         } else {
+            // LS_OPT_FRAME_GRAPH (three-stream mode): the launches below are captured into this slot's graph, or only
+            // described and compared with it; either way the frame then goes out as one graph launch
+            if (multi && tr->opt_frame_graph && !tr->fg_broken && (rc = frame_graph_open(tr, slot, s, frame_signature(tr, srcs, slot)))) return rc;
             // one launch per 16 geometries (the descriptors travel as kernel arguments)
             if (ride) mark(tr, 8, &ev_k1);
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list,
@@ -505,6 +726,8 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                 // no event per frame: a flush (or a mesh copy) records one per stream and orders the handle's stream after it
                 tr->slot_pending[slot] = true;
                 ++tr->ms_seq;
+                // (a caller's bracket keeps the graph open for its own work: ls_frame_graph_end closes it)
+                if (tr->fg_open && (!tr->fg_bracket || readback) && (rc = frame_graph_close(tr))) return rc;
                 s = tr->stream;
                 if (readback && (rc = flush_pipeline(tr))) return rc;
             } else {
@@ -607,6 +830,28 @@ int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     out->points32 = tr->h_points;
     out->hits = tr->opt_readback_hits ? tr->h_hits : nullptr;
     return LS_OK;
+}
+}  // namespace
+
+int trace_locked(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
+{
+    int rc = trace_once(tr, frame, out, readback);
+    // a frame graph that had to be given up launched nothing: the frame is issued again (captured anew, or as plain launches)
+    if (rc == kFrameRetry) rc = trace_once(tr, frame, out, readback);
+    if (rc == kFrameRetry) rc = fail(tr, LS_ERR_HIP, "frame graph: discarded twice in a row");
+    if (rc < LS_OK && rc != -1 && tr->fg_open) {   // an error with a capture open: end it, launch nothing
+        ls::LaunchSink &sk = tr->fg_sink;
+        if (sk.mode == ls::LaunchSink::kCapture) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(sk.stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+        }
+        sk.mode = ls::LaunchSink::kOff;
+        tr->fg_open = false;
+        ls::thread_sink() = nullptr;
+    }
+    return rc;
 }
 
 }  // namespace lsi
@@ -712,6 +957,52 @@ int ls_trace_scene_expand(ls_tracer *tr, void *dst_points32)
         return fail(tr, LS_ERR_HIP, "the frame's progress words never reached the host");
     }
     return check_device_status(tr);
+}
+
+int ls_frame_graph_begin(ls_tracer *tr, uint64_t tag)
+{
+    LS_ENTER(tr);
+    if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open already");
+    tr->fg_bracket = true;
+    tr->fg_tag = tag << 1;
+    return LS_OK;
+}
+
+int ls_frame_graph_stream(ls_tracer *tr, void **hip_stream, uint32_t *slot, int *mode)
+{
+    LS_ENTER(tr);
+    // the frame issued last; when nothing was traced (an empty scene) the stream and slot the NEXT frame of the rotation takes
+    hipStream_t s = tr->last_stream ? tr->last_stream : tr->stream;
+    uint32_t sl = tr->last_slot;
+    if (!tr->traced && tr->opt_pipeline == 2 && use_projection(tr) && tr->slot_stream[0] && !tr->opt_count && !tr->opt_timing) {
+        sl = tr->ms_seq % 3u;
+        s = tr->slot_stream[sl];
+    }
+    if (hip_stream) *hip_stream = s;
+    if (slot) *slot = sl;
+    if (mode) *mode = !tr->fg_open ? LS_FRAME_EAGER : (tr->fg_sink.mode == ls::LaunchSink::kCapture ? LS_FRAME_CAPTURING : LS_FRAME_REPLAYING);
+    return LS_OK;
+}
+
+int ls_frame_graph_end(ls_tracer *tr)
+{
+    LS_ENTER(tr);
+    tr->fg_bracket = false;
+    if (!tr->fg_open) return LS_OK;   // the frame went out as plain launches (or nothing was traced)
+    const int rc = frame_graph_close(tr);
+    return rc == kFrameRetry ? 1 : rc;
+}
+
+int ls_frame_graph_reset(ls_tracer *tr)
+{
+    LS_ENTER(tr);
+    if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open");
+    // (a graph that is still executing keeps what it needs until it has finished: the runtime defers the release)
+    const int rc = flush_pipeline(tr);
+    if (rc) return rc;
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    frame_graph_destroy(tr);
+    return LS_OK;
 }
 
 int ls_tracer_synchronize(ls_tracer *tr)

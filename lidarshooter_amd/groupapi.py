@@ -15,7 +15,10 @@ SHARDED, INTERLEAVED = 0, 1
 ID_BYTES, SLOT_HEADER = 128, 64
 SYMBOLS = ("ls_group_shard_columns", "ls_group_slot_capacity", "ls_group_slot_bytes", "ls_group_write_slot",
            "ls_group_decode_gathered", "ls_group_unique_id", "ls_group_create", "ls_group_destroy", "ls_group_trace",
-           "ls_group_owns_frame", "ls_group_cloud", "ls_group_download_cloud", "ls_group_synchronize", "ls_group_last_error")
+           "ls_group_owns_frame", "ls_group_cloud", "ls_group_download_cloud", "ls_group_synchronize", "ls_group_last_error",
+           "ls_group_create_opts", "ls_group_info")
+FLAG_ONE_COMMUNICATOR, FLAG_NO_GRAPH = 1, 2
+INFO_RCCL_VERSION, INFO_COMM_RANKS, INFO_COMM_DEVICE, INFO_COMMUNICATORS, INFO_PER_SET, INFO_FRAME_GRAPH = 1, 2, 3, 4, 5, 6
 _lib = None
 
 
@@ -40,6 +43,9 @@ def load() -> C.CDLL:
     L.ls_group_decode_gathered.restype = u32
     L.ls_group_unique_id.argtypes = [vp]
     L.ls_group_create.argtypes = [vp, u32, u32, C.c_int, vp, C.POINTER(vp)]
+    L.ls_group_create_opts.argtypes = [vp, u32, u32, C.c_int, u32, vp, C.POINTER(vp)]
+    L.ls_group_info.argtypes = [vp, C.c_int]
+    L.ls_group_info.restype = C.c_long
     L.ls_group_destroy.argtypes = [vp]
     L.ls_group_destroy.restype = None
     L.ls_group_trace.argtypes = [vp, u32]
@@ -80,7 +86,7 @@ def decode_gathered(gathered: np.ndarray, world: int, cap: int) -> np.ndarray:
 
 
 class Group:
-    def __init__(self, tracer: "capi.Tracer", world: int, rank: int, mode: int, uid: bytes | None = None):
+    def __init__(self, tracer: "capi.Tracer", world: int, rank: int, mode: int, uid: bytes | None = None, flags: int = 0):
         self.L = load()
         if uid is None and mode == SHARDED:
             buf = (C.c_uint8 * ID_BYTES)()
@@ -90,9 +96,9 @@ class Group:
         self.uid = uid
         g = C.c_void_p()
         idbuf = (C.c_uint8 * ID_BYTES).from_buffer_copy(uid) if uid else None
-        rc = self.L.ls_group_create(idbuf, world, rank, mode, tracer.h, C.byref(g))
+        rc = self.L.ls_group_create_opts(idbuf, world, rank, mode, flags, tracer.h, C.byref(g))
         if rc != 0:
-            raise capi.LidarShooterHipError(f"ls_group_create: status {rc}")
+            raise capi.LidarShooterHipError(f"ls_group_create_opts: status {rc}")
         self.g, self.tracer = g, tracer
 
     def trace(self, frame: int) -> int:
@@ -100,6 +106,15 @@ class Group:
         if rc < -1:
             raise capi.LidarShooterHipError(self.L.ls_group_last_error(self.g).decode())
         return rc
+
+    def info(self, what: int) -> int:
+        return int(self.L.ls_group_info(self.g, what))
+
+    def rccl(self) -> dict:
+        """what RCCL itself says about this rank's communicator (bench.py's "rccl" object)"""
+        return {"version": self.info(INFO_RCCL_VERSION), "comm_ranks": self.info(INFO_COMM_RANKS), "device": self.info(INFO_COMM_DEVICE),
+                "communicators": self.info(INFO_COMMUNICATORS), "per_set_streams": bool(self.info(INFO_PER_SET)),
+                "frame_graph_state": self.info(INFO_FRAME_GRAPH)}
 
     def owns(self, frame: int) -> bool:
         return bool(self.L.ls_group_owns_frame(self.g, frame))

@@ -6,7 +6,8 @@
 // on the XT-32 scene and checks the reference's known answer (1781 points).
 //
 //   lsbench --config sensor.json [--mesh name=file.stl]... [--syn V H]  [--grid NX NY]
-//           [--frames K] [--warmup W] [--pipeline 0|1|2] [--engine 0|1|2] [--ranks N [--group sharded|interleaved]]
+//           [--frames K] [--warmup W] [--pipeline 0|1|2] [--graph 0|1] [--engine 0|1|2]
+//           [--ranks N [--group sharded|interleaved] [--group-flags F]]
 //   --ranks N    : one process per GPU (forked before anything touches a GPU), frames through include/lidarshooter_group.h:
 //                  azimuth shards + one ncclAllGather of hit-record slots per frame, or whole frames interleaved over the ranks
 //   --syn V H    : replace the sensor's raster by V channels (+15 .. -25 deg) x H azimuths (0 .. 360 deg)
@@ -58,7 +59,7 @@ int upload(DeviceMesh& m, const void* verts, size_t vbytes, const uint32_t* tris
 namespace {
 std::string config, group_mode = "sharded";
 std::vector<std::pair<std::string, std::string>> mesh_files, raw_files;
-int synV = 0, synH = 0, gridX = 0, gridY = 0, frames = 200, warmup = 50, pipeline = 0, engine = 0, ranks = 0;
+int synV = 0, synH = 0, gridX = 0, gridY = 0, frames = 200, warmup = 50, pipeline = 0, engine = 0, ranks = 0, group_flags = 0, frame_graph = 0;
 int run(int rank, int world, const std::string& id_path, int result_fd);
 }  // namespace
 
@@ -78,6 +79,8 @@ int main(int argc, char** argv)
         else if (a == "--engine") { need(1); engine = std::atoi(argv[++i]); }
         else if (a == "--ranks") { need(1); ranks = std::atoi(argv[++i]); }
         else if (a == "--group") { need(1); group_mode = argv[++i]; }
+        else if (a == "--group-flags") { need(1); group_flags = std::atoi(argv[++i]); }   // LS_GROUP_FLAG_*: 1 one communicator (round 3's path), 2 no graph
+        else if (a == "--graph") { need(1); frame_graph = std::atoi(argv[++i]); }         // single process: LS_OPT_FRAME_GRAPH
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (config.empty()) { std::fprintf(stderr, "--config is required\n"); return 2; }
@@ -107,6 +110,7 @@ int main(int argc, char** argv)
         fds[r] = pfd[0];
     }
     double worst = 0.0, enq = 0.0;
+    long ginfo[6] = {0, 0, 0, 0, 0, 0};   // rank 0: RCCL version, ncclCommCount, communicators, per-set mode, frame-graph state, graphs captured
     unsigned rays = 0, points = 0;
     unsigned long long tris = 0;
     char sha[80] = "";
@@ -123,7 +127,10 @@ int main(int argc, char** argv)
         unsigned ry = 0, pt = 0, owns_last = 0;
         unsigned long long tt = 0;
         char h[80] = "";
-        if (std::sscanf(text.c_str(), "%lf %lf %u %llu %u %u %79s", &el, &eq, &ry, &tt, &pt, &owns_last, h) < 6) { rc = 2; continue; }
+        long gi[6] = {0, 0, 0, 0, 0, 0};
+        if (std::sscanf(text.c_str(), "%lf %lf %u %llu %u %u %79s %ld %ld %ld %ld %ld %ld", &el, &eq, &ry, &tt, &pt, &owns_last, h, &gi[0], &gi[1],
+                        &gi[2], &gi[3], &gi[4], &gi[5]) < 6) { rc = 2; continue; }
+        if (r == 0) std::memcpy(ginfo, gi, sizeof(gi));
         worst = std::max(worst, el);
         enq = std::max(enq, eq);
         rays = ry;
@@ -135,9 +142,11 @@ int main(int argc, char** argv)
     const unsigned whole = group_mode == "sharded" ? rays : rays;   // rays of the whole frame either way (reported by the ranks)
     std::printf("{\"harness\": \"lsbench\", \"ranks\": %d, \"group\": \"%s\", \"rays_per_frame\": %u, \"triangles\": %llu, \"frames\": %d, "
                 "\"us_per_frame\": %.3f, \"frames_per_s\": %.1f, \"mrays_per_s\": %.1f, \"host_enqueue_us_per_frame\": %.3f, "
-                "\"points_last_frame\": %u, \"points_sha256\": \"%s\"}\n",
+                "\"points_last_frame\": %u, \"points_sha256\": \"%s\", \"group_flags\": %d, \"rccl\": {\"version\": %ld, \"comm_ranks\": %ld, "
+                "\"communicators\": %ld}, \"per_set_streams\": %ld, \"frame_graph_state\": %ld, \"frame_graphs_captured\": %ld}\n",
                 ranks, group_mode.c_str(), whole, tris, frames, worst / frames * 1e6, frames / worst,
-                static_cast<double>(whole) * frames / worst / 1e6, enq / frames * 1e6, points, sha);
+                static_cast<double>(whole) * frames / worst / 1e6, enq / frames * 1e6, points, sha, group_flags, ginfo[0], ginfo[1], ginfo[2],
+                ginfo[3], ginfo[4], ginfo[5]);
     return 0;
 }
 
@@ -276,7 +285,8 @@ int run(int rank, int world, const std::string& id_path, int result_fd)
             }
         }
         ls_group* g = nullptr;
-        if (ls_group_create(id, static_cast<uint32_t>(world), static_cast<uint32_t>(rank), sharded ? LS_GROUP_SHARDED : LS_GROUP_INTERLEAVED, tr, &g) != LS_OK) {
+        if (ls_group_create_opts(id, static_cast<uint32_t>(world), static_cast<uint32_t>(rank), sharded ? LS_GROUP_SHARDED : LS_GROUP_INTERLEAVED,
+                                 static_cast<uint32_t>(group_flags), tr, &g) != LS_OK) {
             std::fprintf(stderr, "rank %d: ls_group_create failed\n", rank);
             return 2;
         }
@@ -305,9 +315,12 @@ int run(int rank, int world, const std::string& id_path, int result_fd)
             if (n < 0) { std::fprintf(stderr, "download: %s\n", ls_group_last_error(g)); return 2; }
             sha = lidarshooter::sha256Hex(pts.data(), static_cast<size_t>(n) * 32);
         }
-        char line[256];
-        const int len = std::snprintf(line, sizeof(line), "%.9f %.9f %u %llu %ld %d %s\n", elapsed, enqueue_s, whole_rays,
-                                      static_cast<unsigned long long>(total_tris), n, owns_last ? 1 : 0, sha.c_str());
+        char line[384];
+        const int len = std::snprintf(line, sizeof(line), "%.9f %.9f %u %llu %ld %d %s %ld %ld %ld %ld %ld %ld\n", elapsed, enqueue_s, whole_rays,
+                                      static_cast<unsigned long long>(total_tris), n, owns_last ? 1 : 0, sha.c_str(),
+                                      ls_group_info(g, LS_GROUP_INFO_RCCL_VERSION), ls_group_info(g, LS_GROUP_INFO_COMM_RANKS),
+                                      ls_group_info(g, LS_GROUP_INFO_COMMUNICATORS), ls_group_info(g, LS_GROUP_INFO_PER_SET),
+                                      ls_group_info(g, LS_GROUP_INFO_FRAME_GRAPH), ls_get_info(tr, LS_INFO_FRAME_GRAPH_CAPTURES));
         if (result_fd >= 0 && write(result_fd, line, static_cast<size_t>(len)) != len) return 2;
         ls_group_destroy(g);
         ls_tracer_destroy(tr);
@@ -323,6 +336,7 @@ int run(int rank, int world, const std::string& id_path, int result_fd)
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&o.n), 4));
     }
     ls_tracer_set_option(tr, LS_OPT_PIPELINE, pipeline);
+    ls_tracer_set_option(tr, LS_OPT_FRAME_GRAPH, frame_graph);
     // the meshes are handed over once (in place, in HBM); after that every frame restates every mesh's pose
     // (MeshProjector.cpp:448-461 calls updateGeometry for every mesh, every frame): the unchanged-mesh update
     for (const auto& m : meshes)
@@ -357,10 +371,11 @@ int run(int rank, int world, const std::string& id_path, int result_fd)
         HIP_OK(hipMemcpy(h_points.data(), last.points, h_points.size(), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(h_hits.data(), last.hits, h_hits.size(), hipMemcpyDeviceToHost));
     }
-    std::printf("{\"harness\": \"lsbench\", \"rays_per_frame\": %u, \"triangles\": %llu, \"frames\": %d, \"pipeline\": %d, "
+    std::printf("{\"harness\": \"lsbench\", \"rays_per_frame\": %u, \"triangles\": %llu, \"frames\": %d, \"pipeline\": %d, \"frame_graph\": %d, \"frame_graph_replays\": %ld, \"frame_graph_patches\": %ld, "
                 "\"us_per_frame\": %.3f, \"frames_per_s\": %.1f, \"mrays_per_s\": %.1f, \"host_enqueue_us_per_frame\": %.3f, "
                 "\"points_last_frame\": %u, \"points_sha256\": \"%s\", \"hits_sha256\": \"%s\"}\n",
-                rays, static_cast<unsigned long long>(total_tris), frames, pipeline, elapsed / frames * 1e6, frames / elapsed,
+                rays, static_cast<unsigned long long>(total_tris), frames, pipeline, frame_graph, ls_get_info(tr, LS_INFO_FRAME_GRAPH_REPLAYS),
+                ls_get_info(tr, LS_INFO_FRAME_GRAPH_PATCHES), elapsed / frames * 1e6, frames / elapsed,
                 static_cast<double>(rays) * frames / elapsed / 1e6, enqueue_s / frames * 1e6, n_points,
                 lidarshooter::sha256Hex(h_points.data(), h_points.size()).c_str(), lidarshooter::sha256Hex(h_hits.data(), h_hits.size()).c_str());
     ls_tracer_destroy(tr);

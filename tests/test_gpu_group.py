@@ -15,9 +15,11 @@ from conftest import DATA, ROOT, make_tracer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode_name", ["sharded", "interleaved"])
+@pytest.mark.parametrize("mode_name,flags", [("sharded", 0), ("sharded", 1), ("sharded", 2), ("interleaved", 0), ("interleaved", 2)])
 @pytest.mark.parametrize("pipeline", [0, 1, 2])
-def test_group_one_rank(oracle, capi, sensors, meshes, mode_name, pipeline):
+def test_group_one_rank(oracle, capi, sensors, meshes, mode_name, flags, pipeline):
+    """flags: 0 = per-set mode (a communicator and a stream per buffer set, every frame one captured graph: three launches
+    + ncclAllGather + rebuild), 1 = LS_GROUP_FLAG_ONE_COMMUNICATOR (round 3's arrangement), 2 = LS_GROUP_FLAG_NO_GRAPH."""
     from lidarshooter_amd import groupapi
     s = sensors["0001"]
     tr = make_tracer(capi, s, "projection")
@@ -26,7 +28,13 @@ def test_group_one_rank(oracle, capi, sensors, meshes, mode_name, pipeline):
     tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
     tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
     tr.setOption(capi.LS_OPT_PIPELINE, pipeline)
-    g = groupapi.Group(tr, 1, 0, groupapi.SHARDED if mode_name == "sharded" else groupapi.INTERLEAVED)
+    g = groupapi.Group(tr, 1, 0, groupapi.SHARDED if mode_name == "sharded" else groupapi.INTERLEAVED, flags=flags)
+    three = tr.info(capi.LS_INFO_PIPELINE_MODE) == 2
+    if mode_name == "sharded":
+        info = g.rccl()
+        assert info["comm_ranks"] == 1 and info["version"] > 20000 and info["device"] == 0
+        assert info["per_set_streams"] == (three and flags != 1) and info["communicators"] == (3 if info["per_set_streams"] else 1)
+    assert tr.info(capi.LS_INFO_FRAME_GRAPH_STATE) == (1 if three and flags == 0 else 0)
     poses = [oracle.affine_from_components(np.array((0.4 * k, -0.3 * k, 0.02 * k), np.float32), np.array((0.0, 0.0, 0.15 * k), np.float32))
              for k in range(7)]
     refs = [oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)]) for A in poses]
@@ -40,26 +48,33 @@ def test_group_one_rank(oracle, capi, sensors, meshes, mode_name, pipeline):
                 pts, hits = g.download(k)
                 assert np.array_equal(pts, refs[k]["points"]) and np.array_equal(hits, refs[k]["hits"])
     assert tr.info(capi.LS_INFO_PIPELINE_MODE) == 2    # the group keeps three frames in flight per rank
+    if three and flags == 0:   # every frame went out as one graph launch: three captures, the moving mesh's pose patched in
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_STATE) == 1 and tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES) == 3
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS) == len(poses)
     g.close()
+    assert tr.info(capi.LS_INFO_FRAME_GRAPH_STATE) == 0
     assert tr.info(capi.LS_INFO_PIPELINE_MODE) == pipeline
     rc, pts, hits = tr.traceScene(99)              # the tracer is the caller's again
     assert rc == 0 and np.array_equal(pts, refs[-1]["points"])
     tr.close()
 
 
-@pytest.mark.parametrize("group", ["sharded", "interleaved"])
-def test_lsbench_ranks_one(oracle, sensors, meshes, group):
+@pytest.mark.parametrize("group,flags", [("sharded", 0), ("sharded", 1), ("interleaved", 0)])
+def test_lsbench_ranks_one(oracle, sensors, meshes, group, flags):
     """lsbench --ranks 1: the C++ harness through lidarshooter_group.h (fork per rank, id through a file, RCCL)."""
     import hashlib
     exe = os.path.join(ROOT, "lidarshooter_amd", "lsbench")
     out = subprocess.run([exe, "--config", os.path.join(DATA, "config", "hesai-pandar-XT-32-lidar_0000.json"),
                           "--mesh", "ground=" + os.path.join(DATA, "mesh", "ground.stl"),
                           "--mesh", "face=" + os.path.join(DATA, "mesh", "ben.stl"),
-                          "--frames", "120", "--warmup", "10", "--ranks", "1", "--group", group],
+                          "--frames", "120", "--warmup", "10", "--ranks", "1", "--group", group, "--group-flags", str(flags)],
                          capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stderr
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["ranks"] == 1 and rec["group"] == group and rec["points_last_frame"] == 1781
+    if group == "sharded":
+        assert rec["rccl"]["comm_ranks"] == 1 and rec["rccl"]["communicators"] == (3 if flags == 0 else 1)
+        assert rec["frame_graph_state"] == (1 if flags == 0 else 0) and rec["frame_graphs_captured"] == (3 if flags == 0 else 0)
     ref = oracle.trace_frame(sensors["0000"], [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
     assert rec["points_sha256"] == hashlib.sha256(ref["points"].tobytes()).hexdigest()
 

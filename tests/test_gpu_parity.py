@@ -849,7 +849,7 @@ def test_cloud_to_world_two_sensors_merged(oracle, capi, sensors, meshes):
         tr.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 12])
 def test_pipelined_frames(oracle, capi, sensors, meshes, mode):
     """LS_OPT_PIPELINE = 1 (two frames in flight: the finish + pack workgroups of frame i ride in the launch
     of frame i+1) and = 2 (three frames in flight on three streams).  An animated scene (the moving mesh is
@@ -861,7 +861,10 @@ def test_pipelined_frames(oracle, capi, sensors, meshes, mode):
     s = sensors["0001"]
     poses = oracle.play_trajectory(os.path.join(DATA, "config", "trajectory.json"), 0.1)
     tr = make_tracer(capi, s, "projection")
+    graph = mode == 12                                          # three streams, every frame one graph launch (LS_OPT_FRAME_GRAPH)
+    mode = 2 if graph else mode
     tr.setOption(capi.LS_OPT_PIPELINE, mode)
+    tr.setOption(capi.LS_OPT_FRAME_GRAPH, 1 if graph else 0)
     _add(tr, "ground", meshes["ground"])
     _add(tr, "face", meshes["ben"])
     cap = s.V * s.H
@@ -903,6 +906,11 @@ def test_pipelined_frames(oracle, capi, sensors, meshes, mode):
     for i in frames[-mode:]:
         check(i)
     assert len({e["points"].shape[0] for e in expected}) > 3
+    if graph:   # three graphs captured (one per stream of the rotation), every other frame a replay with the pose patched in
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_STATE) == 1
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES) == 3
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS) == len(frames)
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_PATCHES) >= len(frames) - 3
     # synchronous API on the pipelined handle, library-owned (twin) buffers, twice: both twins
     tr.setOutputBuffers(None, None, None, 0)
     ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)]
@@ -921,7 +929,7 @@ def test_pipelined_frames(oracle, capi, sensors, meshes, mode):
     tr.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 12])
 def test_pipeline_stress(oracle, capi, sensors, meshes, mode):
     """900 frames streamed without a host wait in either pipelined mode, the moving mesh cycling through
     four poses (in-place device meshes, transform only), outputs rotating over three caller-owned sets;
@@ -929,7 +937,10 @@ def test_pipeline_stress(oracle, capi, sensors, meshes, mode):
     import torch
     s = sensors["0000"]
     tr = make_tracer(capi, s, "projection")
+    graph = mode == 12                                          # (12: three streams + LS_OPT_FRAME_GRAPH)
+    mode = 2 if graph else mode
     tr.setOption(capi.LS_OPT_PIPELINE, mode)
+    tr.setOption(capi.LS_OPT_FRAME_GRAPH, 1 if graph else 0)
     dev = torch.device("cuda", 0)
     d = {}
     for name, key in (("ground", "ground"), ("face", "ben")):
@@ -961,6 +972,92 @@ def test_pipeline_stress(oracle, capi, sensors, meshes, mode):
                 assert cnt == ref["points"].shape[0], (k, cnt)
                 assert np.array_equal(p.cpu().numpy()[:32 * cnt].reshape(cnt, 32), ref["points"])
                 assert np.array_equal(h.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4), ref["hits"])
+    if graph:
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES) == 3 and tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS) == 900
+    tr.close()
+
+
+def test_frame_graph_follows_the_scene(oracle, capi, sensors, meshes):
+    """LS_OPT_FRAME_GRAPH: what a cached frame graph must survive.  Same poses again: replays with NOTHING patched;
+    a new pose: one node patched (k_project's arguments); another geometry set (a mesh added, later removed): the launch
+    sequence may change, the graphs are captured anew; the option switched off and on again: plain launches in between.
+    Every frame equals the oracle's."""
+    import torch
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_PIPELINE, 2)
+    if tr.info(capi.LS_INFO_PIPELINE_MODE) != 2:
+        pytest.skip("fewer than three concurrent streams on this device")
+    tr.setOption(capi.LS_OPT_FRAME_GRAPH, 1)
+    _add(tr, "ground", meshes["ground"])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    cap = s.V * s.H
+    bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0"), torch.zeros(16 * cap, dtype=torch.uint8, device="cuda:0"),
+             torch.zeros(4, dtype=torch.int32, device="cuda:0")) for _ in range(3)]
+    issued = []
+
+    def frame(ml):
+        i = len(issued)
+        p, h, n = bufs[i % 3]
+        assert tr.commitScene() == 0
+        tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
+        tr.traceSceneAsync(i)
+        issued.append(ml)
+
+    def check_last_three():
+        tr.synchronize()
+        for k in range(len(issued) - 3, len(issued)):
+            p, h, n = bufs[k % 3]
+            ref = oracle.trace_frame(s, issued[k])
+            cnt = int(n[0].item())
+            assert cnt == ref["points"].shape[0], (k, cnt)
+            assert np.array_equal(p.cpu().numpy()[:32 * cnt].reshape(cnt, 32), ref["points"])
+            assert np.array_equal(h.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4), ref["hits"])
+
+    info = lambda: (tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES), tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS), tr.info(capi.LS_INFO_FRAME_GRAPH_PATCHES))
+    g_only = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)]
+    for _ in range(6):
+        frame(g_only)
+    check_last_three()
+    assert info() == (3, 6, 0)                                   # three captures, three pure replays
+    A = oracle.affine_from_components(np.array((1.0, 0.5, 0.1), np.float32), np.array((0.0, 0.0, 0.3), np.float32))
+    tr.updateGeometryTransform("ground", A)
+    moved = [(0, *meshes["ground"], A)]
+    for _ in range(3):
+        frame(moved)
+    check_last_three()
+    assert info() == (3, 9, 3), (info(), bin(tr.info(capi.LS_INFO_FRAME_GRAPH_LAST_PATCHED)))   # the pose went into each of the three graphs once
+    for _ in range(3):
+        frame(moved)
+    assert info() == (3, 12, 3)
+    _add(tr, "face", meshes["ben"])                              # another geometry set
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    both = moved + [(1, *meshes["ben"], oracle.IDENTITY_AFFINE)]
+    for _ in range(4):
+        frame(both)
+    check_last_three()
+    c, r, _ = info()
+    assert r == 16 and c in (3, 6)                               # (two geometries still fit one launch: the sequence may be the same)
+    assert tr.removeGeometry("ground") == 0
+    face_only = [(1, *meshes["ben"], oracle.IDENTITY_AFFINE)]
+    for _ in range(3):
+        frame(face_only)
+    check_last_three()
+    tr.setOption(capi.LS_OPT_FRAME_GRAPH, 0)
+    r0 = info()[1]
+    for _ in range(3):
+        frame(face_only)
+    check_last_three()
+    assert info()[1] == r0                                       # plain launches
+    tr.setOption(capi.LS_OPT_FRAME_GRAPH, 1)
+    for _ in range(3):
+        frame(face_only)
+    check_last_three()
+    assert info()[1] == r0 + 3 and tr.info(capi.LS_INFO_FRAME_GRAPH_STATE) == 1
+    # the synchronous call on the same handle (it closes its graph itself and waits)
+    tr.setOutputBuffers(None, None, None, 0)
+    rc, pts, hits = tr.traceScene(99)
+    _assert_parity(oracle, s, tr, face_only, pts, hits)
     tr.close()
 
 

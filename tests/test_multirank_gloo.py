@@ -116,3 +116,35 @@ def test_c_slot_arithmetic_equals_python():
     want = np.concatenate(recs)
     assert np.array_equal(groupapi.decode_gathered(g_p, world, cap), want)
     assert np.array_equal(shards.decode_gathered(g_c, world, cap).view(np.uint32).reshape(-1, 4), want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N without a launcher (missing 1a): the script starts the N ranks itself -- as a fresh
+# torch.distributed.run child, before anything touches a GPU -- or exits non-zero; it never prints a one-GPU line for --gpus N.
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    return out.returncode, [json.loads(ln) for ln in lines], out.stderr
+
+
+def test_bench_gpus_2_without_launcher_spawns_two_ranks():
+    rc, lines, err = _bench(["--gpus", "2", "--spawn-check"], {"LS_BENCH_REHEARSAL": "1"})
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines                       # ONE JSON line, rank 0's
+    rec = lines[0]
+    assert rec["n_gpus"] == 2 and rec["ranks_met"] == 2 and rec["backend"] == "gloo" and rec["spawned_by_bench"] is True
+
+
+def test_bench_never_reports_fewer_gpus_than_asked_for():
+    # this container has no GPU: --gpus 8 must fail, not fall back to what is there (round 3 printed "n_gpus": 1)
+    rc, lines, err = _bench(["--gpus", "8", "--steps", "2"])
+    assert rc != 0 and lines == [] and "refusing" in err
+    # a launcher whose world disagrees with --gpus is refused as well
+    rc, lines, err = _bench(["--gpus", "4", "--spawn-check"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert rc != 0 and lines == []
