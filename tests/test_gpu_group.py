@@ -152,3 +152,24 @@ def test_sharded_path_two_logical_ranks_on_one_device(oracle, capi, sensors, mes
     for tr in trs:
         tr.synchronize()
         tr.close()
+
+
+def test_bench_two_ranks_rehearsal_without_a_launcher():
+    """`bench.py --gpus 2` with WORLD_SIZE unset: the script starts its two ranks itself (torch.distributed.run as a child,
+    before anything touches the GPU) and rank 0 prints ONE line that says n_gpus 2.  LS_BENCH_REHEARSAL=1: the two ranks
+    share this box's one GPU over gloo (RCCL refuses two ranks on a device), which drives the sharded N > 1 code of bench.py
+    -- shards, slots, gather, rebuild -- end to end; the gathered cloud is the one-GPU cloud."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LS_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--workload", "xt32",
+                          "--no-cpu-baseline", "--min-ms", "5", "--prime-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["gathered_points_rank0"] == 1781                      # OptixTracer_test.cpp:122-169 through two shards
+    assert rec["rccl"]["comm_ranks"] == 2 and rec["rccl"]["comm_ranks_on_every_rank"] == [2, 2]
+    assert rec["rccl"]["launched_by"].startswith("bench.py itself")
+    assert rec["rehearsal_gloo_shared_gpu"] is True
