@@ -112,6 +112,13 @@ typedef struct ls_frame {
  *      OptixTracer::create (OptixTracer.hpp:91) --------------------------------------------- */
 int ls_tracer_create(const ls_sensor_desc *sensor, int hip_device, ls_tracer **out);
 int ls_tracer_create_tables(const ls_sensor_tables *sensor, int hip_device, ls_tracer **out);
+/* ITracer::setSensorConfig (ITracer.hpp:129, ITracer.cpp:48) / a LidarDevice initialised again (LidarDevice.hpp:116-117):
+ * EmbreeTracer::traceScene reads its LidarDevice every frame (EmbreeTracer.cpp:299-307), so another sensor -- raster,
+ * channel table, pose -- takes effect at the next trace.  These calls give the handle another sensor and keep its
+ * geometries: frames in flight complete first, the shard goes back to the full turn, a committed scene is committed
+ * again for the new sensor.  Forms as the two create calls. */
+int ls_tracer_set_sensor(ls_tracer *tr, const ls_sensor_desc *sensor);
+int ls_tracer_set_sensor_tables(ls_tracer *tr, const ls_sensor_tables *sensor);
 void ls_tracer_destroy(ls_tracer *tr);
 
 /* ---- ITracer::addGeometry (ITracer.hpp:50; EmbreeTracer.cpp:115-218; OptixTracer.cpp:63-133).

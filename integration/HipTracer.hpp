@@ -10,6 +10,13 @@
 //   * sensor pose: originToSensorInverse(0) = t exactly, and originToSensor(t + 2^k e_i) = 2^k * Rinv[:,i]
 //     exactly (LidarDevice.cpp:383-401);
 //   * header: initMessage() every frame (LidarDevice.cpp:94-115), as EmbreeTracer::traceScene does.
+// The sensor is not a snapshot: EmbreeTracer::traceScene reads its LidarDevice every frame (EmbreeTracer.cpp:299-307), so
+// ITracer::setSensorConfig (ITracer.cpp:48) or a LidarDevice initialised again in place (LidarDevice.hpp:116-117) takes
+// effect at the next trace.  Here every traceScene compares a fingerprint of the current device -- its address, ray /
+// channel / column counts, the pose (t and Rinv through originToSensor[Inverse]) and the first three walked rays --
+// with the probed one; a difference walks the new device and hands the library the new tables (ls_tracer_set_sensor_tables:
+// the geometries stay).  A change the fingerprint cannot see -- an in-place edit of the channel table beyond channel 0
+// with everything else equal -- is announced with invalidateSensor().
 //
 // Per frame (MeshProjector.cpp:446-464: updateGeometry for every mesh, commitScene, traceScene):
 //   * polygons are flattened and uploaded once per mesh and again only when their fingerprint changes (the
@@ -139,6 +146,7 @@ public:
     int traceScene(std::uint32_t _frameIndex) override
     {
         std::lock_guard<std::mutex> lock(_mutex);
+        followSensor();   // (setSensorConfig / a re-initialised LidarDevice: EmbreeTracer.cpp:299-307 reads _config every frame)
         auto cloud = getTraceCloud();
         getSensorConfig()->initMessage(cloud, static_cast<int>(_frameIndex));
         getSensorConfig()->reset();
@@ -202,6 +210,14 @@ public:
         auto it = _meshes.find(_meshName);
         if (it != _meshes.end()) it->second.haveVertices = it->second.haveElements = false;
     }
+    /// The next traceScene walks the sensor again, whatever its fingerprint says (an in-place edit the fingerprint cannot see)
+    void invalidateSensor()
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        _sensorValid = false;
+    }
+    /// How many times the sensor was probed (1 = at construction only)
+    std::uint64_t getSensorProbeCount() const { return _sensorProbes; }
     /// Number of updateGeometry calls that copied vertex data / that were transform-only (diagnostics)
     std::uint64_t getUploadCount() const { return _uploads; }
     std::uint64_t getSkippedUploadCount() const { return _skipped; }
@@ -231,6 +247,9 @@ private:
             if (e[0] == '1') _policy_ = MeshPolicy::SkipUnchanged;
         SensorProbe probe(*_sensorConfig);
         const ls_sensor_tables tables = probe.tables();
+        _sensorPrint = SensorFingerprint(*_sensorConfig);
+        _sensorValid = true;
+        _sensorProbes = 1;
         const int rc = ls_tracer_create_tables(&tables, _hipDevice, &_handle);
         if (rc != LS_OK)
             throw TraceException(__FILE__, rc == LS_ERR_NO_DEVICE ? "no usable HIP device for the MI355X tracer (there is no CPU fallback)"
@@ -239,6 +258,61 @@ private:
         ls_tracer_set_option(_handle, LS_OPT_HOST_OUTPUT, 2);     // 16 bytes per point over PCIe, expanded into cloud->data
         if (_logger) _logger->debug("HipTracer: {} channels x {} azimuths, {} host copy threads", tables.n_vertical, tables.h_count,
                                     ls_get_info(_handle, LS_INFO_HOST_THREADS));
+    }
+
+    // What one frame can afford to ask the sensor (a dozen calls): enough to notice another device, another raster, another
+    // pose, another azimuth table or another first channel.  Compared bit for bit.
+    struct SensorFingerprint {
+        const void* device = nullptr;
+        unsigned rays = 0, channels = 0, columns = 0;
+        float words[3 + 9 + 9] = {};   // t; Rinv applied to the unit vectors (offset by t); the first three walked directions
+        SensorFingerprint() = default;
+        explicit SensorFingerprint(LidarDevice& d)
+        {
+            device = &d;
+            rays = d.getTotalRays();
+            channels = d.getTotalChannels();
+            columns = d.getScanRayCount();
+            Eigen::Vector3f p(0.0f, 0.0f, 0.0f);
+            d.originToSensorInverse(p);
+            words[0] = p.x(); words[1] = p.y(); words[2] = p.z();
+            for (int i = 0; i < 3; ++i) {
+                Eigen::Vector3f e(i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f, i == 2 ? 1.0f : 0.0f);
+                d.originToSensor(e);
+                words[3 + 3 * i] = e.x(); words[4 + 3 * i] = e.y(); words[5 + 3 * i] = e.z();
+            }
+            d.reset();
+            const unsigned n = rays < 3u ? rays : 3u;
+            for (unsigned r = 0; r < n; ++r) {
+                RTCRayHit ray;
+                int valid = -1;
+                d.nextRay1(ray, &valid);
+                words[12 + 3 * r] = ray.ray.dir_x; words[13 + 3 * r] = ray.ray.dir_y; words[14 + 3 * r] = ray.ray.dir_z;
+            }
+            d.reset();
+        }
+        bool operator==(const SensorFingerprint& o) const
+        {
+            return device == o.device && rays == o.rays && channels == o.channels && columns == o.columns &&
+                   std::memcmp(words, o.words, sizeof(words)) == 0;
+        }
+    };
+
+    // called with _mutex held, at the top of traceScene
+    void followSensor()
+    {
+        LidarDevice::Ptr device = getSensorConfig();
+        if (!device) throw TraceException(__FILE__, "traceScene without a sensor (setSensorConfig(nullptr))", 1);
+        const SensorFingerprint now(*device);
+        if (_sensorValid && now == _sensorPrint) return;
+        SensorProbe probe(*device);   // throws when the device cannot be expressed as factor tables
+        const ls_sensor_tables tables = probe.tables();
+        const int rc = ls_tracer_set_sensor_tables(_handle, &tables);
+        if (rc < -1) throw TraceException(__FILE__, ls_last_error(_handle), rc);
+        _sensorPrint = now;
+        _sensorValid = true;
+        ++_sensorProbes;
+        if (_logger) _logger->debug("HipTracer: the sensor changed: {} channels x {} azimuths now", tables.n_vertical, tables.h_count);
     }
 
     // FNV-1a over a few words: identity probes, not integrity checks
@@ -573,6 +647,9 @@ private:
     std::map<std::string, MeshState> _meshes;
     MeshPolicy _policy_ = MeshPolicy::UploadAlways;
     std::uint64_t _uploads = 0, _skipped = 0;
+    SensorFingerprint _sensorPrint;
+    bool _sensorValid = false;
+    std::uint64_t _sensorProbes = 0;
     ls_tracer* _handle = nullptr;
 };
 

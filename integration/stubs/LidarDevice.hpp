@@ -27,6 +27,8 @@ public:
     Ptr getPtr();
     ~LidarDevice();
 
+    void initialize(const std::string& _config);                                // (LidarDevice.hpp:116-117: the same object, another configuration)
+    void initialize(const std::string& _config, const std::string& _sensorUid);
     void initMessage(sensor_msgs::PointCloud2Ptr _msg, int _frameIndex);
     int nextRay1(RTCRayHit& _ray, int* _valid);
     void originToSensor(Eigen::Vector3f& _sensor) const;

@@ -47,6 +47,17 @@ LidarDevice::LidarDevice(const std::string& _config, const std::string& _sensorU
     _impl->uid = lsh_device_uid(_impl->device);
 }
 
+void LidarDevice::initialize(const std::string& _config) { initialize(_config, ""); }
+void LidarDevice::initialize(const std::string& _config, const std::string& _sensorUid)
+{
+    lsh_device* fresh = lsh_device_create(_config.c_str(), _sensorUid.c_str());
+    if (!fresh) throw std::runtime_error(std::string("stub LidarDevice: ") + lsh_last_error());
+    if (_impl->device) lsh_device_destroy(_impl->device);
+    _impl->device = fresh;
+    _impl->uid = lsh_device_uid(fresh);
+    _impl->vertical = _impl->horizontal = 0;
+}
+
 LidarDevice::~LidarDevice()
 {
     if (_impl && _impl->device) lsh_device_destroy(_impl->device);

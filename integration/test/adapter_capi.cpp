@@ -256,5 +256,22 @@ long lsa_getter(lsa_ctx* c, int what, const char* name)
 // HipTracer::invalidateMesh: how an in-place vertex edit that leaves the header alone is announced under SkipUnchanged
 void lsa_invalidate_mesh(lsa_ctx* c, const char* name) { c->tracer->invalidateMesh(name); }
 
+// ITracer::setSensorConfig (ITracer.cpp:48) with a NEW LidarDevice made from `sensor_config`, through the base-class pointer
+int lsa_set_sensor_config(lsa_ctx* c, const char* sensor_config)
+{
+    try {
+        c->device = LidarDevice::create(sensor_config);
+        c->itracer->setSensorConfig(c->device);
+        return 0;
+    } catch (const std::exception& e) { g_error = e.what(); return -100; }
+}
+// LidarDevice::initialize (LidarDevice.hpp:116-117): the SAME device object reads another configuration
+int lsa_reinitialize_sensor(lsa_ctx* c, const char* sensor_config)
+{
+    try { c->device->initialize(sensor_config); return 0; } catch (const std::exception& e) { g_error = e.what(); return -100; }
+}
+void lsa_invalidate_sensor(lsa_ctx* c) { c->tracer->invalidateSensor(); }
+unsigned long long lsa_sensor_probe_count(lsa_ctx* c) { return c->tracer->getSensorProbeCount(); }
+
 }  // extern "C"
 #pragma GCC visibility pop

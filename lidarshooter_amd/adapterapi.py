@@ -62,6 +62,12 @@ def load() -> C.CDLL:
     L.lsa_getter.restype = C.c_long
     L.lsa_invalidate_mesh.argtypes = [vp, C.c_char_p]
     L.lsa_invalidate_mesh.restype = None
+    L.lsa_set_sensor_config.argtypes = [vp, C.c_char_p]
+    L.lsa_reinitialize_sensor.argtypes = [vp, C.c_char_p]
+    L.lsa_invalidate_sensor.argtypes = [vp]
+    L.lsa_invalidate_sensor.restype = None
+    L.lsa_sensor_probe_count.argtypes = [vp]
+    L.lsa_sensor_probe_count.restype = C.c_ulonglong
     _lib = L
     return L
 
@@ -185,3 +191,19 @@ class AdapterTracer:
 
     def invalidateMesh(self, name: str):
         self.L.lsa_invalidate_mesh(self.c, name.encode())
+
+    def setSensorConfig(self, sensor_config: str):
+        """ITracer::setSensorConfig with a new LidarDevice made from that file (through the base-class pointer)"""
+        if self.L.lsa_set_sensor_config(self.c, sensor_config.encode()) != 0:
+            raise RuntimeError(self.L.lsa_last_error().decode())
+
+    def reinitializeSensor(self, sensor_config: str):
+        """LidarDevice::initialize on the device the tracer already holds"""
+        if self.L.lsa_reinitialize_sensor(self.c, sensor_config.encode()) != 0:
+            raise RuntimeError(self.L.lsa_last_error().decode())
+
+    def invalidateSensor(self):
+        self.L.lsa_invalidate_sensor(self.c)
+
+    def sensorProbeCount(self) -> int:
+        return int(self.L.lsa_sensor_probe_count(self.c))

@@ -44,6 +44,7 @@ SYMBOLS = (
     "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type", "ls_tracer_order_after_last_frame", "ls_tracer_wait_event", "ls_tracer_next_frame_waits", "ls_trace_scene_begin", "ls_trace_scene_expand",
     "ls_frame_graph_begin", "ls_frame_graph_stream", "ls_frame_graph_end", "ls_frame_graph_reset",
+    "ls_tracer_set_sensor", "ls_tracer_set_sensor_tables",
 )
 # include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
 DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",
@@ -105,6 +106,8 @@ def load() -> C.CDLL:
     L.ls_abi_version.restype = i32
     L.ls_tracer_create.argtypes = [C.POINTER(SensorDesc), i32, C.POINTER(vp)]
     L.ls_tracer_create_tables.argtypes = [C.POINTER(SensorTables), i32, C.POINTER(vp)]
+    L.ls_tracer_set_sensor.argtypes = [vp, C.POINTER(SensorDesc)]
+    L.ls_tracer_set_sensor_tables.argtypes = [vp, C.POINTER(SensorTables)]
     L.ls_affine_from_components.argtypes = [f32p, f32p, f32p]
     L.ls_affine_from_components.restype = None
     L.ls_expand_points.argtypes = [vp, vp, u32]
@@ -196,6 +199,19 @@ class Tracer:
         if rc != 0:
             raise LidarShooterHipError(f"ls_tracer_create failed with status {rc} (no HIP device / bad sensor)")
         self.h = h
+
+    def setSensor(self, vertical_deg, h_begin, h_end, h_count, Rinv, t):
+        """ITracer::setSensorConfig: another sensor for this handle, its geometries stay (ls_tracer_set_sensor)"""
+        self._vert = np.ascontiguousarray(vertical_deg, np.float32)
+        sd = SensorDesc()
+        sd.vertical_deg = _f32p(self._vert)
+        sd.n_vertical = self._vert.shape[0]
+        sd.h_begin, sd.h_end, sd.h_count = float(h_begin), float(h_end), int(h_count)
+        sd.Rinv = (C.c_float * 9)(*[float(x) for x in np.asarray(Rinv, np.float32).reshape(9)])
+        sd.t = (C.c_float * 3)(*[float(x) for x in np.asarray(t, np.float32).reshape(3)])
+        self._check(self.L.ls_tracer_set_sensor(self.h, C.byref(sd)), "ls_tracer_set_sensor")
+        self.V, self.H = int(sd.n_vertical), int(h_count)
+        self.az0, self.naz = 0, self.H
 
     # ---- lifetime
     def close(self):

@@ -100,6 +100,95 @@ extern "C" {
 
 int ls_abi_version(void) { return LS_ABI_VERSION; }
 
+// the sensor's tables on the device and on the host, from tr's sensor fields (create, ls_tracer_set_sensor*)
+static int upload_tables(ls_tracer *tr)
+{
+    std::vector<float> tab;
+    fill_tables(tr, tab);
+    float *d = nullptr;
+    LS_HIP(hipMalloc(reinterpret_cast<void **>(&d), tab.size() * 4));
+    if (hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(tr, LS_ERR_HIP, "uploading the sensor tables failed");
+    }
+    if (tr->d_tables) (void)hipFree(tr->d_tables);
+    tr->d_tables = d;
+    tr->host_tables = tab;
+    return LS_OK;
+}
+
+static void check_projection_ok(ls_tracer *tr)
+{
+    tr->projection_ok = true;
+    for (float chi : tr->vertical)
+        if (!(chi >= -90.0f && chi <= 90.0f)) tr->projection_ok = false;  // elevation == channel angle only there
+    if (!std::isfinite(tr->h_begin) || !std::isfinite(tr->h_end)) tr->projection_ok = false;
+    if (tr->V > 32767u) tr->projection_ok = false;  // channel range is packed into 16+15 bits
+}
+
+// the sensor fields of `tr` from a descriptor / from given tables (validated by the caller)
+static void take_sensor_desc(ls_tracer *tr, const ls_sensor_desc *sd)
+{
+    tr->V = sd->n_vertical;
+    tr->H = sd->h_count;
+    tr->vertical.assign(sd->vertical_deg, sd->vertical_deg + sd->n_vertical);
+    tr->given_tables.clear();
+    tr->h_begin = sd->h_begin;
+    tr->h_end = sd->h_end;
+    tr->h_step = (sd->h_end - sd->h_begin) / static_cast<float>(sd->h_count - 1u);  // LidarDevice.cpp:611
+    std::memcpy(tr->rinv, sd->Rinv, sizeof(tr->rinv));
+    std::memcpy(tr->t, sd->t, sizeof(tr->t));
+}
+
+static void take_sensor_tables(ls_tracer *tr, const ls_sensor_tables *st)
+{
+    const uint32_t V = tr->V = st->n_vertical, H = tr->H = st->h_count;
+    tr->vertical.assign(st->elevation_deg, st->elevation_deg + V);
+    tr->h_begin = st->h_begin_deg;
+    tr->h_step = st->h_step_deg;
+    tr->h_end = st->h_begin_deg + st->h_step_deg * static_cast<float>(H - 1u);
+    tr->given_tables.resize(2 * (size_t)V + 2 * (size_t)H);
+    std::memcpy(tr->given_tables.data(), st->sin_theta, V * sizeof(float));
+    std::memcpy(tr->given_tables.data() + V, st->cos_theta, V * sizeof(float));
+    std::memcpy(tr->given_tables.data() + 2 * (size_t)V, st->sin_phi, H * sizeof(float));
+    std::memcpy(tr->given_tables.data() + 2 * (size_t)V + H, st->cos_phi, H * sizeof(float));
+    std::memcpy(tr->rinv, st->Rinv, sizeof(tr->rinv));
+    std::memcpy(tr->t, st->t, sizeof(tr->t));
+}
+
+static bool valid_tables(const ls_sensor_tables *st)
+{
+    return st && st->sin_theta && st->cos_theta && st->elevation_deg && st->sin_phi && st->cos_phi && st->n_vertical != 0 && st->h_count >= 2;
+}
+
+// A handle takes another sensor -- raster, channel tables, pose -- and keeps its geometries (ITracer::setSensorConfig,
+// ITracer.cpp:48: EmbreeTracer::traceScene reads _config every frame, EmbreeTracer.cpp:299-307, so a swapped or
+// re-initialised LidarDevice takes effect at the next trace).  Everything in flight completes first; the shard goes back
+// to the full turn; a committed scene is committed again for the new sensor (the classic BVH lives in the sensor frame).
+static int sensor_changed(ls_tracer *tr)
+{
+    frame_graph_destroy(tr);
+    tr->az0 = 0;
+    tr->naz = tr->H;
+    int rc = upload_tables(tr);
+    if (rc) return rc;
+    check_projection_ok(tr);
+    if (tr->engine == 2 && !tr->projection_ok) tr->engine = 0;   // (the projection engine was asked for and no longer applies)
+    tr->keys_armed = tr->keys_b_armed = tr->keys_c_armed = false;
+    tr->traced = false;
+    tr->pack_split = 0;
+    tr->begin_open = tr->progress_active = false;
+    tr->layout_dirty = true;          // every sensor-frame product (materialised scene, sensor-centred Morton order) is stale
+    tr->scene_materialized = false;
+    tr->bvh_order_valid = false;
+    if (tr->committed) {
+        tr->committed = false;
+        rc = commit_locked(tr);
+        if (rc < -1) return rc;
+    }
+    return LS_OK;
+}
+
 // shared tail of the two create calls: `tr` holds the sensor (V, H, vertical, h_begin / h_step, pose and, for
 // ls_tracer_create_tables, the given factor tables)
 static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
@@ -122,20 +211,13 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
     };
     if (hipStreamCreateWithFlags(&tr->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(LS_ERR_HIP);
     tr->stream = tr->own_stream;
-    std::vector<float> tab;
-    fill_tables(tr, tab);
-    if (hipMalloc(reinterpret_cast<void **>(&tr->d_tables), tab.size() * 4) != hipSuccess) return bail(LS_ERR_HIP);
-    if (hipMemcpy(tr->d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(LS_ERR_HIP);
-    tr->host_tables = tab;
+    if (upload_tables(tr) != LS_OK) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_maxabs), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_visits), 32) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_n_points), 4) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_queue_heads), ls::kQueues * 16 * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipMalloc(reinterpret_cast<void **>(&tr->d_big_count), 4 * ls::kCounterSlotWords * sizeof(uint32_t)) != hipSuccess) return bail(LS_ERR_HIP);
-    for (float chi : tr->vertical)
-        if (!(chi >= -90.0f && chi <= 90.0f)) tr->projection_ok = false;  // elevation == channel angle only there
-    if (!std::isfinite(tr->h_begin) || !std::isfinite(tr->h_end)) tr->projection_ok = false;
-    if (tr->V > 32767u) tr->projection_ok = false;  // channel range is packed into 16+15 bits
+    check_projection_ok(tr);
     tr->trace_blocks = ls::trace_grid_blocks(hip_device);
     {
         // Ray order of the persistent trace grid.  Round 1 visited the channels at a stride near 0.38 V (cheap sky channels
@@ -169,38 +251,44 @@ int ls_tracer_create(const ls_sensor_desc *sd, int hip_device, ls_tracer **out)
     if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return LS_ERR_INVALID_ARGUMENT;
     if ((unsigned long long)sd->n_vertical * sd->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;  // ray indices are 32-bit
     ls_tracer *tr = new ls_tracer();
-    tr->V = sd->n_vertical;
-    tr->H = sd->h_count;
-    tr->vertical.assign(sd->vertical_deg, sd->vertical_deg + sd->n_vertical);
-    tr->h_begin = sd->h_begin;
-    tr->h_end = sd->h_end;
-    tr->h_step = (sd->h_end - sd->h_begin) / static_cast<float>(sd->h_count - 1u);  // LidarDevice.cpp:611
-    std::memcpy(tr->rinv, sd->Rinv, sizeof(tr->rinv));
-    std::memcpy(tr->t, sd->t, sizeof(tr->t));
+    take_sensor_desc(tr, sd);
     return create_device_state(tr, hip_device, out);
+}
+
+int ls_tracer_set_sensor(ls_tracer *tr, const ls_sensor_desc *sd)
+{
+    LS_ENTER(tr);
+    if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "incomplete sensor descriptor");
+    if ((unsigned long long)sd->n_vertical * sd->h_count > 0x7FFFFFFFull) return fail(tr, LS_ERR_OUT_OF_RANGE, "ray indices are 32-bit");
+    if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open");
+    const int rc = flush_pipeline(tr);
+    if (rc) return rc;
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    take_sensor_desc(tr, sd);
+    return sensor_changed(tr);
+}
+
+int ls_tracer_set_sensor_tables(ls_tracer *tr, const ls_sensor_tables *st)
+{
+    LS_ENTER(tr);
+    if (!valid_tables(st)) return fail(tr, LS_ERR_INVALID_ARGUMENT, "incomplete sensor tables");
+    if ((unsigned long long)st->n_vertical * st->h_count > 0x7FFFFFFFull) return fail(tr, LS_ERR_OUT_OF_RANGE, "ray indices are 32-bit");
+    if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open");
+    const int rc = flush_pipeline(tr);
+    if (rc) return rc;
+    LS_HIP(hipStreamSynchronize(tr->stream));
+    take_sensor_tables(tr, st);
+    return sensor_changed(tr);
 }
 
 int ls_tracer_create_tables(const ls_sensor_tables *st, int hip_device, ls_tracer **out)
 {
     if (!out) return LS_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (!st || !st->sin_theta || !st->cos_theta || !st->elevation_deg || !st->sin_phi || !st->cos_phi || st->n_vertical == 0 ||
-        st->h_count < 2)
-        return LS_ERR_INVALID_ARGUMENT;
+    if (!valid_tables(st)) return LS_ERR_INVALID_ARGUMENT;
     if ((unsigned long long)st->n_vertical * st->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;
     ls_tracer *tr = new ls_tracer();
-    const uint32_t V = tr->V = st->n_vertical, H = tr->H = st->h_count;
-    tr->vertical.assign(st->elevation_deg, st->elevation_deg + V);
-    tr->h_begin = st->h_begin_deg;
-    tr->h_step = st->h_step_deg;
-    tr->h_end = st->h_begin_deg + st->h_step_deg * static_cast<float>(H - 1u);
-    tr->given_tables.resize(2 * (size_t)V + 2 * (size_t)H);
-    std::memcpy(tr->given_tables.data(), st->sin_theta, V * sizeof(float));
-    std::memcpy(tr->given_tables.data() + V, st->cos_theta, V * sizeof(float));
-    std::memcpy(tr->given_tables.data() + 2 * (size_t)V, st->sin_phi, H * sizeof(float));
-    std::memcpy(tr->given_tables.data() + 2 * (size_t)V + H, st->cos_phi, H * sizeof(float));
-    std::memcpy(tr->rinv, st->Rinv, sizeof(tr->rinv));
-    std::memcpy(tr->t, st->t, sizeof(tr->t));
+    take_sensor_tables(tr, st);
     return create_device_state(tr, hip_device, out);
 }
 

@@ -277,3 +277,52 @@ def test_adapter_quad_mesh(adapterapi, oracle, sensors):
     with pytest.raises(Exception, match="element vertex count"):
         tr.updateGeometry("wrong")
     tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_follows_the_sensor(adapterapi, oracle, sensors, meshes, tmp_path):
+    """ITracer::setSensorConfig (ITracer.hpp:129, ITracer.cpp:48) and a LidarDevice initialised again in place
+    (LidarDevice.hpp:116-117) take effect at the next traceScene, as with EmbreeTracer, whose traceScene reads its
+    LidarDevice every frame (EmbreeTracer.cpp:299-307).  Round 3's adapter probed the sensor once, in its constructor,
+    and went on tracing the old tables with the new device's header (missing 3)."""
+    from lidarshooter_amd import synth
+    both = {"mesh": meshes["ground"], "face": meshes["ben"]}
+    spec = [(0, "mesh", oracle.IDENTITY_AFFINE), (1, "face", oracle.IDENTITY_AFFINE)]
+    tr = adapterapi.AdapterTracer(CFG["0000"])
+    tr.meshFromSTL("mesh", STL["ground"])
+    tr.meshFromSTL("face", STL["ben"])
+    assert tr.addGeometry("mesh") == 0 and tr.addGeometry("face") == 1
+
+    def frame(i):
+        tr.updateGeometry("mesh")
+        tr.updateGeometry("face")
+        assert tr.commitScene() == 0 and tr.traceScene(i) == 0
+        return tr.cloud()
+
+    c = frame(0)
+    assert c["width"] == 1781 and tr.sensorProbeCount() == 1
+    c = frame(1)
+    assert c["width"] == 1781 and tr.sensorProbeCount() == 1                      # an unchanged sensor is not walked again
+    # ---- another device object through ITracer::setSensorConfig: lidar_0001's pose and uid
+    tr.setSensorConfig(CFG["0001"])
+    c = frame(2)
+    assert c["width"] == 1769 and tr.sensorProbeCount() == 2                       # SURVEY.md 8c: lidar_0001 x ground+ben
+    assert np.array_equal(_points(c), _oracle_points(oracle, sensors["0001"], both, spec))
+    # ---- the same setSensorConfig without a new updateGeometry / commitScene in between: the library re-commits itself
+    tr.setSensorConfig(CFG["0000"])
+    assert tr.traceScene(3) == 0
+    c = tr.cloud()
+    assert c["width"] == 1781 and np.array_equal(_points(c), _oracle_points(oracle, sensors["0000"], both, spec))
+    # ---- the SAME device object, initialised again with another raster (64 channels x 600 columns) and lidar_0000's pose
+    path = synth.write_sensor_json(CFG["0000"], str(tmp_path / "wide.json"), synth.syn_vertical(64), 0.0, 360.0, 600)
+    tr.reinitializeSensor(path)
+    c = frame(4)
+    s2 = oracle.load_sensor(path)
+    want = _oracle_points(oracle, s2, both, spec)
+    assert c["width"] == want.shape[0] > 2000 and np.array_equal(_points(c), want)
+    assert tr.sensorProbeCount() == 4
+    # ---- invalidateSensor: the sensor is walked again at the next trace whatever the fingerprint says; same answer
+    tr.invalidateSensor()
+    c = frame(5)
+    assert tr.sensorProbeCount() == 5 and np.array_equal(_points(c), want)
+    tr.close()

@@ -1202,3 +1202,35 @@ def test_argument_errors(capi, sensors):
         capi.Tracer(s.vertical, s.h_begin, s.h_end, s.h_count, s.Rinv, s.t, device=99)        # no such GPU
     assert tr.commitScene() == -1 and tr.traceScene(0)[0] == -1                               # nothing uploaded yet
     tr.close()
+
+
+@pytest.mark.parametrize("instanced", [1, 0])
+def test_set_sensor_keeps_the_geometries(oracle, capi, sensors, meshes, engine, instanced):
+    """ls_tracer_set_sensor (ITracer::setSensorConfig, ITracer.cpp:48): another raster and pose on a handle that keeps
+    its geometries and its commit; both engines (the classic BVH lives in the sensor frame and is built again), with
+    frames in flight when the sensor changes."""
+    from lidarshooter_amd import synth
+    s0, s1 = sensors["0000"], sensors["0001"]
+    wide = oracle.Sensor(uid="wide", vertical=synth.syn_vertical(48), h_begin=np.float32(-180.0), h_end=np.float32(180.0), h_count=400,
+                         R=s1.R, Rinv=s1.Rinv, t=s1.t)
+    tr = make_tracer(capi, s0, engine)
+    tr.setOption(capi.LS_OPT_BVH_INSTANCED, instanced)
+    _add(tr, "ground", meshes["ground"])
+    _add(tr, "face", meshes["ben"])
+    A = oracle.affine_from_components(np.array((0.5, -1.0, 0.1), np.float32), np.array((0.0, 0.1, 0.8), np.float32))
+    ml = [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], A)]
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    tr.updateGeometry("face", A, *meshes["ben"])
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    _assert_parity(oracle, s0, tr, ml, pts, hits)
+    for k, s in enumerate((s1, wide, s0)):
+        if engine == "projection":
+            tr.setOption(capi.LS_OPT_PIPELINE, 2 if k == 1 else 0)
+            tr.traceSceneAsync(10 + k)                            # a frame in flight when the sensor goes
+        tr.setSensor(s.vertical, s.h_begin, s.h_end, s.h_count, s.Rinv, s.t)
+        assert tr.getTotalRays() == s.V * s.H
+        rc, pts, hits = tr.traceScene(20 + k)                     # no commit in between: the library committed again itself
+        assert rc == 0
+        _assert_parity(oracle, s, tr, ml, pts, hits)
+    tr.close()
