@@ -829,17 +829,45 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         st_ms = adapter_ms()                                   # unchanged cloud: pose-only update, no vertex traffic
         ac = at.cloud()
         vbytes = sum(v.shape[0] * 16 for _, v, _ in meshes)
+        # ---- the PCIe floor of the drop-in frame, from rates measured here: the vertex upload as the adapter does it
+        #      (updateGeometry alone: one copy straight from pageable memory, the call returns when it has been read) and the
+        #      cloud's way back (8 bytes per point -- ray number and t -- into pinned host memory) at this link's D2H rate
+        at.setSkipUnchanged(False)
+        ups = []
+        for _ in range(12):
+            t1 = time.perf_counter()
+            for name, _, _ in meshes:
+                at.updateGeometry(name)
+            ups.append(time.perf_counter() - t1)
+        upload_ms = float(np.median(ups[2:])) * 1e3
+        down_bytes = int(ac["width"]) * 8
+        src = torch.empty(max(down_bytes, 1 << 16), dtype=torch.uint8, device=device)
+        dst = torch.empty(src.numel(), dtype=torch.uint8).pin_memory()
+        downs = []
+        for _ in range(12):
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize(device)
+            downs.append(time.perf_counter() - t1)
+        download_ms = float(np.median(downs[2:])) * 1e3
+        del src, dst
         dropin = {"dropin_ms_per_step": up_ms, "dropin_static_ms_per_step": st_ms, "points": int(ac["width"]),
                   "cloud_equals_headline_hits": int(ac["width"]) == n_hits,
-                  "vertex_bytes_uploaded_per_frame": vbytes, "point_bytes_over_pcie_per_frame": int(ac["width"]) * 16,
+                  "vertex_bytes_uploaded_per_frame": vbytes, "point_bytes_over_pcie_per_frame": down_bytes,
+                  "floor_ms": upload_ms + download_ms, "gap_ms": up_ms - (upload_ms + download_ms),
+                  "floor": {"upload_ms": upload_ms, "upload_gb_per_s": vbytes / (upload_ms * 1e-3) / 1e9,
+                            "download_ms": download_ms, "download_gb_per_s": down_bytes / (download_ms * 1e-3) / 1e9,
+                            "what": "floor_ms = the two PCIe transfers of a frame back to back at the rates measured in this run: the vertex "
+                                    "upload (updateGeometry calls alone) + a device-to-pinned-host copy of the cloud's 8-byte records; gap_ms = "
+                                    "dropin_ms_per_step - floor_ms = kernels + launches + the host-side rebuild that do not hide under a transfer"},
                   "what": "MeshProjector::traceAffineMesh through lidarshooter::HipTracer (integration/HipTracer.hpp, stand-in ROS/PCL "
                           "types): updateGeometry(translation, rotation, mesh) per mesh + commitScene + traceScene into PointCloud2::data; "
                           "dropin = vertices re-sent every frame (default), dropin_static = unchanged cloud detected, pose-only update "
                           "(setMeshPolicy(SkipUnchanged)); polygons are sent once in both",
-                  "pcie_floor_note": "the cloud has to reach host memory: 16 B per point (the other 16 of a record are constants, "
-                                     "rebuilt on the host) = %.2f MB per frame, ~%.0f us at the ~55 GB/s measured on this link; the "
-                                     "vertex upload moves %.1f MB (~%.0f us)" % (int(ac["width"]) * 16 / 1e6, int(ac["width"]) * 16 / 55e3,
-                                                                                vbytes / 1e6, vbytes / 55e3)}
+                  "pcie_floor_note": "the cloud has to reach host memory: 8 B per point ((ray, t): the 32-byte record is rebuilt on the "
+                                     "host from the factor tables) = %.2f MB per frame; the vertex upload moves %.1f MB"
+                                     % (down_bytes / 1e6, vbytes / 1e6)}
         at.close()
 
     total_rays = V * H * (world if independent else 1)
@@ -906,8 +934,10 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
     one_ms = latency_frame_s * 1e3 if latency_frame_s is not None else ms_per_step
 
     out = {
-        "metric": {"syn128x1m": "Mrays/s (full LiDAR frame: update + commit + trace + pack; 128ch x 4096az over 1M tris)",
-                   "syn128x10m": "Mrays/s (full LiDAR frame; 128ch x 4096az over 10M tris)",
+        "metric": {"syn128x1m": "Mrays/s (LiDAR frame = updateGeometry + commitScene + traceScene incl. point packing, 128ch x 4096az over 1M tris; "
+                                "geometry resident in HBM, every mesh's pose restated per frame; cloud left in HBM -- the frame with vertices "
+                                "re-sent from host memory and the cloud delivered to PointCloud2::data is dropin_ms_per_step)",
+                   "syn128x10m": "Mrays/s (LiDAR frame as above; 128ch x 4096az over 10M tris; geometry resident in HBM, cloud left in HBM)",
                    "cfg5": "Mrays/s (one 128ch x 4096az sensor per GPU over a shared 10M-tri scene + animated instance)",
                    "xt32": "Mrays/s (XT-32 over ground+ben)"}[args.workload],
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -236,6 +236,7 @@ private:
         std::size_t vertexBytes = 0;
         std::uint64_t stamp = 0;
         std::uint32_t seq = 0, pointStep = 0;
+        std::uint64_t vertexSample = 0;    // unstamped clouds under SkipUnchanged: hash of 64 sampled vertices
         std::vector<std::uint32_t> flat;   // scratch of the one-off polygon flatten
     };
 
@@ -338,6 +339,19 @@ private:
         return h;
     }
 
+    static std::uint64_t probeVertices(const std::uint8_t* data, std::size_t n, std::size_t pointStep)
+    {
+        std::uint64_t h = 1469598103934665603ull;
+        const std::size_t step = n > 64 ? n / 64 : 1;
+        for (std::size_t i = 0; i < n; i += step) {
+            std::uint32_t w[3];
+            std::memcpy(w, data + i * pointStep, 12);
+            h = mix(h, (static_cast<std::uint64_t>(w[0]) << 32) | w[1]);
+            h = mix(h, w[2]);
+        }
+        return h;
+    }
+
     int updateFromMesh(const std::string& _meshName, const float affine[12], pcl::PolygonMesh::Ptr& _mesh)
     {
         std::lock_guard<std::mutex> lock(_mutex);
@@ -377,9 +391,23 @@ private:
         const std::uint64_t stamp = static_cast<std::uint64_t>(cloud.header.stamp);
         const std::uint32_t seq = static_cast<std::uint32_t>(cloud.header.seq);
         // SkipUnchanged is a contract (see MeshPolicy): identity of buffer and header stands for identity of content
+        // An UNSTAMPED cloud (seq and stamp both zero: a publisher that never fills the header, or a mesh loaded from a file
+        // and copied over in place, MeshProjector.cpp:306-307) cannot announce an edit through its header: for those, and only
+        // those, 64 evenly spaced vertices are hashed as a safety net -- it catches a rigid edit of the whole cloud, not an
+        // edit of vertices it does not sample; invalidateMesh() stays the contract
+        const bool unstamped = seq == 0u && stamp == 0u;
+        std::uint64_t sample = 0;
+        if (unstamped) sample = probeVertices(vertexData, st.numVertices, pointStep);   // (whatever the policy: it may change between frames)
+        if (_policy_ == MeshPolicy::SkipUnchanged && unstamped) {
+            if (!_warnedUnstamped && _logger) {
+                _logger->warn("HipTracer: SkipUnchanged with an unstamped mesh cloud ('{}'): in-place vertex edits must be announced "
+                              "with invalidateMesh(); a 64-vertex sample is compared as a safety net", _meshName);
+                _warnedUnstamped = true;
+            }
+        }
         const bool unchanged = _policy_ == MeshPolicy::SkipUnchanged && st.haveVertices && indices == nullptr &&
                                st.vertexStorage == static_cast<const void*>(vertexData) && st.vertexBytes == vertexBytes &&
-                               st.pointStep == pointStep && st.seq == seq && st.stamp == stamp;
+                               st.pointStep == pointStep && st.seq == seq && st.stamp == stamp && (!unstamped || st.vertexSample == sample);
         int rc;
         if (unchanged) {
             rc = ls_update_geometry_transform(_handle, _meshName.c_str(), affine);
@@ -395,6 +423,7 @@ private:
         st.pointStep = static_cast<std::uint32_t>(pointStep);
         st.seq = seq;
         st.stamp = stamp;
+        st.vertexSample = sample;
         if (indices != nullptr) {
             st.haveElements = true;
             st.polygonStorage = _mesh->polygons.data();
@@ -650,6 +679,7 @@ private:
     SensorFingerprint _sensorPrint;
     bool _sensorValid = false;
     std::uint64_t _sensorProbes = 0;
+    bool _warnedUnstamped = false;
     ls_tracer* _handle = nullptr;
 };
 

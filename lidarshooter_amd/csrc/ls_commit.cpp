@@ -63,8 +63,9 @@ int prepare_blocks(ls_tracer *tr, Geometry &g)
         if (!tr->d_aabb6) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_aabb6), 32));
         tr->bvh_order_valid = false;   // keys_a / keys_b / vals_a are the scratch of this pass
         ++tr->key_scratch_epoch;
-        ls::launch_mesh_order(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.n_verts, g.idx(), nt, tr->d_aabb6,
-                              tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->sort_temp.p, tr->sort_temp.cap, g.d_perm, g.d_idx_sorted);
+        if (!ls::launch_mesh_order(tr->stream, static_cast<const uint8_t *>(g.raw()), g.stride, g.n_verts, g.idx(), nt, tr->d_aabb6,
+                                   tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->sort_temp.p, tr->sort_temp.cap, g.d_perm, g.d_idx_sorted))
+            return fail(tr, LS_ERR_OUT_OF_RANGE, "the sort scratch is smaller than the mesh order needs");
         g.order_stale = false;
         g.bounds_stale = true;
     }
@@ -186,7 +187,8 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             const bool refit = tr->opt_bvh_refit && !ge.blas_topo_dirty && ge.blas_sorted_epoch == tr->key_scratch_epoch;
             if (!refit) {
                 ls::launch_morton(s, verts, tris, ge.n_tris, tr->d_inst_maxabs + i, ka, va);
-                ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, ka, kb, va, vb, ge.n_tris);
+                if (!ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, ka, kb, va, vb, ge.n_tris))
+                    return fail(tr, LS_ERR_OUT_OF_RANGE, "the sort scratch is smaller than a geometry's hierarchy build needs");
                 ge.blas_sorted_epoch = tr->key_scratch_epoch;
             }
             float4 *rb = tr->range_boxes.p + sl.range_first;
@@ -321,7 +323,8 @@ int commit_locked(ls_tracer *tr)
         mark(tr, 1);
         if (!refit) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
         mark(tr, 2);
-        if (!refit) ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt);
+        if (!refit && !ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt))
+            return fail(tr, LS_ERR_OUT_OF_RANGE, "the sort scratch is smaller than the hierarchy build needs");
         mark(tr, 3);
         tr->bvh_order_valid = true;
         tr->bvh_order_tris = nt;

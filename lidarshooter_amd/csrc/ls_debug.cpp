@@ -98,8 +98,8 @@ int ls_debug_sort_pairs(ls_tracer *tr, uint32_t *keys, uint32_t *vals, uint32_t 
     if (e == hipSuccess) e = hipMemcpy(d, keys, (size_t)n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + n, vals, (size_t)n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        ls::launch_sort(tr->stream, temp, tb, d, d + 2 * (size_t)n, d + n, d + 3 * (size_t)n, n);
-        e = hipStreamSynchronize(tr->stream);
+        e = ls::launch_sort(tr->stream, temp, tb, d, d + 2 * (size_t)n, d + n, d + 3 * (size_t)n, n) ? hipStreamSynchronize(tr->stream)
+                                                                                                       : hipErrorInvalidValue;
     }
     if (e == hipSuccess) e = hipMemcpy(keys, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(vals, d + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost);

@@ -233,10 +233,12 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
         { const uint32_t v = (uint32_t)tune_int("LS_TRACE_CHAN_MUL", 1); if (v && gcd(v, tr->V) == 1u) tr->chan_mul = v; }
         { const int v = tune_int("LS_TRACE_REFILL_MIN", 56); if (v >= 1 && v <= 64) tr->refill_min = (uint32_t)v; }
     }
-    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16) != hipSuccess) return bail(LS_ERR_HIP);
-    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_status), 16) != hipSuccess) return bail(LS_ERR_HIP);
+    // (coherent and mapped, explicitly: the host polls these words while kernels are still running)
+    constexpr unsigned kHostWords = hipHostMallocMapped | hipHostMallocCoherent;
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16, kHostWords) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_status), 16, kHostWords) != hipSuccess) return bail(LS_ERR_HIP);
     *tr->h_status = 0u;
-    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_progress), sizeof(ls::HostProgress)) != hipSuccess) return bail(LS_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_progress), sizeof(ls::HostProgress), kHostWords) != hipSuccess) return bail(LS_ERR_HIP);
     std::memset(tr->h_progress, 0, sizeof(ls::HostProgress));
 
     tr->slot_tri_first.assign(1, 0u);

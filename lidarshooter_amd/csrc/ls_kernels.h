@@ -166,7 +166,7 @@ void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t
 void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint32_t ntris,
                    const uint32_t *d_maxabs_bits, uint32_t *keys, uint32_t *vals);
 size_t sort_temp_bytes(uint32_t n);
-void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out,
+bool launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out,
                  uint32_t *vals_in, uint32_t *vals_out, uint32_t n);
 // mesh_records: the records hold the three corners as given (v0, sorted id | v1, 0 | v2, 0) instead of v0 / e1 / e2 / NgC
 // of the transformed triangle -- the per-geometry hierarchies of the instanced mode, built once in mesh space
@@ -272,7 +272,7 @@ uint32_t project_tris_per_wave(uint32_t ntris);   // 64 for big meshes, fewer fo
 uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs);   // survivor-list words for the geometries with bounds (0: none, or too many for one launch)
 // one-off per topology: Morton order of the triangles (centroids in mesh space) -> perm (sorted position -> triangle),
 // idx_sorted; scratch: keys_a/keys_b/vals_a (ntris words each), aabb (6 words), sort temp
-void launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,
+bool launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,
                        uint32_t *aabb6, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, void *sort_temp, size_t sort_temp_bytes,
                        uint32_t *perm, uint32_t *idx_sorted);
 // per vertex upload: mesh-space sheared-box bound of every kCullGroup sorted triangles (2 float4 per group), followed

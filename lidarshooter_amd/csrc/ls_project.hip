@@ -1497,19 +1497,21 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
     if (rider) launch_finish_pack(s, pp, *rider, stats);   // nothing was launched for it to ride with
 }
 
-void launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,
+bool launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,
                        uint32_t *aabb6, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, void *sort_temp, size_t sort_temp_bytes,
                        uint32_t *perm, uint32_t *idx_sorted)
 {
-    if (!ntris || !nverts) return;
+    if (!ntris || !nverts) return true;
+    if (!sort_temp || sort_temp_bytes < ls::sort_temp_bytes(ntris)) return false;   // (before anything is launched)
     (void)hipMemsetAsync(aabb6, 0xFF, 12, s);
     (void)hipMemsetAsync(aabb6 + 3, 0, 12, s);
     const uint32_t vgrid = std::min<uint32_t>((nverts + kBlock - 1) / kBlock, 256u);
     hipLaunchKernelGGL(k_mesh_aabb, dim3(vgrid), dim3(kBlock), 0, s, verts, stride, nverts, aabb6);
     const dim3 tgrid((ntris + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_mesh_morton, tgrid, dim3(kBlock), 0, s, verts, stride, idx, ntris, aabb6, keys_a, vals_a);
-    launch_sort(s, sort_temp, sort_temp_bytes, keys_a, keys_b, vals_a, perm, ntris);
+    if (!launch_sort(s, sort_temp, sort_temp_bytes, keys_a, keys_b, vals_a, perm, ntris)) return false;
     hipLaunchKernelGGL(k_permute_indices, tgrid, dim3(kBlock), 0, s, idx, perm, ntris, idx_sorted);
+    return true;
 }
 
 size_t project_box_entries(uint32_t ntris)

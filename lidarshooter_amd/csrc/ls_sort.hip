@@ -174,10 +174,13 @@ size_t sort_temp_bytes(uint32_t n)
 }
 
 // keys_in / vals_in are left as they are; the sorted pairs end in keys_out / vals_out (in -> temp -> out -> temp -> out)
-void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in,
+// false: the scratch is smaller than sort_temp_bytes(n) -- nothing was launched, keys_out / vals_out are NOT sorted (the
+// callers turn that into LS_ERR_OUT_OF_RANGE instead of building on garbage: ADVICE round 3)
+bool launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in,
                  uint32_t *vals_out, uint32_t n)
 {
-    if (!n || temp_bytes < sort_temp_bytes(n)) return;
+    if (!n) return true;
+    if (!temp || temp_bytes < sort_temp_bytes(n)) return false;
     uint32_t *tk = static_cast<uint32_t *>(temp), *tv = tk + n, *counts = tv + n;
     uint32_t *totals = counts + (size_t)kDigits * sort_tiles(n);
     const uint32_t rows = sort_rows(n), ntiles = sort_tiles(n);
@@ -191,6 +194,7 @@ void launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in
         ki = ko;
         vi = vo;
     }
+    return true;
 }
 
 }  // namespace ls

@@ -185,8 +185,11 @@ int ensure_host_buffers(ls_tracer *tr, size_t records)
     tr->h_points = nullptr;
     tr->h_hits = nullptr;
     tr->h_cap = 0;
-    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_points), records * 32));
-    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_hits), records * 16));
+    // explicitly coherent (fine-grained) and mapped: ls_trace_scene_begin / _expand read these while the stream is still
+    // running, ordered only by the progress words that follow the pack launches -- with HIP_HOST_COHERENT=0, or a runtime
+    // whose default is non-coherent host memory, a plain hipHostMalloc would not promise that
+    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_points), records * 32, hipHostMallocMapped | hipHostMallocCoherent));
+    LS_HIP(hipHostMalloc(reinterpret_cast<void **>(&tr->h_hits), records * 16, hipHostMallocMapped | hipHostMallocCoherent));
     tr->h_cap = records;
     return LS_OK;
 }
@@ -907,9 +910,16 @@ int ls_trace_scene_begin(ls_tracer *tr, uint32_t frame_index, uint32_t *n_points
     if (rc < 0) { tr->progress_active = false; return rc; }   // (-1: empty scene, zero points)
     if (tr->progress_active) {
         if (!wait_epoch(&tr->h_progress->total_epoch, tr->progress_epoch)) {
+            // five seconds without the word: a slow but healthy frame (first-launch code load, a debugger, a loaded box) or a
+            // lost one.  The stream is waited for; after that every word the frame writes is final: only a frame whose
+            // words are STILL missing is an error
             LS_HIP(hipStreamSynchronize(tr->stream));
-            tr->progress_active = false;
-            return fail(tr, LS_ERR_HIP, "the frame's hit count never reached the host");
+            int st;
+            if ((st = check_device_status(tr))) { tr->progress_active = false; return st; }
+            if (__atomic_load_n(&tr->h_progress->total_epoch, __ATOMIC_ACQUIRE) != tr->progress_epoch) {
+                tr->progress_active = false;
+                return fail(tr, LS_ERR_HIP, "the frame's hit count never reached the host");
+            }
         }
         tr->begin_points = __atomic_load_n(&tr->h_progress->total, __ATOMIC_RELAXED);
         tr->begin_first = tr->pack_split ? std::min(__atomic_load_n(&tr->h_progress->n_first, __ATOMIC_RELAXED), tr->begin_points) : 0u;
@@ -953,8 +963,12 @@ int ls_trace_scene_expand(ls_tracer *tr, void *dst_points32)
     pool_run(items_first + items_rest, work);
     if (!n && !wait_epoch(&hp->all_epoch, epoch)) ok.store(false);   // (nothing to expand: still the frame's end)
     if (!ok.load()) {
+        // (as in ls_trace_scene_begin: wait for the stream, then the words are final -- expand whatever a worker gave up on)
         LS_HIP(hipStreamSynchronize(tr->stream));
-        return fail(tr, LS_ERR_HIP, "the frame's progress words never reached the host");
+        int st;
+        if ((st = check_device_status(tr))) return st;
+        if (__atomic_load_n(&hp->all_epoch, __ATOMIC_ACQUIRE) != epoch) return fail(tr, LS_ERR_HIP, "the frame's progress words never reached the host");
+        if (n) expand_hits_range(dst, src, n, sin_theta, cos_theta, cs_phi, V, H);
     }
     return check_device_status(tr);
 }

@@ -208,6 +208,13 @@ def test_adapter_mesh_policies(adapterapi, oracle, sensors, meshes):
     tr.invalidateMesh("mesh")
     assert np.array_equal(frame(7), oracle.trace_frame(s, [(0, lifted, gt, A)])["points"])
     assert tr.uploadCounts() == (4, 4)
+    # an UNSTAMPED cloud (seq and stamp zero) cannot announce anything through its header: for those a 64-vertex sample is
+    # compared as a safety net -- an in-place edit of the whole cloud is seen without invalidateMesh()
+    tr.setVertices("mesh", gv, seq=0)                           # header 7 -> 0: upload
+    assert np.array_equal(frame(8), want_gv) and tr.uploadCounts() == (5, 4)
+    assert np.array_equal(frame(9), want_gv) and tr.uploadCounts() == (5, 5)
+    tr.setVertices("mesh", lifted, seq=0)                       # same buffer, same (empty) header, other bytes
+    assert np.array_equal(frame(10), oracle.trace_frame(s, [(0, lifted, gt, A)])["points"]) and tr.uploadCounts() == (6, 5)
     tr.close()
 
 
