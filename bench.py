@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 from lidarshooter_amd import capi, hostapi, shards, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r03"     # profiles/<tag>_<engine>_hbm.json: the rocprofv3 PMC summary this round's kernels were profiled into
+PROFILE_TAG = "r04"     # profiles/<tag>_<engine>_hbm.json: the rocprofv3 PMC summary this round's kernels were profiled into
 NODE_BYTES, TRI_BYTES, RAY_OUT_BYTES = 64, 48, 8  # DESIGN.md "algorithmic bytes" (BVH engine)
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 

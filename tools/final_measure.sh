@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, in one go (GPU box, repo root):  bash tools/final_measure.sh r03
-TAG=${1:-r03}
+# Everything profiles/ holds for a round, in one go (GPU box, repo root):  bash tools/final_measure.sh r04
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
 mkdir -p gpurun_out/final
@@ -15,9 +15,22 @@ for p in 0 1 2; do
   lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 2000 --warmup 200 --pipeline $p
 done > gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --mesh ground=tests/golden/data/mesh/ground.stl --mesh face=tests/golden/data/mesh/ben.stl --frames 5000 --warmup 200 --pipeline 1 >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
-for g in sharded interleaved; do
-  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 1000 --warmup 100 --ranks 1 --group $g
+# the group through a one-rank communicator: per-set communicators + one captured graph per frame (flags 0, the default), the
+# same without the graph (2), round 3's arrangement (1: one communicator on a collective stream, events); then interleaved
+for fl in 0 2 1; do
+  lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 2000 --warmup 200 --ranks 1 --group sharded --group-flags $fl
 done >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
+lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 2000 --warmup 200 --ranks 1 --group interleaved >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
+lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 2000 --warmup 200 --pipeline 2 --graph 1 >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
+# the N > 1 driver of bench.py on one GPU (every line of it: C group, one-rank communicator), and the host-cost micro-benchmark
+LS_BENCH_FORCE_GROUP=1 python bench.py --no-cpu-baseline --no-dropin > gpurun_out/final/bench_${TAG}_force_group.json 2>> gpurun_out/final/bench.err
+LS_BENCH_FORCE_GROUP=1 python bench.py --no-cpu-baseline --no-dropin --group-flags 1 > gpurun_out/final/bench_${TAG}_force_group_one_communicator.json 2>> gpurun_out/final/bench.err
+(cd tools/micro && ./graph_launch --rccl) > gpurun_out/final/${TAG}_graph_launch_micro.txt 2>&1
+(cd tools/micro && ./chunked_h2d) > gpurun_out/final/${TAG}_chunked_h2d_micro.txt 2>&1
+(cd tools/micro && ./loads_probe) > gpurun_out/final/${TAG}_loads_probe_micro.txt 2>&1
+# what ONE of eight ranks does per frame (no collective): kernel times of an eighth-of-a-turn shard, SYN-1M and SYN-10M
+python tools/shard_cost.py 2 1,8 > gpurun_out/final/${TAG}_shard_cost_1m.txt 2>> gpurun_out/final/bench.err
+W=syn128x10m python tools/shard_cost.py 2 1,8 > gpurun_out/final/${TAG}_shard_cost_10m.txt 2>> gpurun_out/final/bench.err
 python tools/dropin_bench.py 50 > gpurun_out/final/dropin_${TAG}.json 2>> gpurun_out/final/bench.err
 bash tools_profile.sh ${TAG} > gpurun_out/final/profile.log 2>&1
 python tools/prof_summary.py gpurun_out/prof_${TAG} gpurun_out/final/${TAG}_projection > gpurun_out/final/prof_summary.log 2>&1
