@@ -9,6 +9,8 @@
 //     S = 3   5 209 waves, 80 VGPRs + 28 bytes of scratch to fit one round                 25.1 us
 //     S = 4   3 907 waves, 98 VGPRs (4 waves per SIMD: one round)                          21.8 us
 //     64 consecutive triangles per set instead of eight spread runs: S = 2 / 4             24.6 / 38.5 us
+// and with THREE FRAMES IN FLIGHT (lsbench --pipeline 2, the headline's mode; k_project: 15.8 us per frame): S = 2 16.5 us,
+// S = 4 20.4 us per frame -- 40 % fewer instructions buy nothing there either: the overlapped frame is not issue-bound.
 // Ablation (S = 4 / S = 2): loads + band + compaction alone 10.9 / 10.6 us; + the dense pass without trips 15.7 / 14.2 us;
 // + trips 21.8 / 20.5 us.  The streaming half does not get shorter with fewer, fatter waves: the load phase is a throughput
 // (4.5 us whatever S, tools/micro/loads_probe.hip), and with four waves on a SIMD the band test's 680 dependent instructions
