@@ -173,3 +173,33 @@ def test_bench_two_ranks_rehearsal_without_a_launcher():
     assert rec["rccl"]["comm_ranks"] == 2 and rec["rccl"]["comm_ranks_on_every_rank"] == [2, 2]
     assert rec["rccl"]["launched_by"].startswith("bench.py itself")
     assert rec["rehearsal_gloo_shared_gpu"] is True
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_group_empty_scene_and_back(oracle, capi, sensors, meshes, flags):
+    """OptixTracer.cpp:263-288 through the group: a frame of an empty scene traces nothing (-1) and still travels -- an empty
+    slot is gathered, the cloud holds zero points -- in the per-set arrangement (where that frame is plain work on the set's
+    stream, outside the cached graph) and in the one-communicator one; geometry added afterwards, frames are clouds again."""
+    from lidarshooter_amd import groupapi
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, "projection")
+    g = groupapi.Group(tr, 1, 0, groupapi.SHARDED, flags=flags)
+    for f in range(4):
+        assert tr.commitScene() == -1
+        assert g.trace(f) == -1
+    pts, hits = g.download(3)
+    assert pts.shape[0] == 0 and hits.shape[0] == 0
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    for f in range(4, 9):
+        assert tr.commitScene() == 0 and g.trace(f) == 0
+    for f in (6, 7, 8):
+        pts, hits = g.download(f)
+        assert pts.shape[0] == 1668 and np.array_equal(pts, ref["points"]) and np.array_equal(hits, ref["hits"])   # EmbreeTracer_test.cpp:122-135
+    assert tr.removeGeometry("ground") == 0
+    assert g.trace(9) == -1
+    pts, _ = g.download(9)
+    assert pts.shape[0] == 0
+    g.close()
+    tr.close()
