@@ -369,7 +369,12 @@ uint64_t frame_signature(const ls_tracer *tr, const std::vector<ls::GeomSource> 
 int frame_graph_open(ls_tracer *tr, uint32_t slot, hipStream_t s, uint64_t sig)
 {
     FrameGraph &fg = tr->fgraph[slot];
-    if (fg.exec && fg.sig != sig) frame_graph_free(fg);
+    if (fg.exec && fg.sig != sig) {
+        // another launch sequence: the cached graph goes -- once its last launch on this stream has finished (rare: a changed
+        // geometry set, culling switched, a caller's bracket that comes or goes)
+        LS_HIP(hipStreamSynchronize(s));
+        frame_graph_free(fg);
+    }
     ls::LaunchSink &sk = tr->fg_sink;
     sk.n = 0;
     sk.stream = s;
@@ -435,6 +440,7 @@ bool same_launch(const ls::LaunchRecord &a, const ls::LaunchRecord &b)
 // the frame graph is given up for this frame (and, when `broken`, for good): nothing was launched, the rotation steps back
 int frame_graph_discard(ls_tracer *tr, FrameGraph &fg, bool broken)
 {
+    if (fg.exec) (void)hipStreamSynchronize(tr->fg_sink.stream);   // (an earlier launch of it may still be running)
     frame_graph_free(fg);
     if (broken) tr->fg_broken = true;
     if (tr->ms_seq) --tr->ms_seq;   // (trace_once counted the frame when its launches were recorded)

@@ -22,6 +22,7 @@ t0 = time.time(); frames = 0; checked = 0
 while time.time() - t0 < budget:
     mode = int(rng.integers(0, 3))
     tr.setOption(capi.LS_OPT_PIPELINE, mode)
+    tr.setOption(capi.LS_OPT_FRAME_GRAPH, int(rng.integers(0, 2)))   # (three-stream mode: frames as captured graphs, poses patched in)
     for k in range(200):
         A = O.affine_from_components(rng.uniform(-3, 3, 3).astype(np.float32), rng.uniform(-0.5, 0.5, 3).astype(np.float32))
         tr.updateGeometryTransform("face", A)
@@ -37,5 +38,7 @@ while time.time() - t0 < budget:
     if checked % 200 == 0:
         ref = O.trace_frame(s, [(0, *ground, O.IDENTITY_AFFINE), (1, *ben, A)])
         assert np.array_equal(pts, ref["points"])
+print("frame graphs: captured %d, replayed %d, nodes patched %d" % (tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES), tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS),
+                                                                     tr.info(capi.LS_INFO_FRAME_GRAPH_PATCHES)))
 tr.synchronize(); tr.close()
 print("soak ok: %d frames, %d compared with the one-step call, %.0f s" % (frames, checked, time.time() - t0))
