@@ -67,6 +67,17 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
  *   LS_GROUP_FLAG_NO_GRAPH          per-set mode without LS_OPT_FRAME_GRAPH: five plain enqueues per frame on one stream */
 #define LS_GROUP_FLAG_ONE_COMMUNICATOR 1u
 #define LS_GROUP_FLAG_NO_GRAPH 2u
+/*   LS_GROUP_FLAG_SIZED_GATHER      (per-set mode) the all-gather moves the FRONT of every slot only -- the header and as many
+ *                                   records as the set's previous frame, three frames ago, needed on its largest rank, plus a
+ *                                   quarter, in steps of capacity / 16 -- instead of the whole fixed-capacity slot: at the
+ *                                   headline half of a slot is padding.  The size comes out of the gathered headers, so it is
+ *                                   the same number on every rank; the host waits for that frame's rebuild before it enqueues
+ *                                   the set's next frame (at most three frames in flight either way), and a change of size
+ *                                   captures the set's graph anew.  A frame whose hits outgrow the headroom within three frames
+ *                                   is truncated on every rank alike: ls_group_download_cloud returns LS_ERR_OUT_OF_RANGE for it
+ *                                   (ls_group_info: LS_GROUP_INFO_TRUNCATED_FRAMES), never a short cloud as if it were complete.
+ *                                   Off by default: the fixed slots are latency-bound at 1 M triangles. */
+#define LS_GROUP_FLAG_SIZED_GATHER 4u
 int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, uint32_t flags, ls_tracer *tr,
                          ls_group **out);
 void ls_group_destroy(ls_group *g);
@@ -90,6 +101,8 @@ int ls_group_synchronize(ls_group *g);
 #define LS_GROUP_INFO_COMMUNICATORS 4  /* 3 in per-set mode, 1 otherwise, 0 when INTERLEAVED                      */
 #define LS_GROUP_INFO_PER_SET 5        /* 1: per-set mode (see the top of this header)                            */
 #define LS_GROUP_INFO_FRAME_GRAPH 6    /* the tracer's LS_INFO_FRAME_GRAPH_STATE: 0 off, 1 frames are graph launches, 2 refused */
+#define LS_GROUP_INFO_GATHER_CAPACITY 7   /* records of every slot that travel per frame now (the slot capacity unless SIZED_GATHER) */
+#define LS_GROUP_INFO_TRUNCATED_FRAMES 8  /* SIZED_GATHER: frames seen so far whose hits outgrew the gather                           */
 long ls_group_info(ls_group *g, int what);
 const char *ls_group_last_error(const ls_group *g);
 

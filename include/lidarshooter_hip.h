@@ -235,6 +235,13 @@ int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t worl
  * gather without holding up the tracer's stream (include/lidarshooter_group.h does this). */
 int ls_expand_gathered_hits_on(ls_tracer *tr, void *hip_stream, const void *d_gathered, uint32_t world, uint32_t capacity,
                                void *d_points32, void *d_hits, uint32_t *d_n_points);
+/* The sized gather's form (include/lidarshooter_group.h, LS_GROUP_FLAG_SIZED_GATHER): only the FRONT of every slot travelled --
+ * the header with the rank's true count and the first gathered_capacity records; the `world` pieces lie 64 + 16 *
+ * gathered_capacity bytes apart.  The cloud is rebuilt from the records that are there, and 64 bytes of pinned host memory
+ * (host_stat64; may be NULL) receive { u32 largest true count of any rank, u32 truncated (some rank had more hits than
+ * travelled), u32 epoch (released last) }. */
+int ls_expand_gathered_hits_sized(ls_tracer *tr, void *hip_stream, const void *d_gathered, uint32_t world, uint32_t gathered_capacity,
+                                  void *d_points32, void *d_hits, uint32_t *d_n_points, void *host_stat64, uint32_t epoch);
 
 /* The step after the tracer: the sensor-frame cloud into the world frame, on the
  * device.  Replaces CloudTransformer::applyInverseTransform (CloudTransformer.cpp:283-318) +

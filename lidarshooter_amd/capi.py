@@ -44,7 +44,7 @@ SYMBOLS = (
     "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type", "ls_tracer_order_after_last_frame", "ls_tracer_wait_event", "ls_tracer_next_frame_waits", "ls_trace_scene_begin", "ls_trace_scene_expand",
     "ls_frame_graph_begin", "ls_frame_graph_stream", "ls_frame_graph_end", "ls_frame_graph_reset",
-    "ls_tracer_set_sensor", "ls_tracer_set_sensor_tables",
+    "ls_tracer_set_sensor", "ls_tracer_set_sensor_tables", "ls_expand_gathered_hits_sized",
 )
 # include/lidarshooter_hip_debug.h: test / measurement hooks (not part of the drop-in surface)
 DEBUG_SYMBOLS = ("ls_debug_dense_hits", "ls_debug_trace_bruteforce", "ls_debug_scene_size", "ls_debug_download_scene",

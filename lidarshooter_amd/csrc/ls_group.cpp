@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -67,6 +68,12 @@ Rccl &rccl()
 
 constexpr int kSets = 3;
 
+// what ls_expand_gathered_hits_sized leaves in pinned host memory (ls_kernels.h: GatherStat)
+struct GatherStat {
+    uint32_t max_count, truncated, epoch, pad[13];
+};
+static_assert(sizeof(GatherStat) == 64, "one line");
+
 }  // namespace
 
 struct ls_group {
@@ -85,6 +92,13 @@ struct ls_group {
     uint32_t set_frame[kSets] = {};        // which frame each set holds
     bool set_valid[kSets] = {};
     hipStream_t loose[kSets] = {};         // per-set mode: a stream with work the tracer's flush does not know of (empty-scene frames)
+    // LS_GROUP_FLAG_SIZED_GATHER: the gather moves the front of every slot -- header + gcap records -- sized from what the
+    // set's previous tenant needed (the same number on every rank: it comes out of the gathered headers)
+    bool sized = false;
+    uint32_t gcap = 0, gstep = 0;          // records that travel per slot now; the granularity of that number
+    GatherStat *h_stat[kSets] = {};        // pinned: written by the rebuild of the set's frame
+    bool stat_pending[kSets] = {};         // the set's frame will write its stat (nobody has read it yet)
+    unsigned long long truncated_frames = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_collected[kSets] = {};
     bool used[kSets] = {};
@@ -197,6 +211,8 @@ void ls_group_destroy(ls_group *g)
         (void)hipFree(g->cloud_hits[i]);
         (void)hipFree(g->cloud_n[i]);
     }
+    for (GatherStat *&st : g->h_stat)
+        if (st) { (void)hipHostFree(st); st = nullptr; }
     (void)hipFree(g->local_points);
     if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
     delete g;
@@ -313,6 +329,16 @@ int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, ui
     // (every rank has the same device and library, so every rank arrives at the same answer here)
     const bool three_streams = ls_get_info(tr, LS_INFO_PIPELINE_MODE) == 2;
     g->per_set = g->per_set && three_streams;
+    if (g->per_set && (flags & LS_GROUP_FLAG_SIZED_GATHER)) {
+        g->sized = true;
+        g->gcap = g->capacity;                                   // until a frame has said what it needs
+        g->gstep = std::max(1u, (g->capacity + 15u) / 16u);
+        for (int i = 0; i < kSets; ++i) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&g->h_stat[i]), sizeof(GatherStat), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+                return bail(LS_ERR_HIP);
+            std::memset(g->h_stat[i], 0, sizeof(GatherStat));
+        }
+    }
     if (three_streams && (g->per_set || mode == LS_GROUP_INTERLEAVED)) {   // frames as graph launches (INTERLEAVED: the three launches of a frame)
         g->frame_graph_before = std::max(0l, ls_get_info(tr, LS_INFO_FRAME_GRAPH_STATE)) ? 1 : 0;
         g->frame_graph_set = true;
@@ -326,6 +352,48 @@ int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, ui
 }
 
 namespace {
+// The stat of the frame that holds set b, once its rebuild has written it: -> truncated (1 / 0), *need = the largest rank's
+// count; negative on error.  wait: spin for it (the frame is at most three frames old), then the whole group is waited for.
+int read_stat(ls_group *g, int b, bool wait, uint32_t *need)
+{
+    GatherStat *st = g->h_stat[b];
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; __atomic_load_n(&st->epoch, __ATOMIC_ACQUIRE) != 1u; ++spins) {
+        if (!wait) return -1000;   // (not there yet)
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            const int rc = ls_group_synchronize(g);   // a slow but healthy frame: after this its word is final
+            if (rc != LS_OK) return rc;
+            if (__atomic_load_n(&st->epoch, __ATOMIC_ACQUIRE) != 1u) return fail(g, LS_ERR_HIP, "a frame's gather statistics never reached the host");
+        }
+    }
+    if (need) *need = st->max_count;
+    return st->truncated ? 1 : 0;
+}
+
+// LS_GROUP_FLAG_SIZED_GATHER, before set b's next frame is enqueued: how many records of every slot travel.  The set's
+// previous tenant -- three frames ago -- says how many hits the largest shard had (its rebuild left that in pinned memory;
+// the gathered headers it comes from are the same on every rank, so every rank arrives at the same number and the
+// collectives' sizes agree); a quarter of headroom on top, in steps of capacity / 16, growing at once and shrinking only
+// past two steps (every change of size captures the set's graph anew).  A frame whose hits outgrow the headroom within
+// three frames is TRUNCATED on every rank alike: ls_group_download_cloud reports it (LS_ERR_OUT_OF_RANGE), the next frames
+// are sized up; it is never delivered as complete.
+int size_gather(ls_group *g, int b)
+{
+    if (!g->stat_pending[b]) return LS_OK;   // (no tenant yet: the full capacity travels)
+    uint32_t need = 0;
+    const int t = read_stat(g, b, true, &need);
+    if (t < 0) return t;
+    if (t == 1) ++g->truncated_frames;
+    g->stat_pending[b] = false;
+    __atomic_store_n(&g->h_stat[b]->epoch, 0u, __ATOMIC_RELEASE);   // (the next tenant's rebuild writes 1 again: a constant, so a replayed graph needs no patch)
+    const unsigned long long want = (unsigned long long)need + need / 4u + 1024u;
+    uint32_t target = (uint32_t)std::min<unsigned long long>(g->capacity, (want + g->gstep - 1u) / g->gstep * g->gstep);
+    target = std::max(target, std::min(g->gstep, g->capacity));
+    if (target > g->gcap || target + 2u * g->gstep <= g->gcap) g->gcap = target;
+    return LS_OK;
+}
+
 // Per-set mode, one SHARDED frame: the set is the tracer's next slot, so that the frame's launches, its gather (this set's
 // communicator) and the rebuild of the cloud are consecutive work on ONE stream -- no event, no cross-stream wait -- and,
 // with LS_OPT_FRAME_GRAPH, one captured graph per set that every later frame of the set replays with a single
@@ -337,10 +405,15 @@ int trace_per_set(ls_group *g, uint32_t frame_index)
         const long nb = ls_get_info(g->tr, LS_INFO_NEXT_SLOT);
         if (nb < 0 || nb >= kSets) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
         const int b = (int)nb;
+        if (g->sized && attempt == 0) {
+            const int rc_size = size_gather(g, b);
+            if (rc_size != LS_OK) return rc_size;
+        }
         if (ls_tracer_set_output_buffers(g->tr, g->local_points, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]),
                                          g->capacity) != LS_OK)
             return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
-        if (ls_frame_graph_begin(g->tr, reinterpret_cast<uintptr_t>(g)) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
+        // (the tag names what the caller adds to the graph: this group, and how many bytes its collective moves)
+        if (ls_frame_graph_begin(g->tr, reinterpret_cast<uintptr_t>(g) + (g->sized ? g->gcap : 0u)) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
         ls_frame f;
         const int rc = ls_trace_scene_async(g->tr, frame_index, &f);
         if (rc < -1) {
@@ -364,15 +437,20 @@ int trace_per_set(ls_group *g, uint32_t frame_index)
         }
         ncclComm_t comm = b == 0 ? g->comm : g->comm_dup[b - 1];
         // (replaying: the gather is a node of the graph already; only this library's launches are described again)
+        const size_t gather_bytes = g->sized ? (size_t)ls_group_slot_bytes(g->gcap) : g->slot_bytes;
         if (mode != LS_FRAME_REPLAYING) {
-            const ncclResult_t r = rccl().AllGather(g->slot[b], g->gathered[b], g->slot_bytes, ncclUint8, comm, s);
+            const ncclResult_t r = rccl().AllGather(g->slot[b], g->gathered[b], gather_bytes, ncclUint8, comm, s);
             if (r != ncclSuccess) {
                 (void)ls_frame_graph_end(g->tr);   // (a capture that holds a failed collective is not worth keeping either)
                 (void)ls_frame_graph_reset(g->tr);
                 return fail(g, LS_ERR_HIP, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
             }
         }
-        if (ls_expand_gathered_hits_on(g->tr, s, g->gathered[b], g->world, g->capacity, g->cloud_points[b], g->cloud_hits[b], g->cloud_n[b]) != LS_OK) {
+        const int erc = g->sized ? ls_expand_gathered_hits_sized(g->tr, s, g->gathered[b], g->world, g->gcap, g->cloud_points[b], g->cloud_hits[b],
+                                                                g->cloud_n[b], g->h_stat[b], 1u)
+                                 : ls_expand_gathered_hits_on(g->tr, s, g->gathered[b], g->world, g->capacity, g->cloud_points[b], g->cloud_hits[b],
+                                                              g->cloud_n[b]);
+        if (erc != LS_OK) {
             (void)ls_frame_graph_end(g->tr);
             return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
         }
@@ -382,6 +460,7 @@ int trace_per_set(ls_group *g, uint32_t frame_index)
         if (off_rotation) LSG_HIP(hipStreamSynchronize(s));
         g->set_frame[b] = frame_index;
         g->set_valid[b] = true;
+        g->stat_pending[b] = g->sized;
         return rc == -1 ? -1 : 0;
     }
     return fail(g, LS_ERR_HIP, "the frame graph was discarded twice in a row");
@@ -459,6 +538,11 @@ long ls_group_download_cloud(ls_group *g, uint32_t frame_index, void *points32, 
     int rc = ls_group_cloud(g, frame_index, &f);
     if (rc != LS_OK) return rc;
     if ((rc = ls_group_synchronize(g)) != LS_OK) return rc;
+    if (g->sized) {
+        for (int i = 0; i < kSets; ++i)
+            if (g->set_valid[i] && g->set_frame[i] == frame_index && g->stat_pending[i] && read_stat(g, i, false, nullptr) == 1)
+                return fail(g, LS_ERR_OUT_OF_RANGE, "that frame's hits outgrew the sized gather: its cloud is incomplete (the following frames are sized up)");
+    }
     uint32_t n = 0;
     LSG_HIP(hipMemcpy(&n, f.d_n_points, 4, hipMemcpyDeviceToHost));
     if (n > capacity) return fail(g, LS_ERR_OUT_OF_RANGE, "host buffers smaller than the cloud");
@@ -490,6 +574,8 @@ long ls_group_info(ls_group *g, int what)
     case LS_GROUP_INFO_COMMUNICATORS: return g->comm ? (g->per_set ? kSets : 1) : 0;
     case LS_GROUP_INFO_PER_SET: return g->per_set ? 1 : 0;
     case LS_GROUP_INFO_FRAME_GRAPH: return g->tr ? ls_get_info(g->tr, LS_INFO_FRAME_GRAPH_STATE) : 0;
+    case LS_GROUP_INFO_GATHER_CAPACITY: return g->sized ? (long)g->gcap : (long)g->capacity;
+    case LS_GROUP_INFO_TRUNCATED_FRAMES: return (long)g->truncated_frames;
     default: return fail(g, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }

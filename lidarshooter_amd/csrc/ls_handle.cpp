@@ -534,6 +534,20 @@ int ls_expand_gathered_hits_on(ls_tracer *tr, void *hip_stream, const void *d_ga
     return LS_OK;
 }
 
+int ls_expand_gathered_hits_sized(ls_tracer *tr, void *hip_stream, const void *d_gathered, uint32_t world, uint32_t gathered_capacity,
+                                  void *d_points32, void *d_hits, uint32_t *d_n_points, void *host_stat64, uint32_t epoch)
+{
+    LS_ENTER(tr);
+    if (!d_gathered || !d_points32 || !d_hits || !d_n_points || !world || !gathered_capacity)
+        return fail(tr, LS_ERR_INVALID_ARGUMENT, "null argument");
+    static_assert(sizeof(ls::GatherStat) == 64, "one line of pinned host memory");
+    ls::launch_expand_slots(hip_stream ? static_cast<hipStream_t>(hip_stream) : tr->stream, tables(tr),
+                            static_cast<const uint32_t *>(d_gathered), world, gathered_capacity, 16u + 4u * gathered_capacity,
+                            static_cast<uint8_t *>(d_points32), d_hits, d_n_points, static_cast<ls::GatherStat *>(host_stat64), epoch);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
 int ls_expand_gathered_hits(ls_tracer *tr, const void *d_gathered, uint32_t world, uint32_t capacity, void *d_points32,
                             void *d_hits, uint32_t *d_n_points)
 {

@@ -294,8 +294,16 @@ void launch_cloud_to_world(hipStream_t s, const Affine &m, const void *in, const
 // dense per-ray (t, global triangle id) arrays rebuilt from the packed hit records (debug view)
 void launch_dense_from_hits(hipStream_t s, const SensorTables &tb, const void *hits, const uint32_t *n_points,
                             const GeomTable &gt, float *t, uint32_t *gid);
+// what a rebuild of gathered slots tells the host (pinned memory; the sized gather of include/lidarshooter_group.h)
+struct GatherStat {
+    uint32_t max_count;   // the largest rank's true hit count of the frame
+    uint32_t truncated;   // 1: some rank had more hits than travelled -- the frame's cloud is incomplete
+    uint32_t epoch;       // the caller's tag, released last
+    uint32_t pad[13];
+};
 void launch_expand_slots(hipStream_t s, const SensorTables &tb, const uint32_t *gathered, uint32_t world, uint32_t cap,
-                         uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points);
+                         uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points, GatherStat *stat = nullptr,
+                         uint32_t epoch = 0);
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz);
 // the reference's own buffers (LidarDeviceKernels.cu:38-51): Ray 32 B, Hit 24 B per ray; either may be nullptr
 void launch_raygen_aos(hipStream_t s, const SensorTables &tb, void *rays32, void *hits24);

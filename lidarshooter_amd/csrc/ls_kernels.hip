@@ -1069,18 +1069,28 @@ __global__ __launch_bounds__(kBlock) void k_cloud_to_world(Affine m /* a = A, ri
 __global__ __launch_bounds__(kBlock) void k_expand_slots(SensorTables tb, const uint32_t *__restrict__ gathered,
                                                          uint32_t world, uint32_t cap, uint32_t slot_words,
                                                          float4 *__restrict__ points, uint4 *__restrict__ hits,
-                                                         uint32_t *__restrict__ n_points)
+                                                         uint32_t *__restrict__ n_points, GatherStat *__restrict__ stat, uint32_t epoch)
 {
+    // cap: records that TRAVELLED per slot (the sized gather moves the front of a slot: its header holds the rank's true
+    // count, its records beyond cap stayed behind -- such a frame is reported as truncated, never delivered as complete)
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= world * cap) return;
     const uint32_t r = i / cap, j = i - r * cap;
-    uint32_t off = 0, total = 0;
+    uint32_t off = 0, total = 0, most = 0;
     for (uint32_t k = 0; k < world; ++k) {
-        const uint32_t c = min(gathered[(size_t)k * slot_words], cap);
+        const uint32_t c_true = gathered[(size_t)k * slot_words], c = min(c_true, cap);
         if (k < r) off += c;
         total += c;
+        most = max(most, c_true);
     }
-    if (i == 0) *n_points = total;
+    if (i == 0) {
+        *n_points = total;
+        if (stat) {   // pinned host memory: what the host sizes the next gathers from, and whether this one was big enough
+            stat->max_count = most;
+            stat->truncated = most > cap ? 1u : 0u;
+            __hip_atomic_store(&stat->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (j >= min(gathered[(size_t)r * slot_words], cap)) return;
     const uint4 rec = reinterpret_cast<const uint4 *>(gathered + (size_t)r * slot_words + 16)[j];
     const uint32_t v = rec.x / tb.H, h = rec.x - v * tb.H;
@@ -1374,11 +1384,11 @@ void launch_dense_from_hits(hipStream_t s, const SensorTables &tb, const void *h
 }
 
 void launch_expand_slots(hipStream_t s, const SensorTables &tb, const uint32_t *gathered, uint32_t world, uint32_t cap,
-                         uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points)
+                         uint32_t slot_words, uint8_t *points32, void *hits, uint32_t *n_points, GatherStat *stat, uint32_t epoch)
 {
     if (!world || !cap) return;
     launch_k(k_expand_slots, dim3(blocks_for(world * cap)), dim3(kBlock), 0, s, tb, gathered, world, cap,
-             slot_words, reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points);
+             slot_words, reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points, stat, epoch);
 }
 
 void launch_raygen(hipStream_t s, const SensorTables &tb, float *dx, float *dy, float *dz)

@@ -17,8 +17,9 @@ SYMBOLS = ("ls_group_shard_columns", "ls_group_slot_capacity", "ls_group_slot_by
            "ls_group_decode_gathered", "ls_group_unique_id", "ls_group_create", "ls_group_destroy", "ls_group_trace",
            "ls_group_owns_frame", "ls_group_cloud", "ls_group_download_cloud", "ls_group_synchronize", "ls_group_last_error",
            "ls_group_create_opts", "ls_group_info")
-FLAG_ONE_COMMUNICATOR, FLAG_NO_GRAPH = 1, 2
+FLAG_ONE_COMMUNICATOR, FLAG_NO_GRAPH, FLAG_SIZED_GATHER = 1, 2, 4
 INFO_RCCL_VERSION, INFO_COMM_RANKS, INFO_COMM_DEVICE, INFO_COMMUNICATORS, INFO_PER_SET, INFO_FRAME_GRAPH = 1, 2, 3, 4, 5, 6
+INFO_GATHER_CAPACITY, INFO_TRUNCATED_FRAMES = 7, 8
 _lib = None
 
 

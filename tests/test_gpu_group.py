@@ -203,3 +203,50 @@ def test_group_empty_scene_and_back(oracle, capi, sensors, meshes, flags):
     assert pts.shape[0] == 0
     g.close()
     tr.close()
+
+
+def test_group_sized_gather(oracle, capi, sensors, meshes):
+    """LS_GROUP_FLAG_SIZED_GATHER on a one-rank communicator: after three frames the gather moves the front of the slot only
+    (what the set's previous frame needed + a quarter, in steps of capacity / 16), the clouds stay the oracle's; when the scene
+    suddenly has more hits than travel, those frames are REPORTED as truncated -- never delivered short -- and the frames that
+    follow are sized up again."""
+    from lidarshooter_amd import groupapi
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, "projection")
+    tr.addGeometry("face", *[a.shape[0] for a in meshes["ben"]])
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, *meshes["ben"])
+    g = groupapi.Group(tr, 1, 0, groupapi.SHARDED, flags=groupapi.FLAG_SIZED_GATHER)
+    if not g.info(groupapi.INFO_PER_SET):
+        g.close(); tr.close()
+        pytest.skip("fewer than three concurrent streams on this device")
+    cap = s.V * s.H
+    step = (cap + 15) // 16
+    assert g.info(groupapi.INFO_GATHER_CAPACITY) == cap
+    few = oracle.trace_frame(s, [(0, *meshes["ben"], oracle.IDENTITY_AFFINE)])
+    n_few = few["points"].shape[0]
+    assert 0 < n_few < 400
+    for f in range(8):
+        assert tr.commitScene() == 0 and g.trace(f) == 0
+    small = g.info(groupapi.INFO_GATHER_CAPACITY)
+    assert small == -(-(n_few + n_few // 4 + 1024) // step) * step < cap     # sized from the frames before
+    for f in (5, 6, 7):
+        pts, hits = g.download(f)
+        assert np.array_equal(pts, few["points"]) and np.array_equal(hits, few["hits"])
+    assert tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES) >= 6                   # the change of size captured the three graphs anew
+    # ---- the ground appears: 1 668 + hits, more than the 1 200-odd records that travel
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    both = oracle.trace_frame(s, [(0, *meshes["ben"], oracle.IDENTITY_AFFINE), (1, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    assert both["points"].shape[0] > small
+    assert tr.commitScene() == 0 and g.trace(8) == 0
+    with pytest.raises(capi.LidarShooterHipError, match="outgrew"):
+        g.download(8)
+    for f in range(9, 16):
+        assert tr.commitScene() == 0 and g.trace(f) == 0
+    assert g.info(groupapi.INFO_TRUNCATED_FRAMES) >= 3                        # frames 8 .. 10 were sized from frames 5 .. 7
+    assert g.info(groupapi.INFO_GATHER_CAPACITY) >= both["points"].shape[0]
+    for f in (13, 14, 15):
+        pts, hits = g.download(f)
+        assert np.array_equal(pts, both["points"]) and np.array_equal(hits, both["hits"])
+    g.close()
+    tr.close()
