@@ -42,6 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROFILE_TAG = "r04"     # profiles/<tag>_<engine>_hbm.json: the rocprofv3 PMC summary this round's kernels were profiled into
 NODE_BYTES, TRI_BYTES, RAY_OUT_BYTES = 64, 48, 8  # DESIGN.md "algorithmic bytes" (BVH engine)
 DATA = os.path.join(ROOT, "tests", "golden", "data")
+HOST_NUMA = None
 
 
 def parse_args():
@@ -123,6 +124,41 @@ def _affine(lin, ang):
     rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], np.float32)
     m = (rz @ ry @ rx).astype(np.float32)
     return np.concatenate([m, np.asarray(lin, np.float32).reshape(3, 1)], axis=1).reshape(12)
+
+
+def pin_to_gpu_numa_node(dev_index: int):
+    """The frame loop is a host thread that writes packets and doorbells to ONE GPU: on a two-socket host (the pool's boxes: 2 x
+    EPYC 9575F, the cgroup grants 16 CPUs' worth of time anywhere on 256) the scheduler puts it on either socket, and from
+    far one -- or on CPUs it shares with the box's other tenants -- a frame's three launches have been seen to cost 13.7 us of
+    host time instead of 8.3 - 10.6, enough for the three streams to run dry between frames: 18.3 - 18.7 us per frame instead
+    of 16 - 17 (the process-to-process spread of rounds 2 - 4; lsbench and tools/variance_probe.py, which
+    keep the GPU's queues thousands of frames deep, never show it).  So the process is confined to the CPUs of the GPU's own NUMA
+    node, as numactl would: 8 of 8 processes at 16.2 - 16.9 us against 3 of 6 above 18.3 without.  Returns what it did."""
+    try:
+        # the device's PCI address from the HIP runtime (does not initialise more than torch already has), then sysfs
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        node = None
+        try:
+            hip = ctypes.CDLL("libamdhip64.so.7")   # (by soname: the runtime torch has loaded already, never a second copy)
+            if hip.hipDeviceGetPCIBusId(buf, 64, dev_index) == 0:
+                v = int(open(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/numa_node").read().strip())
+                node = v if v >= 0 else None
+        except Exception:
+            node = None
+        if node is None:
+            return {"pinned": False, "why": "no numa_node for the GPU in sysfs"}
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if not cpus:
+            return {"pinned": False, "why": "the GPU's node has no CPU this process may run on", "node": node}
+        os.sched_setaffinity(0, cpus)
+        return {"pinned": True, "node": node, "cpus": len(cpus)}
+    except Exception as e:   # never in the way of the measurement
+        return {"pinned": False, "why": repr(e)}
 
 
 def kernel_source_sha() -> str:
@@ -348,6 +384,8 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    global HOST_NUMA
+    HOST_NUMA = pin_to_gpu_numa_node(dev_index) if os.environ.get("LS_BENCH_NO_PIN") != "1" else {"pinned": False, "why": "LS_BENCH_NO_PIN=1"}
     if world > 1:
         if rehearsal:
             dist.init_process_group("gloo")
@@ -446,6 +484,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         set_out(0)
         count_words = out_bufs
         if pipeline:
+            torch.cuda.synchronize(device)   # (the handle times candidate streams against each other here: nothing of torch's may be running)
             tr.setOption(capi.LS_OPT_PIPELINE, args.pipeline)
             if args.frame_graph:
                 tr.setOption(capi.LS_OPT_FRAME_GRAPH, 1)
@@ -702,6 +741,15 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
     # ---- the timed region: windows of exactly K frames, each bracketed by barrier + synchronize, no instrumentation
     #      inside (hipEvent records would put barrier packets between the kernels).  Whatever --steps says, windows
     #      are repeated until at least --min-ms have been timed; the reported step time is the MEDIAN window's.
+    def window_sync():
+        # single GPU: the device-wide wait the contract asks for covers the three streams the frames rotate over by itself; the
+        # handle's flush (three event records + three waits, ~15 us of host calls that order its own stream behind them) is not
+        # part of a frame and is left to the first call that needs the handle's stream ordered (sync() does it outside the windows)
+        if single:
+            torch.cuda.synchronize(device)
+        else:
+            sync()
+
     def window():
         sync()
         t0 = time.perf_counter()
@@ -711,7 +759,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
             for i in range(args.steps):
                 frame(i)
         enq = time.perf_counter() - t0           # host time to enqueue K frames (diagnostic: host- or GPU-bound?)
-        sync()
+        window_sync()
         el = time.perf_counter() - t0
         if world > 1:
             e = torch.tensor([el], dtype=torch.float64, device=device)
@@ -986,6 +1034,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         "gathered_points_rank0": None if single else (int(grp.download(args.steps - 1)[0].shape[0]) if cgroup else int(cloud_n[0].item())),
         "rehearsal_gloo_shared_gpu": True if rehearsal else None,
         "rccl": rccl_out,
+        "host_numa": HOST_NUMA,
         "frame_graph": {"state": tr.info(capi.LS_INFO_FRAME_GRAPH_STATE), "captures": tr.info(capi.LS_INFO_FRAME_GRAPH_CAPTURES),
                         "replays": tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS), "patches": tr.info(capi.LS_INFO_FRAME_GRAPH_PATCHES)},
         "roofline": dict({

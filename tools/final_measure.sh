@@ -16,8 +16,8 @@ for p in 0 1 2; do
 done > gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --mesh ground=tests/golden/data/mesh/ground.stl --mesh face=tests/golden/data/mesh/ben.stl --frames 5000 --warmup 200 --pipeline 1 >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 # the group through a one-rank communicator: per-set communicators + one captured graph per frame (flags 0, the default), the
-# same without the graph (2), round 3's arrangement (1: one communicator on a collective stream, events); then interleaved
-for fl in 0 2 1; do
+# same without the graph (2), round 3's arrangement (1: one communicator on a collective stream, events), the sized gather (4); then interleaved
+for fl in 0 2 1 4; do
   lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 2000 --warmup 200 --ranks 1 --group sharded --group-flags $fl
 done >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err
 lidarshooter_amd/lsbench --config tests/golden/data/config/hesai-pandar-XT-32-lidar_0000.json --syn 128 4096 --mesh-raw ground=/tmp/syn1m.lsmesh --frames 2000 --warmup 200 --ranks 1 --group interleaved >> gpurun_out/final/lsbench_${TAG}.jsonl 2>> gpurun_out/final/bench.err

@@ -4,6 +4,9 @@ times for the spread across processes.  usage: variance_probe.py [handles per pr
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("PROBE_PRELOAD") == "1":   # the library (and with it /opt/rocm's HIP runtime) before torch brings its own copy
+    from lidarshooter_amd import capi as _c
+    _c.load()
 import numpy as np, torch
 from lidarshooter_amd import capi, hostapi
 import bench
@@ -11,6 +14,9 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 sensor, meshes = bench.build_workload("syn128x1m")
 dev = torch.device("cuda", 0)
+if os.environ.get("PROBE_EXTRA_STREAM") == "1":   # what bench.py did until round 4: a torch stream of its own, made current, before the tracer's streams exist
+    _extra = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(_extra)
 HL = hostapi.load()
 f32p = C.POINTER(C.c_float)
 HL.lsh_stream_frames.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(f32p), C.POINTER(C.c_uint), C.c_uint,
@@ -20,8 +26,12 @@ V, H = len(sensor["vertical"]), int(sensor["h_count"])
 cap = V * H
 res = []
 for rep in range(reps):
+    F = os.environ.get("PROBE_FLAGS", "")
     tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"])
     tr.setOption(capi.LS_OPT_ENGINE, 2)
+    if "f1" in F: tr.setShard(0, H)
+    if "f6" in F: outs_early = [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=dev) for _ in range(3)]
+    if "f2" in F: tr.setOption(capi.LS_OPT_PIPELINE, mode)
     keep = []
     for n, v, t in meshes:
         dv = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev)
@@ -31,7 +41,7 @@ for rep in range(reps):
         tr.updateGeometryDeviceShared(n, capi.IDENTITY_AFFINE, dv.data_ptr(), 12, dt.data_ptr())
     tr.commitScene()
     tr.setOption(capi.LS_OPT_PIPELINE, mode)
-    outs = [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=dev) for _ in range(3)]
+    outs = outs_early if "f6" in F else [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=dev) for _ in range(3)]
     names = (C.c_char_p * len(meshes))(*[m[0].encode() for m in meshes])
     aff = (f32p * len(meshes))(*[C.cast(ident, f32p) for _ in meshes])
     na = (C.c_uint * len(meshes))(*[1 for _ in meshes])
@@ -40,7 +50,31 @@ for rep in range(reps):
     Cn = (C.c_void_p * 3)(*[b.data_ptr() for b in outs])
     def run(first, n):
         assert HL.lsh_stream_frames(tr.h, names, aff, na, len(meshes), P, Hh, Cn, 3, cap, first, n) == 0
+    if "f3" in F:
+        tr.setOption(capi.LS_OPT_COUNT_VISITS, 1); tr.setOutputBuffers(outs[0].data_ptr() + 64, outs[0].data_ptr() + 64 + 32 * cap, outs[0].data_ptr(), cap)
+        tr.traceSceneAsync(0); tr.flush(); torch.cuda.synchronize(dev); tr.visitStats(); tr.setOption(capi.LS_OPT_COUNT_VISITS, 0)
+    if "f4" in F:
+        import ctypes
+        fr = capi.Frame()
+        for b in range(20):
+            for i in range(50):
+                tr.L.ls_update_geometry_transform(tr.h, names[0], C.cast(ident, f32p)); tr.L.ls_commit_scene(tr.h)
+                tr.L.ls_tracer_set_output_buffers(tr.h, C.c_void_p(P[i % 3]), C.c_void_p(Hh[i % 3]), C.c_void_p(Cn[i % 3]), cap)
+                tr.L.ls_trace_scene_async(tr.h, i, C.byref(fr))
+            tr.flush(); torch.cuda.synchronize(dev)
     run(0, 600); tr.synchronize()
+    if "f5" in F or "f7" in F or "f8" in F:
+        def wsync():
+            if "f5" in F: tr.flush(); torch.cuda.synchronize(dev)            # bench.py until round 4: the device-wide wait does the waiting
+            elif "f7" in F: tr.synchronize(); torch.cuda.synchronize(dev)    # the handle's streams first: the device-wide wait finds an idle device
+            else: tr.synchronize()
+        ws5 = []
+        gap = float(os.environ.get("PROBE_GAP_MS", "0")) * 1e-3
+        for w in range(12):
+            wsync()
+            if gap: time.sleep(gap)
+            t0 = time.perf_counter(); run(0, 200); wsync(); ws5.append((time.perf_counter() - t0) / 200 * 1e6)
+        print("windows of 200: median %.2f" % float(np.median(ws5)))
     ws, enq = [], []
     K = int(os.environ.get("PROBE_WINDOW", "1000"))   # frames per timed window
     for w in range(int(os.environ.get("PROBE_WINDOWS", "5"))):
@@ -51,4 +85,5 @@ for rep in range(reps):
     tr.close()
     del outs, keep
     torch.cuda.empty_cache()
-print("PID %d medians: %s" % (os.getpid(), " ".join("%.2f" % float(np.median(w)) for w in res)))
+hip = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+print("PID %d medians: %s   HIP runtime: %s" % (os.getpid(), " ".join("%.2f" % float(np.median(w)) for w in res), hip))
