@@ -179,21 +179,21 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             const ls_tracer::InstSlot &sl = tr->inst_layout[i];
             float *verts = tr->inst_verts.p + 3 * (size_t)le.vfirst;
             const uint32_t *tris = ge.idx();   // mesh-local indices are what a per-geometry hierarchy wants: no rebased copy
-            uint32_t *ka = tr->keys_a.p + le.tfirst, *kb = tr->keys_b.p + le.tfirst, *va = tr->vals_a.p + le.tfirst, *vb = tr->vals_b.p + le.tfirst;
+            uint32_t *ka = tr->keys_a.p + le.tfirst, *kb = tr->keys_b.p + le.tfirst, *vb = tr->vals_b.p + le.tfirst;
             // identity transform: the packed copy holds the vertices as uploaded (1 * x + 0 * y + 0 * z + 0 is x)
             ls::launch_transform(s, ge.raw(), ge.stride, ge.n_verts, kIdA, kIdR, kZero, verts, tr->d_inst_maxabs + i);
             // vertices alone changed and the geometry's sorted keys are still in place: a refit (same order, same
             // topology, every box recomputed) -- what the classic path does with LS_OPT_BVH_REFIT
             const bool refit = tr->opt_bvh_refit && !ge.blas_topo_dirty && ge.blas_sorted_epoch == tr->key_scratch_epoch;
             if (!refit) {
-                ls::launch_morton(s, verts, tris, ge.n_tris, tr->d_inst_maxabs + i, ka, va);
-                if (!ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, ka, kb, va, vb, ge.n_tris))
+                // the keys, and with them the sort's first tile histograms; the values are the triangles' positions
+                ls::launch_morton(s, verts, tris, ge.n_tris, tr->d_inst_maxabs + i, ka, nullptr, ls::sort_first_counts(tr->sort_temp.p, ge.n_tris));
+                if (!ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, ka, kb, nullptr, vb, ge.n_tris, true))
                     return fail(tr, LS_ERR_OUT_OF_RANGE, "the sort scratch is smaller than a geometry's hierarchy build needs");
                 ge.blas_sorted_epoch = tr->key_scratch_epoch;
             }
             float4 *rb = tr->range_boxes.p + sl.range_first;
-            ls::launch_leaves(s, verts, tris, vb, ge.n_tris, g, tr->records.p + sl.rec_first, rb, true);
-            ls::launch_range_tree(s, sl.rt, rb);
+            ls::launch_leaves_tree(s, verts, tris, vb, ge.n_tris, g, tr->records.p + sl.rec_first, sl.rt, rb, true);
             ls::launch_hierarchy(s, kb, sl.n_leaves, g, sl.rt, rb, tr->nodes.p + sl.node_first);
         }
         // a scene of one geometry: the top of its hierarchy for the trace grid's LDS (static with the hierarchy)
@@ -321,17 +321,16 @@ int commit_locked(ls_tracer *tr)
         if ((rc = ensure(tr, tr->range_boxes, 2 * (size_t)tr->range_entries + 2))) return rc;
         if ((rc = materialize_scene(tr, true))) return rc;
         mark(tr, 1);
-        if (!refit) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, tr->vals_a.p);
+        if (!refit) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, nullptr, ls::sort_first_counts(tr->sort_temp.p, nt));
         mark(tr, 2);
-        if (!refit && !ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, tr->vals_a.p, tr->vals_b.p, nt))
+        if (!refit && !ls::launch_sort(s, tr->sort_temp.p, tr->sort_temp.cap, tr->keys_a.p, tr->keys_b.p, nullptr, tr->vals_b.p, nt, true))
             return fail(tr, LS_ERR_OUT_OF_RANGE, "the sort scratch is smaller than the hierarchy build needs");
         mark(tr, 3);
         tr->bvh_order_valid = true;
         tr->bvh_order_tris = nt;
         tr->last_commit_refit = refit;
-        ls::launch_leaves(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->range_boxes.p);
+        ls::launch_leaves_tree(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->rt, tr->range_boxes.p, false);
         mark(tr, 4);
-        ls::launch_range_tree(s, tr->rt, tr->range_boxes.p);
         mark(tr, 5);
         ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
         mark(tr, 6);

@@ -164,15 +164,18 @@ void launch_rebase(hipStream_t s, const uint32_t *idx, uint32_t n_idx, uint32_t 
 // RTC_GEOMETRY_TYPE_QUAD (EmbreeTracer.cpp:179-198): quad (v0,v1,v2,v3) -> triangles (v0,v1,v3), (v2,v3,v1), Embree's split
 void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t n_quads, uint32_t *tri_idx);
 void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint32_t ntris,
-                   const uint32_t *d_maxabs_bits, uint32_t *keys, uint32_t *vals);
+                   const uint32_t *d_maxabs_bits, uint32_t *keys, uint32_t *vals, uint32_t *first_counts = nullptr);
+// the radix sort of the build (ls_sort.hip): tiles of kSortTile keys, digits of ten bits
+constexpr uint32_t kSortTile = 4096, kSortBits = 10, kSortDigits = 1u << kSortBits;
 size_t sort_temp_bytes(uint32_t n);
+uint32_t *sort_first_counts(void *temp, uint32_t n);   // [tiles][kSortDigits]: the first pass's tile histograms (digit = key & 1023)
+// first_counted: sort_first_counts(temp, n) is already filled (k_morton did it); vals_in null: the values are 0 .. n - 1
 bool launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out,
-                 uint32_t *vals_in, uint32_t *vals_out, uint32_t n);
+                 uint32_t *vals_in, uint32_t *vals_out, uint32_t n, bool first_counted = false);
 // mesh_records: the records hold the three corners as given (v0, sorted id | v1, 0 | v2, 0) instead of v0 / e1 / e2 / NgC
 // of the transformed triangle -- the per-geometry hierarchies of the instanced mode, built once in mesh space
-void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,
-                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes, bool mesh_records = false);
-void launch_range_tree(hipStream_t s, const RangeTree &rt, float4 *boxes);
+void launch_leaves_tree(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals, uint32_t ntris,
+                        uint32_t leaf_size, TriRecord *records, const RangeTree &rt, float4 *boxes, bool mesh_records);
 void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleaves, uint32_t leaf_size,
                       const RangeTree &rt, const float4 *boxes, FatNode *nodes);
 

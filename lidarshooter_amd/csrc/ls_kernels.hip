@@ -35,27 +35,31 @@ namespace {
 // also folds max |coordinate| of the scene into *maxabs (bits of a non-negative float).
 // Algorithmic bytes per vertex: stride (read) + 12 (write).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_transform(const uint8_t *__restrict__ raw, uint32_t stride, uint32_t n,
-                                                      Affine m, float *__restrict__ out,
-                                                      uint32_t *__restrict__ maxabs)
+constexpr int kTransformBlock = 1024;   // sixteen waves share one atomic
+__global__ __launch_bounds__(kTransformBlock) void k_transform(const uint8_t *__restrict__ raw, uint32_t stride, uint32_t n,
+                                                               Affine m, float *__restrict__ out,
+                                                               uint32_t *__restrict__ maxabs)
 {
-    __shared__ float s_max[kBlock / 64];
+    __shared__ float s_max[kTransformBlock / 64];
     float mx = 0.0f;
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+    for (uint32_t j = blockIdx.x * kTransformBlock + threadIdx.x; j < n; j += gridDim.x * kTransformBlock) {
         const V3 o = xform_vertex(m, raw + (size_t)j * stride);
         out[3 * (size_t)j + 0] = o.x;
         out[3 * (size_t)j + 1] = o.y;
         out[3 * (size_t)j + 2] = o.z;
         mx = fmaxf(mx, fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))));
     }
-    // one atomic per block (a single hot address sustains only ~90 atomics/us chip-wide)
+    // one atomic per block of 1 024 threads (a single hot address sustains only ~90 atomics/us chip-wide: the 512
+    // atomics of 512 blocks of 256 were 5.7 of this kernel's 9.5 us)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-        if (mx > 0.0f) atomicMax(maxabs, __float_as_uint(mx));
+    if (threadIdx.x < 64) {
+        mx = threadIdx.x < kTransformBlock / 64 ? s_max[threadIdx.x] : 0.0f;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (threadIdx.x == 0 && mx > 0.0f) atomicMax(maxabs, __float_as_uint(mx));
     }
 }
 
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_rebase(const uint32_t *__restrict__ 
 // depth-first order of the radix tree is the traversal order, which is what lets the trace
 // kernel run stackless on skip links.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kMortonBlock = 1024;
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v)
 {
     v &= 0x3FFu;
@@ -93,86 +98,49 @@ __device__ __forceinline__ uint32_t expand_bits(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_morton(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
-                                                   uint32_t ntris, const uint32_t *__restrict__ maxabs,
-                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+// A workgroup takes one tile of the sort (kSortTile keys, four per thread); COUNT: it also leaves the tile's histogram of
+// the first digit where the sort's first pass looks for it (the pass's counting launch -- 5 us -- is not run).
+template <bool COUNT>
+__global__ __launch_bounds__(kMortonBlock) void k_morton(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
+                                                         uint32_t ntris, const uint32_t *__restrict__ maxabs,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                         uint32_t *__restrict__ counts)
 {
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= ntris) return;
+    static_assert(kSortDigits == kMortonBlock && kSortTile % kMortonBlock == 0, "a thread per digit");
+    __shared__ uint32_t s_cnt[kSortDigits];
+    if (COUNT) {
+        s_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const float m = __uint_as_float(*maxabs);
     const float scale = m > 0.0f ? 512.0f / m : 0.0f;
-    const uint32_t i0 = tris[3 * (size_t)k + 0], i1 = tris[3 * (size_t)k + 1], i2 = tris[3 * (size_t)k + 2];
-    uint32_t key = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float p0 = verts[3 * (size_t)i0 + a], p1 = verts[3 * (size_t)i1 + a], p2 = verts[3 * (size_t)i2 + a];
-        const float c = 0.5f * (fminf(p0, fminf(p1, p2)) + fmaxf(p0, fmaxf(p1, p2)));
-        const uint32_t q = min(511u, (uint32_t)(fabsf(c) * scale));
-        key |= expand_bits(q) << (2 - a);
-        key |= (c < 0.0f ? 1u : 0u) << (29 - a);
-    }
-    keys[k] = key;
-    vals[k] = k;
-}
-
-// ------------------------------------------------------------------------------------------
-// Triangle records + leaf boxes, one thread per Morton-sorted position.
-// Leaf k = records [k*g, k*g+g); its box (padded, see below) is entry k of range-tree level 0.
-// Bytes per triangle: 4 (sorted id) + 12 (indices) + 36 (vertices) read, 48 written, + 32/g.
-// ------------------------------------------------------------------------------------------
-template <bool MESH_RECORDS>
-__global__ __launch_bounds__(kBlock) void k_leaves(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
-                                                   const uint32_t *__restrict__ sorted_vals, uint32_t ntris,
-                                                   uint32_t g, TriRecord *__restrict__ records,
-                                                   float4 *__restrict__ boxes)
-{
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    if (p < ntris) {
-        const uint32_t gid = sorted_vals[p];
-        const uint32_t i0 = tris[3 * (size_t)gid + 0], i1 = tris[3 * (size_t)gid + 1], i2 = tris[3 * (size_t)gid + 2];
-        const V3 v0 = {verts[3 * (size_t)i0], verts[3 * (size_t)i0 + 1], verts[3 * (size_t)i0 + 2]};
-        const V3 v1 = {verts[3 * (size_t)i1], verts[3 * (size_t)i1 + 1], verts[3 * (size_t)i1 + 2]};
-        const V3 v2 = {verts[3 * (size_t)i2], verts[3 * (size_t)i2 + 1], verts[3 * (size_t)i2 + 2]};
-        const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
-        const V3 Ng = cross_fma(e2, e1);
-        const float NgC = dot_fma(Ng, v0);
-        float4 *r = reinterpret_cast<float4 *>(records + p);
-        if (MESH_RECORDS) {   // the corners as given: the trace kernel carries them into the sensor frame of its frame
-            r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
-            r[1] = make_float4(v1.x, v1.y, v1.z, 0.0f);
-            r[2] = make_float4(v2.x, v2.y, v2.z, 0.0f);
-        } else {
-            r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
-            r[1] = make_float4(e1.x, e1.y, e1.z, NgC);
-            r[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
-        }
-        // The triangle test accepts rays that miss the exact triangle by rounding error, so boxes
-        // are fattened by 2^-16 of the largest |coordinate|: BVH result == exhaustive result.
-        const float m = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v1.x))),
-                              fmaxf(fmaxf(fmaxf(fabsf(v1.y), fabsf(v1.z)), fmaxf(fabsf(v2.x), fabsf(v2.y))),
-                                    fabsf(v2.z)));
-        const float pad = m * 0x1p-16f;
-        lo[0] = fminf(v0.x, fminf(v1.x, v2.x)) - pad; hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x)) + pad;
-        lo[1] = fminf(v0.y, fminf(v1.y, v2.y)) - pad; hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y)) + pad;
-        lo[2] = fminf(v0.z, fminf(v1.z, v2.z)) - pad; hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z)) + pad;
-    }
-    for (uint32_t off = 1; off < g; off <<= 1) {
+    for (uint32_t r = 0; r < kSortTile / kMortonBlock; ++r) {
+        const uint32_t k = blockIdx.x * kSortTile + r * kMortonBlock + threadIdx.x;
+        if (k < ntris) {
+            const uint32_t i0 = tris[3 * (size_t)k + 0], i1 = tris[3 * (size_t)k + 1], i2 = tris[3 * (size_t)k + 2];
+            uint32_t key = 0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
-            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            for (int a = 0; a < 3; ++a) {
+                const float p0 = verts[3 * (size_t)i0 + a], p1 = verts[3 * (size_t)i1 + a], p2 = verts[3 * (size_t)i2 + a];
+                const float c = 0.5f * (fminf(p0, fminf(p1, p2)) + fmaxf(p0, fmaxf(p1, p2)));
+                const uint32_t q = min(511u, (uint32_t)(fabsf(c) * scale));
+                key |= expand_bits(q) << (2 - a);
+                key |= (c < 0.0f ? 1u : 0u) << (29 - a);
+            }
+            keys[k] = key;
+            if (vals) vals[k] = k;
+            if (COUNT) atomicAdd(&s_cnt[key & (kSortDigits - 1u)], 1u);
         }
     }
-    if (p < ntris && (p % g) == 0) {
-        const uint32_t k = p / g;
-        boxes[2 * (size_t)k] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-        boxes[2 * (size_t)k + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    if (COUNT) {
+        __syncthreads();
+        counts[(size_t)blockIdx.x * kSortDigits + threadIdx.x] = s_cnt[threadIdx.x];
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Aligned-range tree: entry j of level l bounds leaves [j<<l, (j+1)<<l).  k_range_bottom builds
+// Aligned-range tree: entry j of level l bounds leaves [j<<l, (j+1)<<l).  k_leaves_tree (below) builds
 // levels 1..9 for 512 leaves per block in LDS; k_range_top finishes the (few) remaining levels
 // in one block.  No atomics, no cross-workgroup hand-off.
 // ------------------------------------------------------------------------------------------
@@ -197,38 +165,7 @@ __device__ __forceinline__ void store_box(float4 *boxes, uint32_t e, const Box &
 
 constexpr int kBottomLevels = 9;  // 512 leaves per block
 
-__global__ __launch_bounds__(kBlock) void k_range_bottom(RangeTree rt, float4 *__restrict__ boxes)
-{
-    __shared__ float s[6][kBlock];
-    const uint32_t t = threadIdx.x;
-    const uint32_t base0 = blockIdx.x * 512u;
-    Box b = box_empty();
-    {
-        const uint32_t k0 = base0 + 2 * t;
-        if (k0 < rt.count[0]) b = load_box(boxes, k0);
-        if (k0 + 1 < rt.count[0]) { const Box c = load_box(boxes, k0 + 1); box_merge(b, c); }
-    }
-    for (uint32_t l = 1; l <= (uint32_t)kBottomLevels && l < rt.levels; ++l) {
-        const uint32_t n = 512u >> l;  // entries of this level owned by the block
-        if (t < n) {
-            const uint32_t j = (base0 >> l) + t;
-            if (j < rt.count[l]) store_box(boxes, rt.offset[l] + j, b);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { s[i][t] = b.lo[i]; s[3 + i][t] = b.hi[i]; }
-        }
-        __syncthreads();
-        if (t < (n >> 1)) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                b.lo[i] = fminf(s[i][2 * t], s[i][2 * t + 1]);
-                b.hi[i] = fmaxf(s[3 + i][2 * t], s[3 + i][2 * t + 1]);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// the levels above k_range_bottom's, one workgroup: through global memory while a level has more than kTopLds entries
+// the levels above k_leaves_tree's nine, one workgroup: through global memory while a level has more than kTopLds entries
 // (a round trip and a barrier per level), then -- 977 entries at a million leaves -- in LDS, the stores to the tree
 // fire-and-forget (ten levels: 9.5 -> 3 us)
 constexpr uint32_t kTopLds = 1024;
@@ -272,6 +209,113 @@ __global__ __launch_bounds__(kBlock) void k_range_top(RangeTree rt, float4 *__re
         for (uint32_t j = threadIdx.x; j < rt.count[l]; j += kBlock) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) s_a[k][j] = s_b[k][j];
+        }
+        __syncthreads();
+    }
+}
+
+// Triangle records + leaf boxes, one thread per pair of Morton-sorted positions.
+// Leaf k = records [k*g, k*g+g); its box (padded, see below) is entry k of range-tree level 0.
+// Bytes per triangle: 4 (sorted id) + 12 (indices) + 36 (vertices) read, 48 written, + 64/g (leaf box + the tree above it).
+// One triangle: record p written, the triangle's fattened bounds returned (empty past the end).
+template <bool MESH_RECORDS>
+__device__ __forceinline__ Box leaf_triangle(const float *__restrict__ verts, const uint32_t *__restrict__ tris, uint32_t gid, bool have,
+                                             uint32_t p, TriRecord *__restrict__ records)
+{
+    Box bx = box_empty();
+    if (have) {
+        const uint32_t i0 = tris[3 * (size_t)gid + 0], i1 = tris[3 * (size_t)gid + 1], i2 = tris[3 * (size_t)gid + 2];
+        const V3 v0 = {verts[3 * (size_t)i0], verts[3 * (size_t)i0 + 1], verts[3 * (size_t)i0 + 2]};
+        const V3 v1 = {verts[3 * (size_t)i1], verts[3 * (size_t)i1 + 1], verts[3 * (size_t)i1 + 2]};
+        const V3 v2 = {verts[3 * (size_t)i2], verts[3 * (size_t)i2 + 1], verts[3 * (size_t)i2 + 2]};
+        const V3 e1 = sub(v0, v1), e2 = sub(v2, v0);
+        const V3 Ng = cross_fma(e2, e1);
+        const float NgC = dot_fma(Ng, v0);
+        float4 *r = reinterpret_cast<float4 *>(records + p);
+        if (MESH_RECORDS) {   // the corners as given: the trace kernel carries them into the sensor frame of its frame
+            r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
+            r[1] = make_float4(v1.x, v1.y, v1.z, 0.0f);
+            r[2] = make_float4(v2.x, v2.y, v2.z, 0.0f);
+        } else {
+            r[0] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(gid));
+            r[1] = make_float4(e1.x, e1.y, e1.z, NgC);
+            r[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        }
+        // The triangle test accepts rays that miss the exact triangle by rounding error, so boxes
+        // are fattened by 2^-16 of the largest |coordinate|: BVH result == exhaustive result.
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v1.x))),
+                              fmaxf(fmaxf(fmaxf(fabsf(v1.y), fabsf(v1.z)), fmaxf(fabsf(v2.x), fabsf(v2.y))),
+                                    fabsf(v2.z)));
+        const float pad = m * 0x1p-16f;
+        bx.lo[0] = fminf(v0.x, fminf(v1.x, v2.x)) - pad; bx.hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x)) + pad;
+        bx.lo[1] = fminf(v0.y, fminf(v1.y, v2.y)) - pad; bx.hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y)) + pad;
+        bx.lo[2] = fminf(v0.z, fminf(v1.z, v2.z)) - pad; bx.hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z)) + pad;
+    }
+    return bx;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_leaves + k_range_bottom in one launch (round 4: a launch in a chain of dependent launches costs ~5 us before it
+// does anything, and k_range_bottom read back the 32 MB of leaf boxes k_leaves had just written: 23.5 + 13.4 -> 29.1 us).
+// A workgroup takes 512 leaves (512 g triangles, 512 at a time, two per thread with both gathers in flight), writes
+// their records and leaf boxes, keeps the boxes in LDS and reduces the nine levels above them there.  The levels above
+// need every workgroup's top entry: k_range_top, its own launch (7.7 us).  Handing them to the workgroup that finishes
+// last was built and is slower: a release fence per workgroup writes the whole L2 back (1 954 of them: 328 us), and with
+// the entries stored past the L2 instead, the 1 954 tickets on one address cost 21 us (~90 atomics per us on one word).
+// ------------------------------------------------------------------------------------------
+template <bool MESH_RECORDS>
+__global__ __launch_bounds__(kBlock) void k_leaves_tree(const float *__restrict__ verts, const uint32_t *__restrict__ tris,
+                                                        const uint32_t *__restrict__ sorted_vals, uint32_t ntris, uint32_t g,
+                                                        TriRecord *__restrict__ records, RangeTree rt, float4 *__restrict__ boxes)
+{
+    __shared__ float s[6][512];
+    const uint32_t t = threadIdx.x;
+    const uint32_t leaf0 = blockIdx.x * 512u;
+    const uint32_t lg = g == 1u ? 0u : g == 2u ? 1u : g == 4u ? 2u : 3u;
+    for (uint32_t round = 0; round < g; ++round) {
+        const uint32_t pa = (leaf0 << lg) + round * 512u + t, pb = pa + kBlock;
+        const bool ha = pa < ntris, hb = pb < ntris;
+        const uint32_t ga = ha ? sorted_vals[pa] : 0u, gb = hb ? sorted_vals[pb] : 0u;
+        Box a = leaf_triangle<MESH_RECORDS>(verts, tris, ga, ha, pa, records);
+        Box b = leaf_triangle<MESH_RECORDS>(verts, tris, gb, hb, pb, records);
+        for (uint32_t off = 1; off < g; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a.lo[k] = fminf(a.lo[k], __shfl_xor(a.lo[k], off)); a.hi[k] = fmaxf(a.hi[k], __shfl_xor(a.hi[k], off));
+                b.lo[k] = fminf(b.lo[k], __shfl_xor(b.lo[k], off)); b.hi[k] = fmaxf(b.hi[k], __shfl_xor(b.hi[k], off));
+            }
+        }
+        if ((t & (g - 1u)) == 0u) {
+            const uint32_t ka = pa >> lg, kb = pb >> lg;   // leaves
+            if (ha) store_box(boxes, ka, a);
+            if (hb) store_box(boxes, kb, b);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s[k][ka - leaf0] = a.lo[k]; s[3 + k][ka - leaf0] = a.hi[k];
+                s[k][kb - leaf0] = b.lo[k]; s[3 + k][kb - leaf0] = b.hi[k];
+            }
+        }
+    }
+    __syncthreads();
+    Box b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b.lo[k] = fminf(s[k][2 * t], s[k][2 * t + 1]); b.hi[k] = fmaxf(s[3 + k][2 * t], s[3 + k][2 * t + 1]); }
+    __syncthreads();
+    for (uint32_t l = 1; l <= (uint32_t)kBottomLevels && l < rt.levels; ++l) {
+        const uint32_t n = 512u >> l;  // entries of this level owned by the block
+        if (t < n) {
+            const uint32_t j = (leaf0 >> l) + t;
+            if (j < rt.count[l]) store_box(boxes, rt.offset[l] + j, b);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { s[k][t] = b.lo[k]; s[3 + k][t] = b.hi[k]; }
+        }
+        __syncthreads();
+        if (t < (n >> 1)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                b.lo[k] = fminf(s[k][2 * t], s[k][2 * t + 1]);
+                b.hi[k] = fmaxf(s[3 + k][2 * t], s[3 + k][2 * t + 1]);
+            }
         }
         __syncthreads();
     }
@@ -1197,7 +1241,8 @@ void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t 
     for (int i = 0; i < 12; ++i) m.a[i] = affine12[i];
     for (int i = 0; i < 9; ++i) m.rinv[i] = rinv9[i];
     for (int i = 0; i < 3; ++i) m.t[i] = t3[i];
-    hipLaunchKernelGGL(k_transform, dim3(min(blocks_for(n), 512u)), dim3(kBlock), 0, s, static_cast<const uint8_t *>(raw),
+    const uint32_t blocks = (n + (uint32_t)kTransformBlock - 1u) / (uint32_t)kTransformBlock;
+    hipLaunchKernelGGL(k_transform, dim3(min(blocks, 128u)), dim3(kTransformBlock), 0, s, static_cast<const uint8_t *>(raw),
                        stride, n, m, out_xyz, d_maxabs_bits);
 }
 
@@ -1207,32 +1252,30 @@ void launch_rebase(hipStream_t s, const uint32_t *idx, uint32_t n_idx, uint32_t 
     hipLaunchKernelGGL(k_rebase, dim3(blocks_for(n_idx)), dim3(kBlock), 0, s, idx, n_idx, vbase, out);
 }
 
+// vals: null = not written (the sort is told the values are the positions); first_counts: null, or sort_first_counts()
+// of the scratch the keys are going to be sorted with (then launch_sort(..., first_counted = true))
 void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint32_t ntris,
-                   const uint32_t *d_maxabs_bits, uint32_t *keys, uint32_t *vals)
+                   const uint32_t *d_maxabs_bits, uint32_t *keys, uint32_t *vals, uint32_t *first_counts)
 {
     if (!ntris) return;
-    hipLaunchKernelGGL(k_morton, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, ntris, d_maxabs_bits,
-                       keys, vals);
-}
-
-void launch_leaves(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals,
-                   uint32_t ntris, uint32_t leaf_size, TriRecord *records, float4 *boxes, bool mesh_records)
-{
-    if (!ntris) return;
-    if (mesh_records)
-        hipLaunchKernelGGL(k_leaves<true>, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris,
-                           leaf_size, records, boxes);
+    const uint32_t blocks = (ntris + kSortTile - 1u) / kSortTile;
+    if (first_counts)
+        hipLaunchKernelGGL(k_morton<true>, dim3(blocks), dim3(kMortonBlock), 0, s, verts, tris, ntris, d_maxabs_bits, keys, vals, first_counts);
     else
-        hipLaunchKernelGGL(k_leaves<false>, dim3(blocks_for(ntris)), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris,
-                           leaf_size, records, boxes);
+        hipLaunchKernelGGL(k_morton<false>, dim3(blocks), dim3(kMortonBlock), 0, s, verts, tris, ntris, d_maxabs_bits, keys, vals, first_counts);
 }
 
-void launch_range_tree(hipStream_t s, const RangeTree &rt, float4 *boxes)
+// records, leaf boxes and the aligned-range tree: k_leaves_tree, then k_range_top for the levels above a workgroup's 512 leaves
+void launch_leaves_tree(hipStream_t s, const float *verts, const uint32_t *tris, const uint32_t *sorted_vals, uint32_t ntris,
+                        uint32_t leaf_size, TriRecord *records, const RangeTree &rt, float4 *boxes, bool mesh_records)
 {
-    if (rt.levels <= 1) return;
-    hipLaunchKernelGGL(k_range_bottom, dim3((rt.count[0] + 511u) / 512u), dim3(kBlock), 0, s, rt, boxes);
-    if (rt.levels > (uint32_t)kBottomLevels + 1u)
-        hipLaunchKernelGGL(k_range_top, dim3(1), dim3(kBlock), 0, s, rt, boxes);
+    if (!ntris) return;
+    const uint32_t blocks = (rt.count[0] + 511u) / 512u;
+    if (mesh_records)
+        hipLaunchKernelGGL(k_leaves_tree<true>, dim3(blocks), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris, leaf_size, records, rt, boxes);
+    else
+        hipLaunchKernelGGL(k_leaves_tree<false>, dim3(blocks), dim3(kBlock), 0, s, verts, tris, sorted_vals, ntris, leaf_size, records, rt, boxes);
+    if (rt.levels > (uint32_t)kBottomLevels + 1u) hipLaunchKernelGGL(k_range_top, dim3(1), dim3(kBlock), 0, s, rt, boxes);
 }
 
 void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleaves, uint32_t leaf_size,
