@@ -12,6 +12,7 @@
 // eight waves' counts per digit, and every key knows where it goes.  No LDS atomics in the ranking, no sorting network,
 // and the order inside a digit is the input order (stable), which is what makes the Morton order of equal keys -- and with
 // it the hierarchy and the BVH test suite's golden structure -- reproducible.
+// Between the passes the pairs travel as eight-byte (key, value) words (one scattered store per key instead of two).
 // Algorithmic bytes per pass and pair: 4 (count) + 8 read + 8 written (scatter); 60 B per pair for the three passes.
 #include "ls_kernels.h"
 #include "ls_device.h"
@@ -49,6 +50,7 @@ __device__ __forceinline__ uint32_t below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+template <bool PAIRS /* keys: the first words of (key, value) pairs */>
 __global__ __launch_bounds__(kSortThreads) void k_sort_count(const uint32_t *__restrict__ keys, uint32_t n, uint32_t shift,
                                                             uint32_t *__restrict__ counts)
 {
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_count(const uint32_t *__r
 #pragma unroll
     for (uint32_t r = 0; r < kSortRows; ++r) {
         const size_t idx = base + (size_t)r * kSortThreads + tid;
-        key[r] = idx < n ? keys[idx] : 0xFFFFFFFFu;
+        key[r] = idx < n ? keys[PAIRS ? 2 * idx : idx] : 0xFFFFFFFFu;
     }
     __syncthreads();
 #pragma unroll
@@ -117,6 +119,10 @@ __global__ __launch_bounds__(kScanDigits *kScanChunks) void k_sort_scan(uint32_t
     for (; t < t1; ++t) { const uint32_t c = col[(size_t)t * kDigits]; col[(size_t)t * kDigits] = run; run += c; }
 }
 
+// IN_PAIRS: keys_in holds (key, value) pairs, vals_in is not read; OUT_PAIRS: keys_out takes pairs, vals_out is not written.
+// A pass that writes pairs writes ONE eight-byte word per key where separate arrays take two four-byte words in two places:
+// the scattered stores are what a pass costs beyond its 7.5 us (12.0 with them), and they cost per line touched.
+template <bool IN_PAIRS, bool OUT_PAIRS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                               uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n,
                                                               uint32_t shift, const uint32_t *__restrict__ offsets,
@@ -132,8 +138,14 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t *_
 #pragma unroll
     for (uint32_t r = 0; r < kSortRows; ++r) {
         const size_t idx = wave_base + (size_t)r * 64u + lane;
-        key[r] = idx < n ? keys_in[idx] : 0u;
-        val[r] = !vals_in ? (uint32_t)idx : idx < n ? vals_in[idx] : 0u;
+        if (IN_PAIRS) {
+            const uint2 kv = idx < n ? reinterpret_cast<const uint2 *>(keys_in)[idx] : make_uint2(0u, 0u);
+            key[r] = kv.x;
+            val[r] = kv.y;
+        } else {
+            key[r] = idx < n ? keys_in[idx] : 0u;
+            val[r] = !vals_in ? (uint32_t)idx : idx < n ? vals_in[idx] : 0u;
+        }
     }
 #pragma unroll
     for (uint32_t k = 0; k < kSortWaves; ++k) { s_cnt[k][tid] = 0u; s_cnt[k][tid + kSortThreads] = 0u; }
@@ -191,23 +203,27 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t *_
     for (uint32_t r = 0; r < kSortRows; ++r) {
         if (wave_base + (size_t)r * 64u + lane < n) {
             const uint32_t at = mine[(key[r] >> shift) & (kDigits - 1u)] + rank[r];
-            keys_out[at] = key[r];
-            vals_out[at] = val[r];
+            if (OUT_PAIRS) {
+                reinterpret_cast<uint2 *>(keys_out)[at] = make_uint2(key[r], val[r]);
+            } else {
+                keys_out[at] = key[r];
+                vals_out[at] = val[r];
+            }
         }
     }
 }
 
 }  // namespace
 
-// temp: one ping-pong array of n words each for keys and values, then the counts (tiles x 1 024 words) and the digit totals
+// temp: two arrays of n (key, value) pairs, then the counts (tiles x 1 024 words) and the digit totals
 size_t sort_temp_bytes(uint32_t n)
 {
-    return ((size_t)2 * n + (size_t)kDigits * sort_tiles(n) + kDigits + 64) * sizeof(uint32_t);
+    return ((size_t)4 * n + (size_t)kDigits * sort_tiles(n) + kDigits + 64) * sizeof(uint32_t);
 }
 
-uint32_t *sort_first_counts(void *temp, uint32_t n) { return static_cast<uint32_t *>(temp) + (size_t)2 * n; }
+uint32_t *sort_first_counts(void *temp, uint32_t n) { return static_cast<uint32_t *>(temp) + (size_t)4 * n; }
 
-// keys_in / vals_in are left as they are; the sorted pairs end in keys_out / vals_out (in -> out -> temp -> out)
+// keys_in / vals_in are left as they are; the sorted pairs end in keys_out / vals_out (in -> pairs -> pairs -> out)
 // false: the scratch is smaller than sort_temp_bytes(n) -- nothing was launched, keys_out / vals_out are NOT sorted (the
 // callers turn that into LS_ERR_OUT_OF_RANGE instead of building on garbage: ADVICE round 3)
 bool launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in,
@@ -215,19 +231,20 @@ bool launch_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_in
 {
     if (!n) return true;
     if (!temp || temp_bytes < sort_temp_bytes(n)) return false;
-    uint32_t *tk = static_cast<uint32_t *>(temp), *tv = tk + n, *counts = tv + n;
+    uint32_t *p0 = static_cast<uint32_t *>(temp), *p1 = p0 + (size_t)2 * n, *counts = p1 + (size_t)2 * n;
     const uint32_t ntiles = sort_tiles(n);
     uint32_t *totals = counts + (size_t)kDigits * ntiles;
-    const uint32_t *ki = keys_in, *vi = vals_in;
-    for (uint32_t p = 0; p < kSortPasses; ++p) {
-        uint32_t *ko = (p & 1u) ? tk : keys_out, *vo = (p & 1u) ? tv : vals_out;
-        const uint32_t shift = kSortBits * p;
-        if (p || !first_counted) hipLaunchKernelGGL(k_sort_count, dim3(ntiles), dim3(kSortThreads), 0, s, ki, n, shift, counts);
-        hipLaunchKernelGGL(k_sort_scan, dim3(kDigits / kScanDigits), dim3(kScanDigits * kScanChunks), 0, s, counts, ntiles, totals);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(kSortThreads), 0, s, ki, vi, ko, vo, n, shift, counts, totals);
-        ki = ko;
-        vi = vo;
-    }
+    const dim3 grid(ntiles), block(kSortThreads), sgrid(kDigits / kScanDigits), sblock(kScanDigits * kScanChunks);
+    static_assert(kSortPasses == 3, "separate arrays -> pairs -> pairs -> separate arrays");
+    if (!first_counted) hipLaunchKernelGGL(k_sort_count<false>, grid, block, 0, s, keys_in, n, 0u, counts);
+    hipLaunchKernelGGL(k_sort_scan, sgrid, sblock, 0, s, counts, ntiles, totals);
+    hipLaunchKernelGGL((k_sort_scatter<false, true>), grid, block, 0, s, keys_in, vals_in, p0, nullptr, n, 0u, counts, totals);
+    hipLaunchKernelGGL(k_sort_count<true>, grid, block, 0, s, p0, n, kSortBits, counts);
+    hipLaunchKernelGGL(k_sort_scan, sgrid, sblock, 0, s, counts, ntiles, totals);
+    hipLaunchKernelGGL((k_sort_scatter<true, true>), grid, block, 0, s, p0, nullptr, p1, nullptr, n, kSortBits, counts, totals);
+    hipLaunchKernelGGL(k_sort_count<true>, grid, block, 0, s, p1, n, 2u * kSortBits, counts);
+    hipLaunchKernelGGL(k_sort_scan, sgrid, sblock, 0, s, counts, ntiles, totals);
+    hipLaunchKernelGGL((k_sort_scatter<true, false>), grid, block, 0, s, p1, nullptr, keys_out, vals_out, n, 2u * kSortBits, counts, totals);
     return true;
 }
 
