@@ -348,18 +348,35 @@ __device__ __forceinline__ int delta_win(const KeyWindow &kw, int L, int i, uint
 
 // the largest t in [lo, hi) with delta(i, i + t d) > thresh, given that it holds at lo, fails at hi and is monotone in
 // between; all 64 lanes of the wave work on the one node (arguments uniform)
+// A far node is worked on by a GROUP of kFarLanes lanes (LS_FAR_LANES: 64 = the whole wave, one node after the other, as in
+// round 3; 16 = four nodes at a time, a quarter of the probes per round).  More probes per round were measured and are
+// slower (two per lane 65.2, four 69.5 us against 63.5): what the far nodes cost is their probes -- every one a 64-byte
+// line of the key array for four bytes -- not the number of rounds.
+#ifndef LS_FAR_LANES
+#define LS_FAR_LANES 16
+#endif
+constexpr int kFarLanes = LS_FAR_LANES;
+__device__ __forceinline__ int group_count(bool p, uint32_t lane)
+{
+    const unsigned long long b = __ballot(p);
+    if (kFarLanes == 64) return (int)__popcll(b);
+    const uint32_t q = lane / (uint32_t)kFarLanes;
+    return (int)__popcll((b >> (q * (uint32_t)kFarLanes)) & ((1ull << (kFarLanes & 63)) - 1ull));
+}
+// all groups of the wave call this together (a group without a node: lo = hi = 0)
 __device__ __forceinline__ int coop_search(const uint32_t *__restrict__ keys, uint32_t g, int L, int i, uint32_t ki, int d, int thresh,
                                            int lo, int hi, uint32_t lane)
 {
-    while (hi - lo > 1) {
-        const int step = (hi - lo + 63) / 64;
-        const int t = lo + ((int)lane + 1) * step;
+    const int sub = (int)(lane % (uint32_t)kFarLanes);
+    while (__any(hi - lo > 1)) {
+        const int step = max(1, (hi - lo + kFarLanes - 1) / kFarLanes);
+        const int t = lo + (sub + 1) * step;
         bool p = false;
         if (t < hi) {
             const int j = i + t * d;
             p = j >= 0 && j < L && delta_of(i, ki, j, keys[(size_t)j * g]) > thresh;
         }
-        const int c = (int)__popcll(__ballot(p));   // monotone: the lanes that hold are the first c
+        const int c = group_count(p, lane);   // monotone: the lanes that hold are the first c of the group
         hi = min(hi, lo + (c + 1) * step);
         lo = lo + c * step;
     }
@@ -368,17 +385,21 @@ __device__ __forceinline__ int coop_search(const uint32_t *__restrict__ keys, ui
 
 // bounds of leaves [l, r] from the aligned-range tree: level v contributes entry a_v = ceil(l / 2^v) if that is odd and
 // entry e_v - 1, e_v = floor((r + 1) / 2^v), if e_v is odd, as long as a_v < e_v
-__device__ __forceinline__ Box coop_range_box(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t r, uint32_t lane)
+__device__ __forceinline__ Box coop_range_box(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t r, uint32_t lane, bool have)
 {
     Box b = box_empty();
-    const uint32_t lev = lane >> 1;
-    if (lev < rt.levels) {
-        const uint32_t a = (l + (1u << lev) - 1u) >> lev, e = (r + 1u) >> lev;
-        const bool take = a < e && ((lane & 1u) ? (e & 1u) : (a & 1u));
-        if (take) b = load_box(boxes, rt.offset[lev] + ((lane & 1u) ? e - 1u : a));
+    const uint32_t sub = lane % (uint32_t)kFarLanes;
+#pragma unroll
+    for (uint32_t k = 0; k < 64u / (uint32_t)kFarLanes; ++k) {   // 64 (level, side) slots over the group's lanes
+        const uint32_t slot = sub + k * (uint32_t)kFarLanes, lev = slot >> 1;
+        if (have && lev < rt.levels) {
+            const uint32_t a = (l + (1u << lev) - 1u) >> lev, e = (r + 1u) >> lev;
+            const bool take = a < e && ((slot & 1u) ? (e & 1u) : (a & 1u));
+            if (take) { const Box c = load_box(boxes, rt.offset[lev] + ((slot & 1u) ? e - 1u : a)); box_merge(b, c); }
+        }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = kFarLanes / 2; off >= 1; off >>= 1) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             b.lo[k] = fminf(b.lo[k], __shfl_xor(b.lo[k], off));
@@ -466,20 +487,45 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict
         }
     }
     Box bl = box_empty(), br = box_empty();
-    // the wave's far nodes, one after the other, all lanes on each
-    for (unsigned long long todo = __ballot(node && far); todo; todo &= todo - 1ull) {
-        const int f = __builtin_ctzll(todo);
-        const int fi = __builtin_amdgcn_readlane(i, f), fd = __builtin_amdgcn_readlane(d, f), fdmin = __builtin_amdgcn_readlane(dmin, f);
-        const uint32_t fki = (uint32_t)__builtin_amdgcn_readlane((int)ki, f);
+    // the wave's far nodes, 64 / kFarLanes at a time, a group of lanes on each
+    for (unsigned long long todo = __ballot(node && far); todo;) {
+        constexpr int kGroups = 64 / kFarLanes;
+        const int q = (int)(lane / (uint32_t)kFarLanes);
+        int f = -1;   // the lane whose node this group takes: the q-th of the far lanes left
+        unsigned long long batch = 0ull, m = todo;
+#pragma unroll
+        for (int k = 0; k < kGroups; ++k) {
+            if (m) {
+                const int b = __builtin_ctzll(m);
+                if (k == q) f = b;
+                batch |= 1ull << b;
+                m &= m - 1ull;
+            }
+        }
+        todo = m;
+        const bool have = f >= 0;
+        const int src = have ? f : 0;
+        const int fi = __shfl(i, src), fd = __shfl(d, src), fdmin = __shfl(dmin, src);
+        const uint32_t fki = (uint32_t)__shfl((int)ki, src);
         const int reach = fd > 0 ? L - 1 - fi : fi;   // the last t with i + t d inside [0, L)
-        const int flen = coop_search(keys, g, L, fi, fki, fd, fdmin, 1, reach + 1, lane);
+        const int flen = coop_search(keys, g, L, fi, fki, fd, fdmin, have ? 1 : 0, have ? reach + 1 : 0, lane);
         const int fj = fi + flen * fd;
-        const int fdnode = delta_of(fi, fki, fj, keys[(size_t)fj * g]);
-        const int fs = coop_search(keys, g, L, fi, fki, fd, fdnode, 0, flen, lane);
+        const int fdnode = have ? delta_of(fi, fki, fj, keys[(size_t)fj * g]) : 0;
+        const int fs = coop_search(keys, g, L, fi, fki, fd, fdnode, 0, have ? flen : 0, lane);
         const int fgamma = fi + fs * fd + min(fd, 0), fl = min(fi, fj), fr = max(fi, fj);
-        const Box cl = coop_range_box(rt, boxes, (uint32_t)fl, (uint32_t)fgamma, lane);
-        const Box cr = coop_range_box(rt, boxes, (uint32_t)fgamma + 1u, (uint32_t)fr, lane);
-        if ((int)lane == f) { len = flen; s = fs; bl = cl; br = cr; }
+        const Box cl = coop_range_box(rt, boxes, (uint32_t)fl, (uint32_t)fgamma, lane, have);
+        const Box cr = coop_range_box(rt, boxes, (uint32_t)fgamma + 1u, (uint32_t)fr, lane, have);
+        // the owner takes the result from the first lane of the group that worked on its node (its rank among the batch)
+        const bool mine_now = (batch >> lane) & 1ull;
+        const int from = (int)__popcll(batch & ((1ull << lane) - 1ull)) * kFarLanes;
+        const int olen = __shfl(flen, from), os = __shfl(fs, from);
+        Box obl, obr;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            obl.lo[k] = __shfl(cl.lo[k], from); obl.hi[k] = __shfl(cl.hi[k], from);
+            obr.lo[k] = __shfl(cr.lo[k], from); obr.hi[k] = __shfl(cr.hi[k], from);
+        }
+        if (mine_now) { len = olen; s = os; bl = obl; br = obr; }
     }
     const int j = i + len * d;
     const int gamma = i + s * d + min(d, 0);
