@@ -28,6 +28,8 @@ LS_BENCH_FORCE_GROUP=1 python bench.py --no-cpu-baseline --no-dropin --group-fla
 (cd tools/micro && ./graph_launch --rccl) > gpurun_out/final/${TAG}_graph_launch_micro.txt 2>&1
 (cd tools/micro && ./chunked_h2d) > gpurun_out/final/${TAG}_chunked_h2d_micro.txt 2>&1
 (cd tools/micro && ./loads_probe) > gpurun_out/final/${TAG}_loads_probe_micro.txt 2>&1
+(cd tools/micro && ./atomic_rate) > gpurun_out/final/${TAG}_atomic_rate_micro.txt 2>&1
+(cd tools/micro && ./strided_h2d) > gpurun_out/final/${TAG}_strided_h2d_micro.txt 2>&1
 # what ONE of eight ranks does per frame (no collective): kernel times of an eighth-of-a-turn shard, SYN-1M and SYN-10M
 python tools/shard_cost.py 2 1,8 > gpurun_out/final/${TAG}_shard_cost_1m.txt 2>> gpurun_out/final/bench.err
 W=syn128x10m python tools/shard_cost.py 2 1,8 > gpurun_out/final/${TAG}_shard_cost_10m.txt 2>> gpurun_out/final/bench.err
