@@ -99,7 +99,7 @@ struct ProjectParams {
     int sector_on;                 // the shard covers less than 180 degrees of azimuth: sec_a / sec_b are valid
     float sec_a[2], sec_b[2];      // unit vectors (cos, sin) of the padded sector's first / second boundary, counter-clockwise
     uint32_t big_cells;            // footprints above this many cells go to the gather queue
-    int debug;                     // diagnostic: 1 = stop after the vertex loads, 2 = after the footprints
+    int debug;                     // diagnostic: 1 = stop after the vertex loads, 3 = after the band test, 2 = after the footprints
     int spread;                    // big meshes: a wave takes its triangles in runs spread over the whole mesh (balances the cells per
                                    // wave: shorter kernel) instead of one contiguous run (fewer cache lines: better with frames overlapping)
     uint32_t xcd_remap;            // one geometry, no culling: workgroup -> triangles so that each XCD streams one contiguous eighth

@@ -447,7 +447,9 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             outside = (a0 < 0.0f && a1 < 0.0f && a2 < 0.0f) || (b0 < 0.0f && b1 < 0.0f && b2 < 0.0f);
         }
         Foot f = {0, 0, 0, 0, 0, 0};
-        if (!outside) f = footprint(pp, ct, v0, v1, v2);
+        if (!outside) band(pp, ct, v0, v1, v2, f.i0, f.nch);
+        if (pp.debug == 3) { if (f.nch == 0xFFFFFFFFu) best[0] = 0; return; }
+        if (f.nch) columns(pp, v0, v1, v2, f.h0a, f.na, f.h0b, f.nb);
         cells = f.nch * (f.na + f.nb);
         if (pp.debug == 2) { if (cells == 0xFFFFFFFFu) best[0] = 0; return; }
         if (cells) {
