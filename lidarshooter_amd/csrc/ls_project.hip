@@ -195,14 +195,6 @@ __device__ __forceinline__ void columns(const ProjectParams &pp, V3 v0, V3 v1, V
     if (full) { h0a = az_first; na = az_last - az_first + 1u; h0b = 0; nb = 0; }
 }
 
-__device__ __forceinline__ Foot footprint(const ProjectParams &pp, const ChanTables &ct, V3 v0, V3 v1, V3 v2)
-{
-    Foot f = {0, 0, 0, 0, 0, 0};
-    band(pp, ct, v0, v1, v2, f.i0, f.nch);
-    if (f.nch) columns(pp, v0, v1, v2, f.h0a, f.na, f.h0b, f.nb);
-    return f;
-}
-
 // cell m of a footprint -> (channel, column)
 __device__ __forceinline__ void foot_cell(const ChanTables &ct, uint32_t i0, uint32_t h0a, uint32_t na, uint32_t h0b,
                                           uint32_t nb, uint32_t m, uint32_t &v, uint32_t &h)
