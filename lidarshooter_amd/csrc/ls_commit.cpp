@@ -9,11 +9,14 @@
 namespace lsi {
 
 // (re)build the committed scene arrays (transformed vertices, rebased indices) on the device
-int materialize_scene(ls_tracer *tr, bool with_maxabs)
+// keep_indices: the rebased indices of the last call are still right (same layout, no index upload since: a refit)
+int materialize_scene(ls_tracer *tr, bool with_maxabs, bool keep_indices)
 {
     int rc;
     if ((rc = ensure(tr, tr->verts, (size_t)tr->n_verts * 3))) return rc;
+    const uint32_t *tris_before = tr->tris.p;
     if ((rc = ensure(tr, tr->tris, (size_t)tr->n_tris * 3))) return rc;
+    const bool rebase = !(keep_indices && tr->tris_rebased && tr->tris.p == tris_before);
     hipStream_t s = tr->stream;
     if (with_maxabs) LS_HIP(hipMemsetAsync(tr->d_maxabs, 0, 4, s));
     for (const auto &le : tr->layout) {
@@ -22,9 +25,10 @@ int materialize_scene(ls_tracer *tr, bool with_maxabs)
         Geometry &ge = it->second;
         ls::launch_transform(s, ge.raw(), ge.stride, ge.n_verts, ge.affine, tr->rinv, tr->t,
                              tr->verts.p + 3 * (size_t)le.vfirst, tr->d_maxabs);
-        ls::launch_rebase(s, ge.idx(), ge.n_tris * 3, le.vfirst, tr->tris.p + 3 * (size_t)le.tfirst);
+        if (rebase) ls::launch_rebase(s, ge.idx(), ge.n_tris * 3, le.vfirst, tr->tris.p + 3 * (size_t)le.tfirst);
     }
     LS_HIP(hipGetLastError());
+    tr->tris_rebased = true;
     tr->scene_materialized = true;
     return LS_OK;
 }
@@ -168,6 +172,7 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
         if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(biggest)))) return rc;
         if (!tr->d_inst_maxabs) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_inst_maxabs), ls::kGeomsPerLaunch * 4));
         tr->bvh_order_valid = false;   // the key arrays hold per-geometry slices now
+        tr->classic_nodes_valid = false;
         if (fresh) ++tr->key_scratch_epoch;   // the slices moved
         hipStream_t s = tr->stream;
         static const float kIdA[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, kIdR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kZero[3] = {0, 0, 0};
@@ -194,7 +199,9 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             }
             float4 *rb = tr->range_boxes.p + sl.range_first;
             ls::launch_leaves_tree(s, verts, tris, vb, ge.n_tris, g, tr->records.p + sl.rec_first, sl.rt, rb, true);
-            ls::launch_hierarchy(s, kb, sl.n_leaves, g, sl.rt, rb, tr->nodes.p + sl.node_first);
+            // (a refit finds the topology of these very keys in the nodes: fresh layouts and classic builds in between clear the condition)
+            if (refit) ls::launch_refit_nodes(s, sl.n_leaves, sl.rt, rb, tr->nodes.p + sl.node_first);
+            else ls::launch_hierarchy(s, kb, sl.n_leaves, g, sl.rt, rb, tr->nodes.p + sl.node_first);
         }
         // a scene of one geometry: the top of its hierarchy for the trace grid's LDS (static with the hierarchy)
         tr->treelet_valid = false;
@@ -319,7 +326,7 @@ int commit_locked(ls_tracer *tr)
         if ((rc = ensure(tr, tr->nodes, (size_t)L))) return rc;
         if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
         if ((rc = ensure(tr, tr->range_boxes, 2 * (size_t)tr->range_entries + 2))) return rc;
-        if ((rc = materialize_scene(tr, true))) return rc;
+        if ((rc = materialize_scene(tr, true, refit))) return rc;   // (a refit: same layout, same indices as the last build's)
         mark(tr, 1);
         if (!refit) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, nullptr, ls::sort_first_counts(tr->sort_temp.p, nt));
         mark(tr, 2);
@@ -332,7 +339,9 @@ int commit_locked(ls_tracer *tr)
         ls::launch_leaves_tree(s, tr->verts.p, tr->tris.p, tr->vals_b.p, nt, g, tr->records.p, tr->rt, tr->range_boxes.p, false);
         mark(tr, 4);
         mark(tr, 5);
-        ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
+        if (refit && tr->classic_nodes_valid) ls::launch_refit_nodes(s, L, tr->rt, tr->range_boxes.p, tr->nodes.p);
+        else ls::launch_hierarchy(s, tr->keys_b.p, L, g, tr->rt, tr->range_boxes.p, tr->nodes.p);
+        tr->classic_nodes_valid = true;
         mark(tr, 6);
         LS_HIP(hipGetLastError());
         tr->bvh_built = true;

@@ -181,6 +181,7 @@ static int sensor_changed(ls_tracer *tr)
     tr->layout_dirty = true;          // every sensor-frame product (materialised scene, sensor-centred Morton order) is stale
     tr->scene_materialized = false;
     tr->bvh_order_valid = false;
+    tr->classic_nodes_valid = false;
     if (tr->committed) {
         tr->committed = false;
         rc = commit_locked(tr);

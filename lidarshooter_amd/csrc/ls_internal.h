@@ -192,6 +192,8 @@ struct ls_tracer {
     lsi::DevBuf<ls::FatNode> treelet; // one-geometry scenes: the top of that hierarchy, breadth-first (k_trace_inst stages it in LDS)
     bool treelet_valid = false;
     bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
+    bool tris_rebased = false;          // tr->tris holds the rebased indices of the current layout and index uploads
+    bool classic_nodes_valid = false;   // tr->nodes holds the classic hierarchy of the keys bvh_order_valid speaks of (k_refit_nodes may reuse its topology)
     uint32_t bvh_order_tris = 0;
     bool last_commit_refit = false;
     int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (geometries of 2 M triangles or more, cull_enabled)
@@ -307,7 +309,7 @@ struct SinkScope {
 void affine_from_components(const float *lin, const float *ang, float *A);
 void free_geometry(Geometry &g);
 // ls_commit.cpp
-int materialize_scene(ls_tracer *tr, bool with_maxabs);
+int materialize_scene(ls_tracer *tr, bool with_maxabs, bool keep_indices = false);
 bool cull_enabled(const ls_tracer *tr, const Geometry &g);
 bool inst_inverse(const ls_tracer *tr, const Geometry &ge, double *minv9, double *o3, double *cond);
 int commit_locked(ls_tracer *tr);

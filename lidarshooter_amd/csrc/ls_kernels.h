@@ -178,6 +178,7 @@ void launch_leaves_tree(hipStream_t s, const float *verts, const uint32_t *tris,
                         uint32_t leaf_size, TriRecord *records, const RangeTree &rt, float4 *boxes, bool mesh_records);
 void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleaves, uint32_t leaf_size,
                       const RangeTree &rt, const float4 *boxes, FatNode *nodes);
+void launch_refit_nodes(hipStream_t s, uint32_t nleaves, const RangeTree &rt, const float4 *boxes, FatNode *nodes);
 
 // ---- trace ---------------------------------------------------------------------------------
 uint32_t trace_grid_blocks(int device);  // persistent grid: resident blocks of the device

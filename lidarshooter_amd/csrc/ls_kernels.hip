@@ -412,6 +412,7 @@ __device__ __forceinline__ Box coop_range_box(const RangeTree &rt, const float4 
 // the same for one lane's node, both children at once: [l, gamma] and [gamma + 1, r].  The four loads of a level go out
 // before the previous level's four are merged (unconditionally -- entry 0 when there is nothing to take -- so that the
 // number of loads in flight is known to the compiler and it can wait for all but the newest)
+template <bool MASKED>
 __device__ __forceinline__ void range_box_pair(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t gamma, uint32_t r,
                                                Box &bl, Box &br)
 {
@@ -427,8 +428,17 @@ __device__ __forceinline__ void range_box_pair(const RangeTree &rt, const float4
         const uint32_t base = act0 || act1 ? rt.offset[lev] : 0u;
         const uint32_t at[4] = {has[0] ? base + a0 : 0u, has[1] ? base + e0 - 1u : 0u, has[2] ? base + a1 : 0u, has[3] ? base + e1 - 1u : 0u};
         float4 q[8];
+        if (MASKED) {
+            // only the lanes that take the entry load it: k_refit_nodes 55.4 -> 48.0 us (a load's cost follows its active lanes);
+            // k_hierarchy, with its searches' registers next to these, gets slower that way (60.9 -> 65.6 us) and loads all
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { q[2 * k] = boxes[2 * (size_t)at[k]]; q[2 * k + 1] = boxes[2 * (size_t)at[k] + 1]; }
+            for (int k = 0; k < 8; ++k) q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (has[k]) { q[2 * k] = boxes[2 * (size_t)at[k]]; q[2 * k + 1] = boxes[2 * (size_t)at[k] + 1]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { q[2 * k] = boxes[2 * (size_t)at[k]]; q[2 * k + 1] = boxes[2 * (size_t)at[k] + 1]; }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (had[k]) {
@@ -532,15 +542,16 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict
     const int l = min(i, j), r = max(i, j);
     const uint32_t left = (l == gamma) ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
     const uint32_t right = (r == gamma + 1) ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-    if (node && !far) range_box_pair(rt, boxes, (uint32_t)l, (uint32_t)gamma, (uint32_t)r, bl, br);
+    if (node && !far) range_box_pair<false>(rt, boxes, (uint32_t)l, (uint32_t)gamma, (uint32_t)r, bl, br);
     // the wave's 64 nodes are 4 KB in a row: through LDS, so that every store instruction writes 1 KB contiguous (a lane
     // storing its own node's four quarters writes 16 bytes of 64 different lines each time)
     float4 *mine = s_out[threadIdx.x >> 6];
     if (node) {
         mine[4 * lane + 0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
         mine[4 * lane + 1] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __uint_as_float(right));
-        mine[4 * lane + 2] = make_float4(br.lo[0], br.lo[1], br.lo[2], 0.0f);
-        mine[4 * lane + 3] = make_float4(br.hi[0], br.hi[1], br.hi[2], 0.0f);
+        // (the fourth words of the right child's box: the node's leaf range, for k_refit_nodes)
+        mine[4 * lane + 2] = make_float4(br.lo[0], br.lo[1], br.lo[2], __uint_as_float((uint32_t)l));
+        mine[4 * lane + 3] = make_float4(br.hi[0], br.hi[1], br.hi[2], __uint_as_float((uint32_t)r));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -550,6 +561,63 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict
     for (int k = 0; k < 4; ++k) {
         const int q = k * 64 + (int)lane;   // quarter q of the wave's 256
         if (wave_first + (q >> 2) < L - 1) out[q] = mine[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Refit: the hierarchy's topology stands (same sorted keys), only the boxes follow the vertices.  k_hierarchy left every
+// node's leaf range next to its child references, so a node needs no search: its two range queries and 48 bytes of stores.
+// Nodes with long ranges go to groups of lanes as k_hierarchy's far nodes do.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_refit_nodes(uint32_t L_, RangeTree rt, const float4 *__restrict__ boxes, FatNode *__restrict__ nodes)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool node = i + 1u < L_;
+    uint32_t left = 0, right = 0, l = 0, r = 0;
+    if (node) {
+        const float4 *q = reinterpret_cast<const float4 *>(nodes + i);
+        left = __float_as_uint(q[0].w); right = __float_as_uint(q[1].w);
+        l = __float_as_uint(q[2].w); r = __float_as_uint(q[3].w);
+    }
+    const uint32_t gamma = left & ~kLeafBit;
+    const bool wide = node && r - l >= (uint32_t)(kBlock + 2 * kKeyWindow);
+    Box bl = box_empty(), br = box_empty();
+    for (unsigned long long todo = __ballot(wide); todo;) {
+        constexpr int kGroups = 64 / kFarLanes;
+        const int q = (int)(lane / (uint32_t)kFarLanes);
+        int f = -1;
+        unsigned long long batch = 0ull, m = todo;
+#pragma unroll
+        for (int k = 0; k < kGroups; ++k) {
+            if (m) {
+                const int b = __builtin_ctzll(m);
+                if (k == q) f = b;
+                batch |= 1ull << b;
+                m &= m - 1ull;
+            }
+        }
+        todo = m;
+        const bool have = f >= 0;
+        const int src = have ? f : 0;
+        const uint32_t fl = (uint32_t)__shfl((int)l, src), fg = (uint32_t)__shfl((int)gamma, src), fr = (uint32_t)__shfl((int)r, src);
+        const Box cl = coop_range_box(rt, boxes, fl, fg, lane, have);
+        const Box cr = coop_range_box(rt, boxes, fg + 1u, fr, lane, have);
+        const int from = (int)__popcll(batch & ((1ull << lane) - 1ull)) * kFarLanes;
+        Box obl, obr;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            obl.lo[k] = __shfl(cl.lo[k], from); obl.hi[k] = __shfl(cl.hi[k], from);
+            obr.lo[k] = __shfl(cr.lo[k], from); obr.hi[k] = __shfl(cr.hi[k], from);
+        }
+        if ((batch >> lane) & 1ull) { bl = obl; br = obr; }
+    }
+    if (node && !wide) range_box_pair<true>(rt, boxes, l, gamma, r, bl, br);
+    if (node) {
+        float4 *out = reinterpret_cast<float4 *>(nodes + i);
+        out[0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
+        out[1] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __uint_as_float(right));
+        out[2] = make_float4(br.lo[0], br.lo[1], br.lo[2], __uint_as_float(l));
+        out[3] = make_float4(br.hi[0], br.hi[1], br.hi[2], __uint_as_float(r));
     }
 }
 
@@ -1330,6 +1398,13 @@ void launch_hierarchy(hipStream_t s, const uint32_t *sorted_keys, uint32_t nleav
     if (nleaves < 2) return;
     hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(nleaves - 1)), dim3(kBlock), 0, s, sorted_keys, nleaves,
                        leaf_size, rt, boxes, nodes);
+}
+
+// refit: the nodes hold the topology of the same sorted keys (launch_hierarchy ran on them): boxes only
+void launch_refit_nodes(hipStream_t s, uint32_t nleaves, const RangeTree &rt, const float4 *boxes, FatNode *nodes)
+{
+    if (nleaves < 2) return;
+    hipLaunchKernelGGL(k_refit_nodes, dim3(blocks_for(nleaves - 1)), dim3(kBlock), 0, s, nleaves, rt, boxes, nodes);
 }
 
 uint32_t trace_grid_blocks(int device)

@@ -141,8 +141,8 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
             ls::launch_quads_to_triangles(tr->stream, idx, g.n_elems, g.d_idx);
             g.shared_idx = nullptr;
             if (!g.has_idx) tr->layout_dirty = true;
-            g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true;
-        } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true; }
+            g.has_idx = true; g.idx_dirty = true; tr->tris_rebased = false; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true;
+        } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; tr->tris_rebased = false; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true; }
         return LS_OK;
     }
     if (!verts && !idx) return LS_OK;   // transform only: nothing is copied, nothing to order
@@ -196,7 +196,7 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         }
         if (!g.has_idx) tr->layout_dirty = true;
         g.has_idx = true;
-        g.idx_dirty = true;
+        g.idx_dirty = true; tr->tris_rebased = false;
     }
     return LS_OK;
 }

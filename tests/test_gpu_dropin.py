@@ -285,6 +285,52 @@ def test_bvh_refit(oracle, capi, sensors, meshes):
     tr.close()
 
 
+def test_bvh_refit_after_an_index_upload_under_another_engine(oracle, capi, sensors, meshes):
+    """The classic hierarchy's refit reuses what the last build left on the device (sorted order, tree topology with the
+    nodes' leaf ranges, the rebased index copy).  Indices uploaded while the PROJECTION engine is active (same triangle
+    count, other triangles) must not be met by those leftovers when the BVH engine comes back: every frame equals the oracle."""
+    from lidarshooter_amd import synth
+    s = sensors["0000"]
+    gv, gt = synth.grid_mesh(60, 40, half=40.0, seed=5)
+    bv, bt = meshes["ben"]
+    tr = make_tracer(capi, s, "bvh")
+    tr.setOption(capi.LS_OPT_BVH_INSTANCED, 0)
+    tr.addGeometry("ground", gv.shape[0], gt.shape[0])
+    tr.addGeometry("face", bv.shape[0], bt.shape[0])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gv, gt)
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+    assert tr.commitScene() == 0
+    A = oracle.affine_from_components(np.array((1.0, 2.0, 0.1), np.float32), np.array((0.0, 0.0, 0.5), np.float32))
+    tr.updateGeometryTransform("face", A)
+    assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_LAST_COMMIT_REFIT) == 1
+    rc, pts, hits = tr.traceScene(0)
+    ref = oracle.trace_frame(s, [(0, gv, gt, oracle.IDENTITY_AFFINE), (1, bv, bt, A)])
+    assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    # projection engine: the ground gets other triangles over the same vertices (every other cell's diagonal pair dropped
+    # for a copy of its neighbour: same count, different set)
+    gt2 = gt.copy()
+    gt2[0::4] = gt[1::4]
+    tr.setOption(capi.LS_OPT_ENGINE, 2)
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, gv, gt2)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(1)
+    ref = oracle.trace_frame(s, [(0, gv, gt2, oracle.IDENTITY_AFFINE), (1, bv, bt, A)])
+    assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    # back to the BVH engine, poses only
+    tr.setOption(capi.LS_OPT_ENGINE, 1)
+    tr.updateGeometryTransform("face", oracle.IDENTITY_AFFINE)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(2)
+    ref = oracle.trace_frame(s, [(0, gv, gt2, oracle.IDENTITY_AFFINE), (1, bv, bt, oracle.IDENTITY_AFFINE)])
+    assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    tr.updateGeometryTransform("face", A)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(3)
+    ref = oracle.trace_frame(s, [(0, gv, gt2, oracle.IDENTITY_AFFINE), (1, bv, bt, A)])
+    assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+    tr.close()
+
+
 def test_bvh_instanced(oracle, capi, sensors, meshes):
     """BVH engine, instanced mode (the default): one hierarchy per geometry in mesh space, rays carried into it.  A commit
     after which only poses differ builds nothing; a vertex or topology change rebuilds that geometry alone; matrices that
