@@ -410,9 +410,8 @@ __device__ __forceinline__ Box coop_range_box(const RangeTree &rt, const float4 
 }
 
 // the same for one lane's node, both children at once: [l, gamma] and [gamma + 1, r].  The four loads of a level go out
-// before the previous level's four are merged (unconditionally -- entry 0 when there is nothing to take -- so that the
-// number of loads in flight is known to the compiler and it can wait for all but the newest)
-template <bool MASKED>
+// before the previous level's four are merged (a load instruction per entry and level, masked to the lanes that take
+// the entry: the number of loads in flight stays known to the compiler, which waits for all but the newest)
 __device__ __forceinline__ void range_box_pair(const RangeTree &rt, const float4 *__restrict__ boxes, uint32_t l, uint32_t gamma, uint32_t r,
                                                Box &bl, Box &br)
 {
@@ -426,19 +425,14 @@ __device__ __forceinline__ void range_box_pair(const RangeTree &rt, const float4
         const bool act0 = lev < rt.levels && a0 < e0, act1 = lev < rt.levels && a1 < e1;
         const bool has[4] = {act0 && (a0 & 1u), act0 && (e0 & 1u), act1 && (a1 & 1u), act1 && (e1 & 1u)};
         const uint32_t base = act0 || act1 ? rt.offset[lev] : 0u;
-        const uint32_t at[4] = {has[0] ? base + a0 : 0u, has[1] ? base + e0 - 1u : 0u, has[2] ? base + a1 : 0u, has[3] ? base + e1 - 1u : 0u};
+        const uint32_t at[4] = {base + a0, base + e0 - 1u, base + a1, base + e1 - 1u};
         float4 q[8];
-        if (MASKED) {
-            // only the lanes that take the entry load it: k_refit_nodes 55.4 -> 48.0 us (a load's cost follows its active lanes);
-            // k_hierarchy, with its searches' registers next to these, gets slower that way (60.9 -> 65.6 us) and loads all
+        // only the lanes that take an entry load it (a load's cost follows its active lanes): k_refit_nodes 55.4 -> 48.0 us,
+        // k_hierarchy 58.8 -> 57.3 us once it is held at six waves per SIMD (61.2 without: 88 registers, five waves)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 8; ++k) q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (has[k]) { q[2 * k] = boxes[2 * (size_t)at[k]]; q[2 * k + 1] = boxes[2 * (size_t)at[k] + 1]; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { q[2 * k] = boxes[2 * (size_t)at[k]]; q[2 * k + 1] = boxes[2 * (size_t)at[k] + 1]; }
-        }
+        for (int k = 0; k < 4; ++k) if (has[k]) { q[2 * k] = boxes[2 * (size_t)at[k]]; q[2 * k + 1] = boxes[2 * (size_t)at[k] + 1]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (had[k]) {
@@ -461,7 +455,8 @@ __device__ __forceinline__ void range_box_pair(const RangeTree &rt, const float4
 // its two children [l,split] and [split+1,r] from the aligned-range tree -- no bottom-up pass, no
 // atomics, no cross-workgroup hand-off.  The left child precedes the right one in Morton order.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict__ keys, uint32_t L_, uint32_t g,
+// (six waves per SIMD asked for: with the range queries' loads masked the allocator would otherwise take 88 registers and five)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_hierarchy(const uint32_t *__restrict__ keys, uint32_t L_, uint32_t g,
                                                       RangeTree rt, const float4 *__restrict__ boxes,
                                                       FatNode *__restrict__ nodes)
 {
@@ -542,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t *__restrict
     const int l = min(i, j), r = max(i, j);
     const uint32_t left = (l == gamma) ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
     const uint32_t right = (r == gamma + 1) ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-    if (node && !far) range_box_pair<false>(rt, boxes, (uint32_t)l, (uint32_t)gamma, (uint32_t)r, bl, br);
+    if (node && !far) range_box_pair(rt, boxes, (uint32_t)l, (uint32_t)gamma, (uint32_t)r, bl, br);
     // the wave's 64 nodes are 4 KB in a row: through LDS, so that every store instruction writes 1 KB contiguous (a lane
     // storing its own node's four quarters writes 16 bytes of 64 different lines each time)
     float4 *mine = s_out[threadIdx.x >> 6];
@@ -611,7 +606,7 @@ __global__ __launch_bounds__(kBlock) void k_refit_nodes(uint32_t L_, RangeTree r
         }
         if ((batch >> lane) & 1ull) { bl = obl; br = obr; }
     }
-    if (node && !wide) range_box_pair<true>(rt, boxes, l, gamma, r, bl, br);
+    if (node && !wide) range_box_pair(rt, boxes, l, gamma, r, bl, br);
     if (node) {
         float4 *out = reinterpret_cast<float4 *>(nodes + i);
         out[0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
