@@ -67,5 +67,8 @@ W=syn128x10m bash tools/pmc_tool.sh ${TAG}_10m "FETCH_SIZE" "WRITE_SIZE" -- tool
 # BVH engine: a full rebuild of SYN-1M every frame (instanced and classic): the build kernels, the hand-written sort among them
 bash tools/rocprof_kernels.sh ${TAG}_rebuild tools/rebuild_cost.py > gpurun_out/final/${TAG}_bvh_rebuild_kernels.txt 2>&1
 tail -2 gpurun_out/rp_${TAG}_rebuild/stdout.log >> gpurun_out/final/${TAG}_bvh_rebuild_kernels.txt
+# and a refit per frame (classic hierarchy, poses restated): transform, leaves + range tree, k_refit_nodes
+bash tools/rocprof_kernels.sh ${TAG}_refit tools/refit_cost.py 50 > gpurun_out/final/${TAG}_bvh_refit_kernels.txt 2>&1
+tail -2 gpurun_out/rp_${TAG}_refit/stdout.log >> gpurun_out/final/${TAG}_bvh_refit_kernels.txt
 ls gpurun_out/final
 tail -3 gpurun_out/final/bench.err
