@@ -133,7 +133,8 @@ def pin_to_gpu_numa_node(dev_index: int):
     host time instead of 8.3 - 10.6, enough for the three streams to run dry between frames: 18.3 - 18.7 us per frame instead
     of 16 - 17 (the process-to-process spread of rounds 2 - 4; lsbench and tools/variance_probe.py, which
     keep the GPU's queues thousands of frames deep, never show it).  So the process is confined to the CPUs of the GPU's own NUMA
-    node, as numactl would: 8 of 8 processes at 16.2 - 16.9 us against 3 of 6 above 18.3 without.  Returns what it did."""
+    node, as numactl would -- all of its threads, the runtime's helper threads that exist by then included: 8 of 8 processes at
+    16.0 - 16.3 us (16.2 - 16.9 with the calling thread alone) against 3 of 6 above 18.3 without.  Returns what it did."""
     try:
         # the device's PCI address from the HIP runtime (does not initialise more than torch already has), then sysfs
         import ctypes
@@ -155,8 +156,17 @@ def pin_to_gpu_numa_node(dev_index: int):
         cpus &= set(os.sched_getaffinity(0))
         if not cpus:
             return {"pinned": False, "why": "the GPU's node has no CPU this process may run on", "node": node}
+        # every thread the process has by now (sched_setaffinity(0, ...) is the calling thread alone; the runtime's helper
+        # threads that exist already would stay where they are), and, by inheritance, every thread made later
+        tids = 0
+        for t in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(t), cpus)
+                tids += 1
+            except OSError:
+                pass
         os.sched_setaffinity(0, cpus)
-        return {"pinned": True, "node": node, "cpus": len(cpus)}
+        return {"pinned": True, "node": node, "cpus": len(cpus), "threads": tids}
     except Exception as e:   # never in the way of the measurement
         return {"pinned": False, "why": repr(e)}
 
