@@ -170,13 +170,16 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
         uint32_t biggest = 0;
         for (const Geometry *ge : order) biggest = std::max(biggest, ge->n_tris);
         if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(biggest)))) return rc;
-        if (!tr->d_inst_maxabs) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_inst_maxabs), ls::kGeomsPerLaunch * 4));
+        if (!tr->d_inst_maxabs) {
+            LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_inst_maxabs), ls::kGeomsPerLaunch * 4));
+            LS_HIP(hipMemsetAsync(tr->d_inst_maxabs, 0, ls::kGeomsPerLaunch * 4, tr->stream));
+        }
         tr->bvh_order_valid = false;   // the key arrays hold per-geometry slices now
         tr->classic_nodes_valid = false;
         if (fresh) ++tr->key_scratch_epoch;   // the slices moved
         hipStream_t s = tr->stream;
         static const float kIdA[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, kIdR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kZero[3] = {0, 0, 0};
-        LS_HIP(hipMemsetAsync(tr->d_inst_maxabs, 0, ls::kGeomsPerLaunch * 4, s));
+        // (d_inst_maxabs is zero here: zeroed when it was made and behind every build's read-back, off the next build's path)
         for (size_t i = 0; i < order.size(); ++i) {
             Geometry &ge = *order[i];
             if (!fresh && !ge.blas_dirty) continue;
@@ -208,7 +211,6 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
         static const bool no_treelet = tune_int("LS_TRACE_NO_TREELET", 0) != 0;
         if (order.size() == 1 && tr->inst_layout[0].n_leaves > 1u && !no_treelet) {
             if ((rc = ensure(tr, tr->treelet, (size_t)ls::kTreeletNodes))) return rc;
-            LS_HIP(hipMemsetAsync(tr->treelet.p, 0, (size_t)ls::kTreeletNodes * sizeof(ls::FatNode), s));
             ls::launch_treelet(s, tr->nodes.p + tr->inst_layout[0].node_first, tr->inst_layout[0].n_leaves, tr->treelet.p);
             tr->treelet_valid = true;
         }
@@ -217,6 +219,7 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
         uint32_t bits[ls::kGeomsPerLaunch];
         LS_HIP(hipMemcpyAsync(bits, tr->d_inst_maxabs, sizeof(bits), hipMemcpyDeviceToHost, s));
         LS_HIP(hipStreamSynchronize(s));
+        LS_HIP(hipMemsetAsync(tr->d_inst_maxabs, 0, ls::kGeomsPerLaunch * 4, s));   // for the next build
         for (size_t i = 0; i < order.size(); ++i) {
             Geometry &ge = *order[i];
             if (!fresh && !ge.blas_dirty) continue;

@@ -803,6 +803,11 @@ __global__ __launch_bounds__(kBlock) void k_treelet(const FatNode *__restrict__ 
         __syncthreads();
         done = end;
     }
+    // (a hierarchy of fewer nodes than slots: the rest reads as zero -- no memset in front of this kernel)
+    for (uint32_t slot = min(s_n, kTreeletNodes) + threadIdx.x; slot < kTreeletNodes; slot += kBlock) {
+        float4 *o = out[slot].q;
+        o[0] = o[1] = o[2] = o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
