@@ -329,7 +329,7 @@ int commit_locked(ls_tracer *tr)
         if ((rc = ensure(tr, tr->nodes, (size_t)L))) return rc;
         if ((rc = ensure(tr, tr->sort_temp, ls::sort_temp_bytes(nt)))) return rc;
         if ((rc = ensure(tr, tr->range_boxes, 2 * (size_t)tr->range_entries + 2))) return rc;
-        if ((rc = materialize_scene(tr, true, refit))) return rc;   // (a refit: same layout, same indices as the last build's)
+        if ((rc = materialize_scene(tr, !refit, refit))) return rc;   // (a refit: same layout, same indices as the last build's; nobody reads the extent: k_morton is not run)
         mark(tr, 1);
         if (!refit) ls::launch_morton(s, tr->verts.p, tr->tris.p, nt, tr->d_maxabs, tr->keys_a.p, nullptr, ls::sort_first_counts(tr->sort_temp.p, nt));
         mark(tr, 2);

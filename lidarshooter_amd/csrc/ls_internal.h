@@ -128,6 +128,7 @@ struct ls_tracer {
     bool bvh_built = false;
     lsi::DevBuf<uint32_t> spill;       // traversal-stack overflow area of the persistent trace grid
     uint32_t *d_queue_heads = nullptr;
+    bool queue_heads_armed = false;   // the last BVH frame's k_rowcount zeroed them again
     uint32_t trace_blocks = 0, chan_mul = 1, refill_min = 56;
     // LS_OPT_PIPELINE: the finish + pack workgroups of frame i ride in the launch of frame i+1's k_project;
     // everything a frame in flight touches exists twice (parity), the queue counter three times

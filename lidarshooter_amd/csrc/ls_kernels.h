@@ -214,7 +214,7 @@ void launch_treelet(hipStream_t s, const FatNode *nodes, uint32_t n_leaves, FatN
 void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq, const InstBatch &batch,
                             const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
                             uint32_t *gid_out, uint32_t *spill, unsigned long long *visit_counts /* nullptr = do not count */);
-void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts);
+void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts, uint32_t *queue_heads = nullptr);   // queue_heads: zeroed for the next k_trace
 // Progress of a synchronous frame whose compact points go straight to pinned host memory (ls_trace_scene_begin /
 // ls_trace_scene_expand): the device publishes, with system-scope release, (1) the frame's hit count as the pack pass
 // starts (its first workgroup adds up the finish pass's block counts), together with the number of points the ray blocks

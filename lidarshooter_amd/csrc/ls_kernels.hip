@@ -1010,10 +1010,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
 }
 
 // hits per block of 256 consecutive rays (feeds the ordered pack)
+// (and the ray queues' heads go back to zero for the next frame's k_trace -- the traversal that used them is done: no
+// memset launch in front of a frame)
 __global__ __launch_bounds__(kBlock) void k_rowcount(const uint32_t *__restrict__ gid, uint32_t n,
-                                                     uint32_t *__restrict__ block_counts)
+                                                     uint32_t *__restrict__ block_counts, uint32_t *__restrict__ queue_heads)
 {
     __shared__ uint32_t s_cnt[kBlock / 64];
+    static_assert(kQueues * 16 <= kBlock, "one thread per word of the queue heads");
+    if (blockIdx.x == 0 && queue_heads && threadIdx.x < (uint32_t)kQueues * 16u) queue_heads[threadIdx.x] = 0u;
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     const bool hit = q < n && gid[q] != kInvalid;
     const unsigned long long m = __ballot(hit);
@@ -1469,10 +1473,10 @@ void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t
     hipLaunchKernelGGL(k_quads_to_triangles, dim3(blocks_for(n_quads)), dim3(kBlock), 0, s, quad_idx, n_quads, tri_idx);
 }
 
-void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts)
+void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts, uint32_t *queue_heads)
 {
     if (!nrays) return;
-    hipLaunchKernelGGL(k_rowcount, dim3(blocks_for(nrays)), dim3(kBlock), 0, s, gid, nrays, row_counts);
+    hipLaunchKernelGGL(k_rowcount, dim3(blocks_for(nrays)), dim3(kBlock), 0, s, gid, nrays, row_counts, queue_heads);
 }
 
 void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid, const uint32_t *block_counts,

@@ -749,7 +749,10 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     } else {
         if (!tr->bvh_built) return fail(tr, LS_ERR_NOT_COMMITTED, "the BVH engine was selected after the last commit");
         if ((rc = flush_pipeline(tr))) return rc;
-        LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
+        // the ray queues' heads are zero: the last BVH frame's k_rowcount left them so (a frame that never got that far, or
+        // the first one, zeroes them here)
+        if (!tr->queue_heads_armed) LS_HIP(hipMemsetAsync(tr->d_queue_heads, 0, ls::kQueues * 16 * sizeof(uint32_t), s));
+        tr->queue_heads_armed = false;
         ls::RayQueues rq;
         rq.heads = tr->d_queue_heads;
         rq.chan_mul = tr->chan_mul;
@@ -794,7 +797,8 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                              tr->n_tris, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
         }
         mark(tr, 8);
-        ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p);
+        ls::launch_rowcount(s, tr->hit_gid.p, shard_rays(tr), tr->row_counts.p, tr->d_queue_heads);
+        tr->queue_heads_armed = shard_rays(tr) != 0u;
         tr->keys_armed = false;  // the counter array was just used with the BVH layout
         mark(tr, 9);
         const ls::GeomTable gt = geom_table(tr);
