@@ -19,7 +19,8 @@ constexpr int kStackSpill = 32;      // further entries in global memory (tree d
 
 // 64-byte BVH2 node: both child boxes + both child references (DESIGN.md "BVH layout").
 //   q[0] = (L.lo.x, L.lo.y, L.lo.z, bits(left ref))    q[1] = (L.hi.x, L.hi.y, L.hi.z, bits(right ref))
-//   q[2] = (R.lo.x, R.lo.y, R.lo.z, 0)                 q[3] = (R.hi.x, R.hi.y, R.hi.z, 0)
+//   q[2] = (R.lo.x, R.lo.y, R.lo.z, first leaf)        q[3] = (R.hi.x, R.hi.y, R.hi.z, last leaf)   (the node's leaf range:
+//   the traversal does not read it, a refit -- k_refit_nodes -- does instead of searching)
 // Node i is Karras' internal node i; the left child comes first in Morton order = front to back.
 struct alignas(64) FatNode {
     float4 q[4];
