@@ -71,6 +71,7 @@ struct RayQueues {
     uint32_t chan_mul;             // channels are visited in the order (j * chan_mul) % V (coprime with V)
     uint32_t refill_min;           // idle lanes of a wave that trigger a refill
     const uint32_t *chan_order;    // position in ascending elevation order -> channel (the projection engine's chan_perm); visited from the top ring down
+    uint32_t leaf_wait;            // lanes of a wave that must be standing at a leaf before the wave runs its leaf tests (0: every trip)
 };
 
 // mesh transform A (row-major 3x4), sensor rotation inverse and sensor translation

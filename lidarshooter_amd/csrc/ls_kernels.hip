@@ -710,6 +710,13 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
         }
         if (act == 0ull) break;
         if (COUNT) ++trips;
+        // the leaf tests run when enough lanes stand at a leaf (or nobody has a node to go to): a lane at a leaf waits
+        bool leaf_phase = true;
+        if (rq.leaf_wait) {
+            const unsigned long long at_leaf = __ballot(has && (cur & kLeafBit));
+            const unsigned long long at_node = __ballot(has && !(cur & kLeafBit));
+            leaf_phase = (uint32_t)__popcll(at_leaf) >= rq.leaf_wait || at_node == 0ull;
+        }
         if (has) {
             if (!(cur & kLeafBit)) {
                 const float4 *nd = nodes[cur].q;
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
                     if (sp) { --sp; cur = sp < (uint32_t)kStackLds ? s_stack[sp][tid] : my_spill[sp - kStackLds]; }
                 }
             }
-            while (cur != kInvalid && (cur & kLeafBit)) {
+            while (leaf_phase && cur != kInvalid && (cur & kLeafBit)) {
                 const uint32_t first = (cur & ~kLeafBit) * g;
                 const uint32_t last = min(first + g, ntris);
                 for (uint32_t s = first; s < last; ++s) {
@@ -915,6 +922,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
         }
         if (act == 0ull) break;
         if (COUNT) ++trips;
+        bool leaf_phase = true;
         // one traversal step of this lane in geometry `ig`: a node (both child boxes), then the leaves it leads to
         auto step = [&](const InstGeom &ig) {
             // `ig` is geometry `gi` as this trip started; advance() may move the lane on to another geometry, whose
@@ -958,7 +966,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
             }
             // (a leaf reached above belongs to `ig` unless advance() moved on to another geometry: then the loop does not
             // run and the next trip continues there)
-            while (cur != kInvalid && (cur & kLeafBit) && (SINGLE || gi == at_entry)) {
+            while (leaf_phase && cur != kInvalid && (cur & kLeafBit) && (SINGLE || gi == at_entry)) {
                 const uint32_t first = (cur & ~kLeafBit) * g;
                 const uint32_t last = min(first + g, ig.n_tris);
                 for (uint32_t s = first; s < last; ++s) {
@@ -987,6 +995,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
                 advance();
             }
         };
+        // the leaf tests run when enough lanes stand at a leaf (or nobody has a node to go to): a lane at a leaf waits
+        if (rq.leaf_wait) {
+            const unsigned long long at_leaf = __ballot(has && cur != kInvalid && (cur & kLeafBit));
+            const unsigned long long at_node = __ballot(has && cur != kInvalid && !(cur & kLeafBit));
+            leaf_phase = (uint32_t)__popcll(at_leaf) >= rq.leaf_wait || at_node == 0ull;
+        }
         if (has) {
             if (SINGLE) step(batch.g[0]);
             else step(batch.g[gi]);

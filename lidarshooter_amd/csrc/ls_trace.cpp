@@ -757,6 +757,10 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         rq.heads = tr->d_queue_heads;
         rq.chan_mul = tr->chan_mul;
         rq.refill_min = tr->refill_min;
+        // a wave runs its leaf tests when 16 of its lanes stand at a leaf (or none has a node to go to): the ~200 instructions
+        // of a leaf test are then issued every few trips for many lanes instead of on every trip for a handful
+        // (4 / 8 / 16 / 24 / 32 / 48 lanes: 143.2 / 140.7 / 139.1 / 141.3 / 149.6 / 154.8 us per frame against 153.4 with none)
+        { static const int lw = tune_int("LS_TRACE_LEAF_WAIT", 16); rq.leaf_wait = (uint32_t)std::max(0, std::min(64, lw)); }
         rq.chan_order = reinterpret_cast<const uint32_t *>(tr->d_tables + 4 * (size_t)tr->V + 2 * (size_t)tr->H);   // chan_perm (fill_tables)
         { static const bool no_order = tune_int("LS_TRACE_NO_ORDER", 0) != 0; if (no_order) rq.chan_order = nullptr; }
         mark(tr, 7);
