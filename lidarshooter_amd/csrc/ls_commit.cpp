@@ -41,7 +41,9 @@ int materialize_scene(ls_tracer *tr, bool with_maxabs, bool keep_indices)
 bool cull_enabled(const ls_tracer *tr, const Geometry &g)
 {
     if (tr->opt_block_cull != 2) return tr->opt_block_cull != 0;
-    return g.n_tris >= 2000000u;
+    if (g.n_tris >= 2000000u) return true;
+    double lo, hi;
+    return g.n_tris >= 524288u && shard_sector(tr, lo, hi);
 }
 
 // Group-culling data of one geometry, brought up to date (stream-ordered on the handle's stream).

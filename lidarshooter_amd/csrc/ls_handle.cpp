@@ -304,7 +304,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     for (int i = 0; i < 3; ++i)
         if (tr->slot_stream[i]) (void)hipStreamSynchronize(tr->slot_stream[i]);
     frame_graph_destroy(tr);
-    release(tr->best_keys_b); release(tr->big_queue_b); release(tr->points_b); release(tr->hits_b); release(tr->pack_status);
+    release(tr->best_keys_b); release(tr->big_queue_b); release(tr->points_b); release(tr->hits_b); release(tr->pack_status); release(tr->pack_status_ms);
     release(tr->best_keys_c); release(tr->big_queue_c); release(tr->points_c); release(tr->hits_c);
     if (tr->d_n_points_b) (void)hipFree(tr->d_n_points_b);
     if (tr->d_n_points_c) (void)hipFree(tr->d_n_points_c);

@@ -156,6 +156,9 @@ struct ls_tracer {
     lsi::DevBuf<uint8_t> big_queue_c, points_c, hits_c;
     uint32_t *d_n_points_c = nullptr;
     bool keys_c_armed = false;
+    // three-stream mode, small shards: finish + pack of a frame as ONE launch with the chained prefix (k_finish_pack); per slot
+    // the status words of its ray blocks and, behind them, the tag word the kernel itself steps (FinishPackArgs::epoch_word)
+    lsi::DevBuf<unsigned long long> pack_status_ms;
     bool traced_projection = false;        // the last trace ran on the projection engine (dense arrays on demand)
     const void *last_d_hits = nullptr;     // its hit records and count (device)
     const uint32_t *last_d_n = nullptr;
@@ -197,7 +200,7 @@ struct ls_tracer {
     bool classic_nodes_valid = false;   // tr->nodes holds the classic hierarchy of the keys bvh_order_valid speaks of (k_refit_nodes may reuse its topology)
     uint32_t bvh_order_tris = 0;
     bool last_commit_refit = false;
-    int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (geometries of 2 M triangles or more, cull_enabled)
+    int opt_block_cull = 2;      // LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto (geometries of 2 M triangles or more; from 512 k under an azimuth shard: cull_enabled)
     lsi::DevBuf<uint32_t> cull_list;  // three survivor lists (one per frame that can be in flight) of cull_chunks entries
     uint32_t cull_chunks = 0;
     uint32_t *d_aabb6 = nullptr; // scratch of launch_mesh_order
@@ -312,6 +315,7 @@ void free_geometry(Geometry &g);
 // ls_commit.cpp
 int materialize_scene(ls_tracer *tr, bool with_maxabs, bool keep_indices = false);
 bool cull_enabled(const ls_tracer *tr, const Geometry &g);
+bool shard_sector(const ls_tracer *tr, double &lo_deg, double &hi_deg);   // ls_trace.cpp
 bool inst_inverse(const ls_tracer *tr, const Geometry &ge, double *minv9, double *o3, double *cond);
 int commit_locked(ls_tracer *tr);
 // ls_host_pool.cpp

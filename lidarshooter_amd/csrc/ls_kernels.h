@@ -105,6 +105,8 @@ struct ProjectParams {
     int spread;                    // big meshes: a wave takes its triangles in runs spread over the whole mesh (balances the cells per
                                    // wave: shorter kernel) instead of one contiguous run (fewer cache lines: better with frames overlapping)
     uint32_t xcd_remap;            // one geometry, no culling: workgroup -> triangles so that each XCD streams one contiguous eighth
+    int cols_lds;                  // the shard is at most kColsLdsMax columns: k_project keeps their (cos, sin) in LDS (needs V <= 2048: the channel tables there too)
+    int cull_deal;                 // group culling: a segment's survivors are dealt to its waves at a stride (azimuth shards), not taken in runs
 };
 
 // one geometry as uploaded (xform = 1: vertices still need A / Rinv / t) or the committed scene
@@ -129,6 +131,7 @@ struct GeomSource {
 
 // the geometries of one k_project launch (kernel argument: no upload)
 constexpr int kGeomsPerLaunch = 16;
+constexpr uint32_t kColsLdsMax = 1024;   // columns of a shard whose directions k_project stages in LDS (8 KB)
 struct GeomBatch {
     uint32_t n;
     uint32_t block_first[kGeomsPerLaunch + 1];   // first workgroup of geometry i; [n] = grid size
@@ -257,6 +260,9 @@ struct FinishPackArgs {
     uint32_t *rearm_big_count;      // the counter of the frame after the next: set to 0
     unsigned long long *status;     // per workgroup (epoch << 32) | hits, for the chained prefix
     uint32_t epoch;                 // tag this frame's workgroups wait for
+    uint32_t *epoch_word;           // non-null: the tag lives in device memory instead (read at the start of every workgroup, stepped by
+                                    // the last one when all have published) -- the arguments of a frame are then the same every
+                                    // frame, and a captured frame graph needs no patch for it (three-stream mode, small shards)
     uint32_t publish_epoch;         // tag they publish (== epoch; LS_OPT_DEBUG_FAULT publishes another one)
     uint32_t spin_limit;            // polls before a waiting workgroup gives up and raises device_status
     uint32_t *device_status;        // sticky status word in pinned host memory (bit 0: a chained prefix gave up)
@@ -275,7 +281,7 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
                     const FinishPackArgs *rider = nullptr, uint32_t *cull_list = nullptr, hipEvent_t ev_start = nullptr,
                     hipEvent_t ev_stop = nullptr);   // ev_*: ride on the k_project dispatch (its own begin / end timestamps)
 uint32_t project_tris_per_wave(uint32_t ntris);   // 64 for big meshes, fewer for small ones (more waves than ntris / 64)
-uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs);   // survivor-list words for the geometries with bounds (0: none, or too many for one launch)
+uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs, bool sector);   // survivor-list words for the geometries with bounds (0: none, or too many for one launch)
 // one-off per topology: Morton order of the triangles (centroids in mesh space) -> perm (sorted position -> triangle),
 // idx_sorted; scratch: keys_a/keys_b/vals_a (ntris words each), aabb (6 words), sort temp
 bool launch_mesh_order(hipStream_t s, const uint8_t *verts, uint32_t stride, uint32_t nverts, const uint32_t *idx, uint32_t ntris,

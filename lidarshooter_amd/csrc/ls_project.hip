@@ -69,6 +69,7 @@ struct Foot {
 struct ChanTables {
     const float *tan_up, *tan_dn, *sin_theta, *cos_theta;
     const uint32_t *perm;
+    const float2 *cols;   // (cos phi, sin phi) of the shard's columns [az0, az0 + naz) in LDS (ProjectParams::cols_lds), else nullptr
 };
 
 // The footprint is computed in two steps: band() (elevation -> channel range; run for every triangle --
@@ -221,7 +222,7 @@ __device__ __forceinline__ void test_cell(const ProjectParams &pp, const ChanTab
 {
     // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
     const float st = ct.sin_theta[v];
-    const float2 cs = pp.tb.cs_phi[h];
+    const float2 cs = ct.cols ? ct.cols[h - pp.tb.az0] : pp.tb.cs_phi[h];   // (uniform: a cell trip of a small shard waits for no global load)
     const V3 d = {st * cs.x, st * cs.y, ct.cos_theta[v]};
     float t;
     if (tri_test(d, v0, e1, e2, NgC, t)) {
@@ -327,7 +328,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     // of a worst-case grid were workgroups that found nothing, 120 000 waves to launch and retire -- and a wave whose
     // segment holds more than that comes round again (the loop at the end)
     constexpr uint32_t kPerWave = 64u / kCullGroup;
-    uint32_t n_live = 0, seg = 0, seg_block = 0;
+    uint32_t n_live = 0, n_deal = 0, seg = 0, seg_block = 0;
     uint32_t rank = 0, first_entry = 0;   // CULLED: this wave among its segment's; its lanes' list entry, read ahead
     const uint32_t *seg_list = nullptr;
     if (CULLED) {
@@ -339,9 +340,16 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         // dependent ones (count -> entry -> corners), which is what this kernel's waves spend their time in.  Positions
         // behind the count hold survivors of earlier frames or nothing: read (inside the segment), never used
         seg_list = cull_list + batch.list_first[gi] + (size_t)seg * batch.seg_cap[gi];
-        first_entry = seg_list[min(rank * kPerWave + lane / kCullGroup, batch.seg_cap[gi] - 1u)];
+        if (!pp.cull_deal) first_entry = seg_list[min(rank * kPerWave + lane / kCullGroup, batch.seg_cap[gi] - 1u)];
         n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)big_count[kCullCountAt + (gi * kCullSegs + seg) * 16u]);
-        if (seg_block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
+        // DEALT (pp.cull_deal, azimuth shards): the segment's n_live survivors go to its W = ceil(n_live / kPerWave) waves like
+        // cards -- wave r takes entries r, r + W, r + 2 W ... -- instead of kPerWave consecutive ones each.  Consecutive
+        // survivors are Morton neighbours; a shard's few hundred waves leave the chip three quarters empty, so its kernel
+        // is as long as its heaviest wave, and the waves that hold nothing but the sector's nearest ground walked 12 trips of
+        // 64 cells where the mean is 2.4 (tests/analysis/shard_balance.py: dealt, the heaviest walks 4).  Costs the memory
+        // round trip the read-ahead above saves (the stride needs the count first)
+        n_deal = pp.cull_deal ? (n_live + kPerWave - 1u) / kPerWave : 0u;
+        if (pp.cull_deal ? seg_block * (kBlock / 64) >= n_deal : seg_block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
     }
     // ---- which triangle this lane takes, and its loads, BEFORE the channel tables are staged: index load -> vertex
     //      gather is a chain of two memory round trips, the staging (global -> LDS, then a workgroup barrier) a third
@@ -351,10 +359,16 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     bool live_wave = true;
     if (CULLED) {
         if (COUNT && rank == 0 && lane == 0) atomicAdd(&stats[1], (unsigned long long)n_live);   // counts[2]: surviving groups
-        live_wave = rank * kPerWave < n_live;              // the survivors' last workgroup is partly filled
-        // (a wave takes consecutive survivors; taking them at a stride of the number of live waves, as the unculled path's
-        // spread runs do, was within noise at 10 M triangles and would put the count in front of the entry load again)
-        if (rank * kPerWave + lane / kCullGroup < n_live) k = first_entry * kCullGroup + (lane % kCullGroup);
+        // (a full turn's wave takes consecutive survivors; taking them at a stride, as the unculled path's spread runs do,
+        // was within noise at 10 M triangles and puts the count in front of the entry load again)
+        if (pp.cull_deal) {
+            live_wave = rank < n_deal;
+            const uint32_t e = (lane / kCullGroup) * n_deal + rank;
+            if (live_wave && e < n_live) k = seg_list[e] * kCullGroup + (lane % kCullGroup);
+        } else {
+            live_wave = rank * kPerWave < n_live;              // the survivors' last workgroup is partly filled
+            if (rank * kPerWave + lane / kCullGroup < n_live) k = first_entry * kCullGroup + (lane % kCullGroup);
+        }
     } else {
         // a small mesh is cut into more waves than triangles / 64 (tris_per_wave < 64, the upper lanes only
         // join the cell tests): its footprints are large, and the cells are what takes the time
@@ -393,7 +407,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         }
     };
     load_corners();
-    ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm};
+    ChanTables ct = {pp.chan_tan_up, pp.chan_tan_dn, pp.tb.sin_theta, pp.tb.cos_theta, pp.chan_perm, nullptr};
     if (LDS_TABLES) {
         const uint32_t V = pp.tb.V;
         for (uint32_t i = threadIdx.x; i < V; i += kBlock) {
@@ -403,7 +417,15 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             s_chan[3 * V + i] = pp.tb.cos_theta[i];
             s_chan[4 * V + i] = __uint_as_float(pp.chan_perm[i]);
         }
-        ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V)};
+        ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V), nullptr};
+        if (pp.cols_lds) {
+            // a small shard's column directions too (behind the channel tables, eight-byte aligned): 4 KB for an eighth of
+            // 4 096 columns.  The full raster's 32 KB would cost the kernel its residency (+4 KB of LDS per
+            // workgroup cost 2 us there); a shard's few hundred workgroups leave the chip's LDS empty anyway
+            float2 *s_cols = reinterpret_cast<float2 *>(s_chan + ((5u * V + 1u) & ~1u));
+            for (uint32_t i = threadIdx.x; i < pp.tb.naz; i += kBlock) s_cols[i] = pp.tb.cs_phi[pp.tb.az0 + i];
+            ct.cols = s_cols;
+        }
         __syncthreads();
     }
     if (!live_wave) return;   // (no barrier follows)
@@ -513,8 +535,8 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
     if (!CULLED) break;
     rank += batch.seg_blocks[gi] * (kBlock / 64);   // the segment's next wave-load that nobody else takes
-    if (rank * kPerWave >= n_live) break;
-    const uint32_t e = rank * kPerWave + lane / kCullGroup;
+    if (pp.cull_deal ? rank >= n_deal : rank * kPerWave >= n_live) break;
+    const uint32_t e = pp.cull_deal ? (lane / kCullGroup) * n_deal + rank : rank * kPerWave + lane / kCullGroup;
     k = e < n_live ? seg_list[e] * kCullGroup + (lane % kCullGroup) : 0xFFFFFFFFu;
     load_corners();
     }
@@ -529,7 +551,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k
                                                     unsigned long long *__restrict__ stats, const uint32_t *__restrict__ cull_list)
 {
     __shared__ ProjectLds lds;
-    extern __shared__ float s_chan[];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];
     project_body<COUNT, LDS_TABLES, MULTI, CULLED>(pp, batch, blockIdx.x, lds, s_chan, best, big, big_capacity, big_count, stats, cull_list);
 }
 
@@ -834,6 +856,22 @@ __device__ __forceinline__ bool chan_query(const ChanQuery &cq, float tan_lo, fl
 // er + et <= sqrt 2 rad with the box's radius  rad = nrm (hx (1 + |sx|) + hy (1 + |sy|) + hz),  nrm = the largest
 // singular value of L (1 for a rigid pose; from the host), and the bound is monotone in it.  The same radius bounds the
 // reach of the box seen from above (azimuth-sector test of a shard).  Everything is a bound with slack: approximate rsq / products are fine.
+// the azimuth-sector half of the test below, alone (k_cull's workgroup-level early out): seen from above the box lies inside
+// the disc of radius rad around its centre; it is outside a boundary plane of the shard's sector if the centre is further
+// out than that.  Needs no channel table.
+__device__ __forceinline__ bool box_out_of_sector(const ProjectParams &pp, const LinearMap &m, float4 b0, float4 b1)
+{
+    const float hx = b0.w, hy = b1.x, hz = b1.y, sx = b1.z, sy = b1.w;
+    if (!(hx < INFINITY)) return false;   // unbounded (NaN / infinite coordinates): never rejected
+    const float cx = fmaf(m.l[0], b0.x, fmaf(m.l[1], b0.y, fmaf(m.l[2], b0.z, m.o[0])));
+    const float cy = fmaf(m.l[3], b0.x, fmaf(m.l[4], b0.y, fmaf(m.l[5], b0.z, m.o[1])));
+    const float rho2 = fmaf(cx, cx, cy * cy);
+    if (!(rho2 > 1e-12f) || !(rho2 < INFINITY)) return false;   // on the axis
+    const float rad = m.nrm * fmaf(hx, 1.0f + fabsf(sx), fmaf(hy, 1.0f + fabsf(sy), hz)) * 1.00001f;
+    const float reach = fmaf(rad, 1.0001f, 1e-6f * rho2 * __builtin_amdgcn_rsqf(rho2));
+    return (pp.sec_a[0] * cy - pp.sec_a[1] * cx < -reach) | (cx * pp.sec_b[1] - cy * pp.sec_b[0] < -reach);
+}
+
 template <bool LUT>
 __device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, const ChanQuery &cq, const LinearMap &m, float4 b0, float4 b1)
 {
@@ -876,7 +914,7 @@ __device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, cons
 // host so that the whole pass is ONE round of resident workgroups where it can: at 1 024 groups per workgroup SYN-10M
 // took 2 441 workgroups for 2 048 places -- two rounds of an 8 us workgroup); a workgroup belongs to one geometry
 // (batch.cull_first).  Round `it` of wave w is block  first/64 + 4 it + w  of the mesh -- 64 consecutive groups under one
-// coarse bound: lanes 0..3 of every wave test the wave's four block bounds first and the wave skips, loads included,
+// coarse bound: every wave tests the workgroup's 4 x rounds block bounds first (one per lane) and skips, loads included,
 // the rounds whose block no ring can meet (on SYN-10M 39 % of the blocks; a lone group survives 23 % of the time).
 // Survivors are collected in LDS and appended to one of the geometry's kCullSegs list segments -- workgroup j to
 // segment j % kCullSegs -- with ONE global atomic per workgroup on that segment's counter.
@@ -900,12 +938,20 @@ __global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, CullBatch bat
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t n_groups = (src.ntris + kCullGroup - 1u) / kCullGroup;
     const uint32_t n_blocks = (n_groups + kCullBlockGroups - 1u) / kCullBlockGroups;
-    // the wave's four coarse bounds go out first, before the channel tables are staged: the two waits overlap
+    // The coarse bounds go out first, before the channel tables are staged (the two waits overlap) -- ALL of the workgroup's
+    // 4 x rounds block bounds in every wave (lane j holds block g0 / 64 + j = round j / 4 of wave j % 4; a kilobyte out of the
+    // L2), so that every wave comes to the same answer without a word of LDS: under an azimuth shard a workgroup none of whose
+    // blocks reaches into the sector ends HERE -- before the staging, the barrier and the ring tests.  Seven in eight do for an
+    // eighth of a turn, and at ten million triangles the pass is 1 953 workgroups that would each have filled a slot for a
+    // table staging and a barrier's worth of time.
+    static_assert(kCullMaxRounds * (kBlock / 64) <= 32, "the workgroup's block bounds fit the lanes of one wave, their ballot a word");
     const float4 *__restrict__ block_boxes = src.boxes + 2 * (size_t)n_groups;
-    const uint32_t my_block = g0 / kCullBlockGroups + lane * (kBlock / 64) + w;
-    const bool has_block = lane < rounds && my_block < n_blocks;
+    const uint32_t my_block = g0 / kCullBlockGroups + lane;
+    const bool has_block = lane < rounds * (kBlock / 64) && my_block < n_blocks;
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
     if (has_block) { c0 = block_boxes[2 * (size_t)my_block]; c1 = block_boxes[2 * (size_t)my_block + 1]; }
+    const LinearMap &m = src.m;
+    if (pp.sector_on && !__any(has_block && !box_out_of_sector(pp, m, c0, c1))) return;   // (the same in all four waves: no barrier is left waiting)
     const uint32_t V = pp.tb.V;
     ChanQuery cq = {pp.chan_tan_up, pp.chan_tan_dn, pp.chan_lut, pp.lut_t0, pp.lut_scale, V};
     if (threadIdx.x == 0) s_n = 0;
@@ -925,9 +971,10 @@ __global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, CullBatch bat
         }
     }
     __syncthreads();
-    const LinearMap &m = src.m;
     const bool block_alive = group_meets_raster<LUT>(pp, cq, m, c0, c1);
-    const uint32_t alive = (uint32_t)__ballot(has_block && block_alive) & ((1u << rounds) - 1u);
+    const uint32_t alive_all = (uint32_t)__ballot(has_block && block_alive);
+    uint32_t alive = 0;   // bit `it`: this wave's block of round `it`
+    for (uint32_t it = 0; it < rounds; ++it) alive |= ((alive_all >> (it * (kBlock / 64) + w)) & 1u) << it;
     // the rounds whose block is alive, two at a time: both rounds' bound loads go out first, then the two tests -- straight-
     // line code -- interleave (an odd round out is tested on its own: its partner is a predicated-off copy of itself)
     if (COUNT && lane == 0 && alive) atomicAdd(&stats[2], (unsigned long long)(__popc(alive) * kCullBlockGroups));   // counts[3]: group bounds read
@@ -1083,6 +1130,8 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     const uint32_t q = block_idx * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t n_big = min(*fa.big_count, fa.big_capacity);
+    const uint32_t epoch = fa.epoch_word ? *fa.epoch_word : fa.epoch;
+    const uint32_t publish_epoch = fa.epoch_word ? epoch : fa.publish_epoch;
     unsigned long long key = ~0ull;
     uint32_t v = 0, h = 0, rank = 0;
     V3 d = {0.f, 0.f, 0.f};
@@ -1151,11 +1200,7 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     __syncthreads();
     const uint32_t mine = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     if (threadIdx.x == 0)
-        __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)fa.publish_epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (block_idx == 0) {   // the queue / survivor counters of the frame after the next: nobody reads them now
-        if (threadIdx.x == 0) fa.rearm_big_count[0] = 0u;
-        for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) fa.rearm_big_count[kCullCountAt + i * 16u] = 0u;
-    }
+        __hip_atomic_store(&fa.status[block_idx], ((unsigned long long)publish_epoch << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // hits of all workgroups before this one.  Waiting is rare (every workgroup publishes within a few
     // microseconds of its neighbours unless the queue gather is heavy) and must stay cheap for the ones
     // still working: the polls back off quickly (s_sleep 1, 4, 16, 64, 127, 127, ... x 64 cycles)
@@ -1163,7 +1208,7 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     bool stuck = false;
     for (uint32_t i = threadIdx.x; i < block_idx; i += kBlock) {
         unsigned long long st = __hip_atomic_load(&fa.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t spin = 0; (uint32_t)(st >> 32) != fa.epoch; ++spin) {
+        for (uint32_t spin = 0; (uint32_t)(st >> 32) != epoch; ++spin) {
             if (spin > fa.spin_limit) { stuck = true; break; }   // ~1 s; never seen; keeps a broken premise from hanging the GPU
             if (spin == 0) __builtin_amdgcn_s_sleep(1);
             else if (spin == 1) __builtin_amdgcn_s_sleep(4);
@@ -1181,7 +1226,16 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
     __syncthreads();
     const bool bad = s_part[0] == 0xFFFFFFFFu || s_part[1] == 0xFFFFFFFFu || s_part[2] == 0xFFFFFFFFu || s_part[3] == 0xFFFFFFFFu;
     uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    if (block_idx == fa.n_blocks - 1u && threadIdx.x == 0) *fa.n_points = bad ? 0u : base + mine;
+    if (block_idx == fa.n_blocks - 1u) {
+        if (threadIdx.x == 0) *fa.n_points = bad ? 0u : base + mine;
+        // Every workgroup before this one has published, so each of them has read the queue length (and the tag) and is done
+        // with the queue: the queue / survivor counters are re-armed HERE -- they may be the very ones this frame used (three-
+        // stream mode: a slot's next frame follows in stream order), or those of the frame after the next (rider mode) -- and
+        // a tag in device memory steps on (0 is what fresh status words carry: skipped).
+        if (threadIdx.x == 0) fa.rearm_big_count[0] = 0u;
+        for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) fa.rearm_big_count[kCullCountAt + i * 16u] = 0u;
+        if (fa.epoch_word && threadIdx.x == 0) *fa.epoch_word = epoch + 1u ? epoch + 1u : 1u;
+    }
     if (bad) {
         // the frame is lost: tell the host (checked at its next wait: ls_trace_scene, ls_tracer_synchronize)
         if (threadIdx.x == 0) __hip_atomic_fetch_or(fa.device_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1229,7 +1283,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k
                                                   const uint32_t *__restrict__ cull_list)
 {
     __shared__ ProjectLds lds;
-    extern __shared__ float s_chan[];
+    extern __shared__ __attribute__((aligned(16))) float s_chan[];
     const uint32_t rel = blockIdx.x - fp_start;
     if (rel < fa.n_blocks)
         finish_pack_body<false>(pp, fa, rel, reinterpret_cast<uint32_t *>(&lds), nullptr);
@@ -1331,8 +1385,9 @@ LinearMap linear_map(const GeomSource &src)
 
 // the geometries that carry group bounds, as one batch: false if there are none or more than a launch takes.
 // blocks = k_project's grid (worst case: every group survives), entries = survivor-list words, batch.cull_first[n] = k_cull's grid
-bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch, uint32_t &blocks, uint32_t &entries)
+bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch, uint32_t &blocks, uint32_t &entries, bool sector, uint32_t grid_pct = 0)
 {
+    if (!grid_pct) grid_pct = cull_grid_pct();
     batch.n = 0;
     blocks = entries = 0;
     uint32_t cull_blocks = 0;
@@ -1343,6 +1398,10 @@ bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch
         if (srcs[i].boxes && srcs[i].ntris) all_groups += (srcs[i].ntris + kCullGroup - 1) / kCullGroup;
     uint32_t rounds = 2;
     while (rounds < kCullMaxRounds && (all_groups + (unsigned long long)rounds * kBlock - 1) / ((unsigned long long)rounds * kBlock) > cull_resident_workgroups()) ++rounds;
+    // Under an azimuth shard most workgroups end at their block bounds (k_cull's early out) and the ones that stay are as
+    // long as their rounds, which a wave takes two at a time, each pair a memory round trip and a test behind the other: the
+    // few live workgroups of a shard do better with the shortest chain, whatever the number of workgroups that come and go
+    if (sector) { static const int r = lsi::tune_int("LS_CULL_SHARD_ROUNDS", 2); rounds = (uint32_t)std::min<int>(std::max(r, 2), (int)std::max(rounds, 2u)); }
     batch.cull_rounds = rounds;
     const uint32_t per_wg = rounds * kBlock;
     for (uint32_t i = 0; i < n_srcs; ++i) {
@@ -1359,7 +1418,7 @@ bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch
         batch.seg_cap[batch.n] = seg_cap;
         batch.g[batch.n] = src;
         // k_project's workgroups per segment: room for cull_grid_pct() % of the groups to survive (a wave loops when more do)
-        const uint32_t seg_blocks = std::max(1u, (uint32_t)(((unsigned long long)(seg_cap / kGroupsPerWorkgroup) * cull_grid_pct() + 99u) / 100u));
+        const uint32_t seg_blocks = std::max(1u, (uint32_t)(((unsigned long long)(seg_cap / kGroupsPerWorkgroup) * grid_pct + 99u) / 100u));
         batch.seg_blocks[batch.n] = seg_blocks;
         blocks += kCullSegs * seg_blocks;
         entries += kCullSegs * seg_cap;
@@ -1373,11 +1432,11 @@ bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch
 }
 }  // namespace
 
-uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs)
+uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs, bool sector)
 {
     GeomBatch batch;
     uint32_t blocks, entries;
-    return fill_culled_batch(srcs, n_srcs, batch, blocks, entries) ? entries : 0u;
+    return fill_culled_batch(srcs, n_srcs, batch, blocks, entries, sector) ? entries : 0u;
 }
 
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
@@ -1388,8 +1447,8 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
     TL_HOST_HOOK(s);
     static const int fp_at = lsi::tune_int("LS_PROJECT_FP_AT", -1);
     BigItem *bq = static_cast<BigItem *>(big);
-    const size_t lds = 5 * (size_t)pp.tb.V * sizeof(float);
     const bool lt = pp.tb.V <= 2048u;   // channel tables fit in LDS (40 KB at most)
+    const size_t lds = (((5 * (size_t)pp.tb.V + 1) & ~(size_t)1) + (pp.cols_lds ? 2 * (size_t)pp.tb.naz : 0)) * sizeof(float);
 
     // one launch over `batch` (the previous frame's finish + pack workgroups ride in the first launch of the frame)
     auto launch = [&](const GeomBatch &batch, uint32_t blocks, const uint32_t *list) {
@@ -1434,7 +1493,14 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         GeomBatch batch;
         std::memset(static_cast<void *>(&batch), 0, sizeof(batch));
         uint32_t blocks, entries;
-        if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries)) {
+        // k_project<CULLED>'s grid: room for half of the groups to survive; under an azimuth shard for the shard's share of
+        // the turn (an eighth of a turn: 12 %; a wave whose segment holds more comes round again, so any size is right).
+        // A workgroup that finds nothing still has to be launched, read its segment's count and retire -- and at ten
+        // million triangles half of the groups are 31 744 workgroups, of which an eighth-of-a-turn shard feeds 1 100
+        uint32_t grid_pct = cull_grid_pct();
+        if (pp.sector_on && pp.tb.H) grid_pct = std::max(4u, std::min(grid_pct, (uint32_t)((100ull * pp.tb.naz + pp.tb.H - 1u) / pp.tb.H)));
+        { static const int shard_pct = lsi::tune_int("LS_PROJECT_SHARD_GRID_PCT", 0); if (shard_pct > 0 && pp.sector_on) grid_pct = (uint32_t)shard_pct; }
+        if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries, pp.sector_on != 0, grid_pct)) {
             const dim3 cgrid(batch.cull_first[batch.n]);
             CullBatch cb;
             std::memset(static_cast<void *>(&cb), 0, sizeof(cb));   // (argument bytes are compared frame to frame by the frame graph)
@@ -1533,7 +1599,7 @@ void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPack
 {
     if (!fa.n_blocks) return;
     if (stats) hipLaunchKernelGGL(k_finish_pack<true>, dim3(fa.n_blocks), dim3(kBlock), 0, s, pp, fa, stats);
-    else hipLaunchKernelGGL(k_finish_pack<false>, dim3(fa.n_blocks), dim3(kBlock), 0, s, pp, fa, stats);
+    else launch_k(k_finish_pack<false>, dim3(fa.n_blocks), dim3(kBlock), 0, s, pp, fa, stats);
 }
 
 }  // namespace ls

@@ -36,6 +36,21 @@ ls::GeomTable geom_table(const ls_tracer *tr)
     return gt;
 }
 
+// the shard's azimuth sector [lo, hi] in degrees, padded by the angular margin and 1.5 columns per side; false when the
+// handle traces the full turn or a shard of 179 degrees or more (no sector test then)
+bool shard_sector(const ls_tracer *tr, double &lo, double &hi)
+{
+    lo = hi = 0.0;
+    if (!(tr->naz < tr->H) || tr->h_step == 0.0f) return false;
+    const double step = tr->h_step, pad = kProjectMarginDeg + 1.5 * std::fabs(step);
+    lo = (double)tr->h_begin + step * (double)tr->az0;
+    hi = (double)tr->h_begin + step * (double)(tr->az0 + tr->naz - 1u);
+    if (lo > hi) std::swap(lo, hi);
+    lo -= pad;
+    hi += pad;
+    return hi - lo < 179.0;
+}
+
 ls::ProjectParams project_params(const ls_tracer *tr)
 {
     ls::ProjectParams pp;
@@ -58,17 +73,11 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     // directions in counter-clockwise order; used to reject triangles early when it spans less than 180 degrees
     pp.sector_on = 0;
     pp.sec_a[0] = pp.sec_a[1] = pp.sec_b[0] = pp.sec_b[1] = 0.0f;
-    if (tr->naz < tr->H && pp.step_deg != 0.0f) {
-        const double step = pp.step_deg, pad = kProjectMarginDeg + 1.5 * std::fabs(step);
-        double lo = (double)tr->h_begin + step * (double)tr->az0, hi = (double)tr->h_begin + step * (double)(tr->az0 + tr->naz - 1u);
-        if (lo > hi) std::swap(lo, hi);
-        lo -= pad;
-        hi += pad;
-        if (hi - lo < 179.0) {
-            pp.sector_on = 1;
-            pp.sec_a[0] = (float)std::cos(lo * M_PI / 180.0); pp.sec_a[1] = (float)std::sin(lo * M_PI / 180.0);
-            pp.sec_b[0] = (float)std::cos(hi * M_PI / 180.0); pp.sec_b[1] = (float)std::sin(hi * M_PI / 180.0);
-        }
+    double lo, hi;
+    if (shard_sector(tr, lo, hi)) {
+        pp.sector_on = 1;
+        pp.sec_a[0] = (float)std::cos(lo * M_PI / 180.0); pp.sec_a[1] = (float)std::sin(lo * M_PI / 180.0);
+        pp.sec_b[0] = (float)std::cos(hi * M_PI / 180.0); pp.sec_b[1] = (float)std::sin(hi * M_PI / 180.0);
     }
     static const uint32_t big_cells = (uint32_t)tune_int("LS_PROJECT_BIG_CELLS", 128);
     static const int debug = tune_int("LS_PROJECT_DEBUG", 0);
@@ -76,6 +85,14 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     pp.debug = debug;
     pp.spread = 1;   // trace_locked clears it for frames that overlap on the three slot streams
     pp.xcd_remap = 0;
+    // an azimuth shard's culled launch deals the survivors to its waves (ls_project.hip, DEALT)
+    static const int deal = tune_int("LS_PROJECT_CULL_DEAL", -1);
+    pp.cull_deal = deal >= 0 ? deal : pp.sector_on;
+    static const int cols_lds = tune_int("LS_PROJECT_COLS_LDS", -1);
+    // (off: measured on an eighth of a turn -- at SYN-1M 0.1 - 0.4 us off a frame, at SYN-10M 2 us ON the rank with the
+    // most triangles in its sector: the 4 KB cost two resident workgroups per CU, and its grid is thousands of workgroups
+    // that come and go.  Kept behind the experiment knob.)
+    pp.cols_lds = cols_lds > 0 && tr->naz <= ls::kColsLdsMax && tr->V <= 2048u ? 1 : 0;
     return pp;
 }
 
@@ -244,6 +261,11 @@ int ensure_outputs(ls_tracer *tr)
             if ((rc = ensure(tr, tr->hits_c, nr * 16))) return rc;
         }
         if (!tr->d_n_points_c) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_n_points_c), 4));
+        {
+            const size_t cap1 = tr->pack_status_ms.cap;
+            if ((rc = ensure(tr, tr->pack_status_ms, 3 * ((nr + 255) / 256 + 8)))) return rc;
+            if (tr->pack_status_ms.cap != cap1) tr->keys_armed = false;   // (fresh memory: initialised with the keys)
+        }
         if ((rc = ensure_slot_streams(tr))) return rc;
     }
     if ((tr->opt_pipeline || tr->pipe_seq) && use_projection(tr)) {   // twins: needed as long as the rotation may stand on parity 1
@@ -610,6 +632,12 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             // first frame (or a new shard / raster): key set 0, all queue counters, the block counts.  In three-
             // stream mode the other streams' frames use those counters too: the initialisation completes first
             ls::launch_project_init(s, pp, tr->best_keys.p, tr->d_big_count, tr->row_counts.p);
+            if (tr->pack_status_ms.p) {
+                // no status word carries a tag, every slot's tag word starts at 1 (the regions follow the shard's block count)
+                LS_HIP(hipMemsetAsync(tr->pack_status_ms.p, 0, tr->pack_status_ms.cap * 8, s));
+                for (uint32_t k = 0; k < 3u; ++k)
+                    LS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tr->pack_status_ms.p + (size_t)k * (n_blocks + 8u) + n_blocks), 1, 1, s));
+            }
             if (multi) LS_HIP(hipStreamSynchronize(s));
             tr->keys_armed = true;
             tr->frame_parity = 0;
@@ -671,7 +699,7 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         // survivor list of this frame's k_cull: one of three (as many frames as can be in flight)
         uint32_t *cull_list = nullptr;
         if (any_culled) {
-            const uint32_t entries = ls::project_cull_entries(srcs.data(), (uint32_t)srcs.size());
+            const uint32_t entries = ls::project_cull_entries(srcs.data(), (uint32_t)srcs.size(), pp.sector_on != 0);
             if (entries) {
                 if (entries > tr->cull_chunks) {
                     if ((rc = flush_pipeline(tr))) return rc;
@@ -725,12 +753,46 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list,
                                ev_k0, ev_k1);
             if (!ride) mark(tr, 8);
-            ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
-            mark(tr, 9);
-            // (a frame that reports its progress sends 8-byte (ray, t) records: ls_trace_scene_expand rebuilds the points)
-            ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n,
-                                 progress ? 2u : compact, progress ? &pg : nullptr);
-            mark(tr, 10);
+            // Three-stream mode, a shard of at most kFuseBlocks ray blocks: finish + pack as ONE launch (k_finish_pack: the
+            // chained prefix of rider mode; a few hundred workgroups, all resident at once, publish within a microsecond of
+            // each other).  Each of the two launches it replaces sat at the ~5 us floor of a dependent launch for half a
+            // megabyte of keys; at the full raster's 2 048 blocks the look-back costs more than the second read of the keys
+            // (16.3 - 16.6 us per frame against 15.4) and the two launches stay.
+            static const uint32_t fuse_blocks = (uint32_t)tune_int("LS_FUSE_FINISH_PACK_BLOCKS", 512);
+            // Plain launches only: there the frame is bound by the host's enqueues and a launch less is what pays (an eighth-
+            // of-a-turn shard at SYN-1M: 10.9 - 15.9 -> 8.2 - 11.9 us per frame); inside a captured frame graph a node costs
+            // the host nothing and the look-back's polls cost more than the second read of the keys (8.3 -> 9.1 us, 10.8 -> 12.0
+            // at SYN-10M).
+            const bool graphed = tr->opt_frame_graph && !tr->fg_broken;
+            if (multi && !graphed && n_blocks <= fuse_blocks && tr->pack_status_ms.p) {
+                ls::FinishPackArgs fa;
+                std::memset(static_cast<void *>(&fa), 0, sizeof(fa));   // (padding too: the frame graph compares argument bytes)
+                fa.best = keys;
+                fa.big = bigq;
+                fa.big_capacity = tr->big_capacity;
+                fa.big_count = big_count;
+                fa.rearm_big_count = big_count;   // the slot's own: re-armed by the last workgroup, behind every reader
+                fa.status = tr->pack_status_ms.p + (size_t)slot * (n_blocks + 8u);
+                fa.epoch_word = reinterpret_cast<uint32_t *>(tr->pack_status_ms.p + (size_t)slot * (n_blocks + 8u) + n_blocks);
+                fa.spin_limit = 1u << 18;
+                fa.device_status = tr->h_status;
+                fa.gt = gt;
+                fa.points32 = d_points;
+                fa.hits = d_hits;
+                fa.n_points = d_n;
+                fa.n_blocks = n_blocks;
+                fa.compact = compact;
+                ls::launch_finish_pack(s, pp, fa, nullptr);
+                mark(tr, 9);
+                mark(tr, 10);
+            } else {
+                ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
+                mark(tr, 9);
+                // (a frame that reports its progress sends 8-byte (ray, t) records: ls_trace_scene_expand rebuilds the points)
+                ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n,
+                                     progress ? 2u : compact, progress ? &pg : nullptr);
+                mark(tr, 10);
+            }
             if (multi) {
                 // no event per frame: a flush (or a mesh copy) records one per stream and orders the handle's stream after it
                 tr->slot_pending[slot] = true;

@@ -1,6 +1,7 @@
 // host_capi.cpp -- tiny C entry points over the C++ host mirror so that tests/ and bench.py
 // (Python) can drive LidarDevice / HipTracer / loadPolygonFileSTL exactly as a C++ user would.
 // Exceptions are turned into negative return codes here; nothing else lives in this file.
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -192,6 +193,34 @@ int lsh_stream_frames(void* tracer, const char* const* names, const float* const
         }
         rc = ls_trace_scene_async(tr, frame, &f);
         if (rc < -1) return rc;
+    }
+    return 0;
+}
+
+// lsh_stream_frames with a clock around each of its calls (tools/shard_cost.py: where a frame's host time goes):
+// ns[0] pose updates, ns[1] commit, ns[2] trace -- summed over the frames.
+int lsh_stream_frames_timed(void* tracer, const char* const* names, const float* const* affines, const unsigned* n_affines, unsigned n_meshes,
+                            unsigned first_frame, unsigned n_frames, double* ns3)
+{
+    ls_tracer* tr = static_cast<ls_tracer*>(tracer);
+    ls_frame f;
+    auto now = [] { return std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    ns3[0] = ns3[1] = ns3[2] = 0.0;
+    for (unsigned k = 0; k < n_frames; ++k) {
+        const unsigned frame = first_frame + k;
+        const double t0 = now();
+        for (unsigned m = 0; m < n_meshes; ++m) {
+            const int rc = ls_update_geometry_transform(tr, names[m], affines[m] + 12u * (n_affines[m] ? frame % n_affines[m] : 0u));
+            if (rc < 0) return rc;
+        }
+        const double t1 = now();
+        int rc = ls_commit_scene(tr);
+        if (rc < -1) return rc;
+        const double t2 = now();
+        rc = ls_trace_scene_async(tr, frame, &f);
+        if (rc < -1) return rc;
+        const double t3 = now();
+        ns3[0] += t1 - t0; ns3[1] += t2 - t1; ns3[2] += t3 - t2;
     }
     return 0;
 }

@@ -1,5 +1,6 @@
 """Culling in the projection engine (LS_OPT_BLOCK_CULL: Morton-ordered mesh; a bound per 4 triangles and k_cull, which
-drops groups no ring / no shard column can meet -- forced on here, auto takes it from 2 M triangles) must not change a
+drops groups no ring / no shard column can meet -- forced on here, auto takes it from 2 M triangles, and from 512 k under
+an azimuth shard narrower than half a turn) must not change a
 single bit: culled == unculled == BVH
 engine on the headline-sized scene under moving transforms, vertex updates, azimuth shards and both frames-in-flight modes."""
 import numpy as np
@@ -29,7 +30,7 @@ def test_cull_equals_unculled_under_transforms_and_shards(oracle, capi, sensors)
     from lidarshooter_amd import synth
     v, t = synth.syn_1m()
     s = _syn_sensor(oracle, sensors, V=128, H=4096)
-    # on: group culling forced; auto: the size rule (from 2 M triangles: not here); off
+    # on: group culling forced; auto: the size rule (from 2 M triangles: not here; from 512 k under a narrow shard: here); off
     on, auto, off = make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection")
     on.setOption(capi.LS_OPT_BLOCK_CULL, 1)
     off.setOption(capi.LS_OPT_BLOCK_CULL, 0)
@@ -60,6 +61,15 @@ def test_cull_equals_unculled_under_transforms_and_shards(oracle, capi, sensors)
         ref = _frame(off)
         _same(_frame(on), ref)
         _same(_frame(auto), ref)
+    # the auto rule (cull_enabled, ls_commit.cpp): a geometry of 512 k triangles or more is culled under a shard narrower than
+    # half a turn (k_cull's counters run), not on the full turn or a half turn
+    auto.setOption(capi.LS_OPT_COUNT_VISITS, 1)
+    for (first, n), culls in (((512, 512), True), ((0, 4096), False), ((0, 2048), False), ((3900, 196), True)):
+        auto.setShard(first, n)
+        _frame(auto)
+        survivors, bounds_read = auto.visitStats()[2:4]
+        assert (survivors > 0 and bounds_read > 0) == culls, (first, n, survivors, bounds_read)
+    auto.setOption(capi.LS_OPT_COUNT_VISITS, 0)
     # shards of a moved mesh, rigid or not
     seen = 0
     for A in (oracle.affine_from_components(np.array((12.0, -30.0, 0.8), np.float32), np.array((0.05, -0.02, 2.4), np.float32)),
@@ -162,6 +172,68 @@ def test_cull_with_frames_in_flight(oracle, capi, sensors, mode):
                 assert np.array_equal(p.cpu().numpy()[:32 * cnt].reshape(cnt, 32), pts)
                 got = h.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4)
                 assert np.array_equal(got, np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1))
+    tr.close()
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_streamed_shard_equals_the_synchronous_unculled_one(oracle, capi, sensors, graph):
+    """What one of eight ranks runs (tools/shard_cost.py): an eighth-of-a-turn shard of SYN-128 over SYN-1M, three frames in
+    flight, the auto rule's culling (k_cull's sector early out, survivors dealt to the waves), finish + pack as ONE launch
+    with the chained prefix under plain launches / as two nodes inside captured frame graphs; a pose that changes every
+    frame, the shard moved in mid-stream (the status words and their tag follow the new block count).  Every frame's hit
+    records and points equal those of a synchronous, unculled frame of the same shard and pose."""
+    import torch
+    from lidarshooter_amd import synth
+    v, t = synth.syn_1m()
+    s = _syn_sensor(oracle, sensors, V=128, H=4096)
+    dev = torch.device("cuda", 0)
+    dv = torch.from_numpy(v).to(dev)
+    dt = torch.from_numpy(t.view(np.int32)).to(dev)
+    poses = [oracle.affine_from_components(np.array((0.9 * k, -0.3 * k, 0.04 * k), np.float32), np.array((0.0, 0.01 * k, 0.15 * k), np.float32))
+             for k in range(5)]
+    shards = ((2048, 512), (0, 512), (3584, 512), (1000, 300))
+    ref_tr = make_tracer(capi, s, "projection")
+    ref_tr.setOption(capi.LS_OPT_BLOCK_CULL, 0)
+    ref_tr.addGeometry("g", v.shape[0], t.shape[0])
+    ref_tr.updateGeometryDeviceShared("g", poses[0], dv.data_ptr(), 12, dt.data_ptr())
+    refs = {}
+    for first, n in shards:
+        ref_tr.setShard(first, n)
+        for k, A in enumerate(poses):
+            ref_tr.updateGeometryTransform("g", A)
+            refs[(first, n, k)] = _frame(ref_tr)[1:]
+    ref_tr.close()
+    tr = make_tracer(capi, s, "projection")
+    tr.setOption(capi.LS_OPT_PIPELINE, 2)
+    tr.setOption(capi.LS_OPT_FRAME_GRAPH, graph)
+    tr.addGeometry("g", v.shape[0], t.shape[0])
+    tr.updateGeometryDeviceShared("g", poses[0], dv.data_ptr(), 12, dt.data_ptr())
+    cap = s.V * 512
+    bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device=dev), torch.zeros(16 * cap, dtype=torch.uint8, device=dev),
+             torch.zeros(4, dtype=torch.int32, device=dev)) for _ in range(3)]
+    total = 0
+    for first, n in shards:
+        tr.setShard(first, n)
+        for i in range(15):
+            tr.updateGeometryTransform("g", poses[i % 5])
+            assert tr.commitScene() == 0
+            p, h, cnt = bufs[i % 3]
+            tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), cnt.data_ptr(), cap)
+            tr.traceSceneAsync(i)
+            if i % 3 == 2:
+                tr.synchronize()
+                for k in (i - 2, i - 1, i):
+                    p, h, cnt = bufs[k % 3]
+                    pts, hits = refs[(first, n, k % 5)]
+                    c = int(cnt[0].item())
+                    assert c == pts.shape[0], (first, n, k, c, pts.shape[0])
+                    assert np.array_equal(p.cpu().numpy()[:32 * c].reshape(c, 32), pts)
+                    got = h.cpu().numpy()[:16 * c].view(np.uint32).reshape(c, 4)
+                    assert np.array_equal(got, np.stack([hits["ray"], hits["geom"], hits["prim"], hits["t"].view(np.uint32)], axis=1))
+                    total += c
+    assert total > 100000
+    if graph:
+        assert tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS) >= 4 * 12
     tr.close()
 
 
