@@ -78,6 +78,12 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
  *                                   (ls_group_info: LS_GROUP_INFO_TRUNCATED_FRAMES), never a short cloud as if it were complete.
  *                                   Off by default: the fixed slots are latency-bound at 1 M triangles. */
 #define LS_GROUP_FLAG_SIZED_GATHER 4u
+/* The arrangement (per-set communicators, frames as graphs) is agreed on by the ranks at create: each rank says what it can do
+ * -- its communicator duplicates exist, its tracer found three concurrent streams (a timing calibration) -- the answers are
+ * gathered over the first communicator and every rank takes the AND (LS_GROUP_INFO_ARRANGEMENT_MINE / _COMMON): a rank that
+ * fell back alone would issue its collectives on another communicator than its peers and the group would hang.
+ *   LS_GROUP_FLAG_DEBUG_PEER_REFUSES  test only: the gathered answers are treated as if a peer had answered "neither" */
+#define LS_GROUP_FLAG_DEBUG_PEER_REFUSES 0x100u
 int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, uint32_t flags, ls_tracer *tr,
                          ls_group **out);
 void ls_group_destroy(ls_group *g);
@@ -90,6 +96,11 @@ int ls_group_owns_frame(const ls_group *g, uint32_t frame_index);
 /* The whole frame's cloud on this rank: device pointers (points32, hits, count word), complete once the group's
  * collective stream has drained (ls_group_synchronize) -- buffers are reused three frames later. */
 int ls_group_cloud(ls_group *g, uint32_t frame_index, ls_frame *out);
+/* Whether that frame's cloud is complete -- to be asked after ls_group_synchronize (or any wait that covers the frame) by a
+ * caller that reads ls_group_cloud's device pointers itself: LS_OK, or LS_ERR_OUT_OF_RANGE when LS_GROUP_FLAG_SIZED_GATHER
+ * truncated it (ls_group_download_cloud checks this itself), or when the frame's buffers have been reused.  Without the flag
+ * every frame is complete.  Returns LS_ERR_NOT_COMMITTED while the frame's rebuild has not finished. */
+int ls_group_frame_status(ls_group *g, uint32_t frame_index);
 /* The same cloud copied to host memory (waits for the frame): points32 takes 32 bytes per point, hits 16 (either may
  * be NULL); returns the number of points or a negative ls_status.  capacity in points. */
 long ls_group_download_cloud(ls_group *g, uint32_t frame_index, void *points32, void *hits, uint32_t capacity);
@@ -102,7 +113,10 @@ int ls_group_synchronize(ls_group *g);
 #define LS_GROUP_INFO_PER_SET 5        /* 1: per-set mode (see the top of this header)                            */
 #define LS_GROUP_INFO_FRAME_GRAPH 6    /* the tracer's LS_INFO_FRAME_GRAPH_STATE: 0 off, 1 frames are graph launches, 2 refused */
 #define LS_GROUP_INFO_GATHER_CAPACITY 7   /* records of every slot that travel per frame now (the slot capacity unless SIZED_GATHER) */
-#define LS_GROUP_INFO_TRUNCATED_FRAMES 8  /* SIZED_GATHER: frames seen so far whose hits outgrew the gather                           */
+#define LS_GROUP_INFO_TRUNCATED_FRAMES 8  /* SIZED_GATHER: frames whose hits outgrew the gather -- those counted when their set was reused plus
+                                           * the finished ones among the (at most three) frames still held                            */
+#define LS_GROUP_INFO_ARRANGEMENT_MINE 9    /* what this rank could do: bit 0 a communicator per set, bit 1 three concurrent streams  */
+#define LS_GROUP_INFO_ARRANGEMENT_COMMON 10 /* the AND over all ranks: what the group runs                                            */
 long ls_group_info(ls_group *g, int what);
 const char *ls_group_last_error(const ls_group *g);
 

@@ -282,6 +282,11 @@ int ls_tracer_next_frame_waits(ls_tracer *tr, void *hip_event);
  * >= ls_total_rays of the shard) instead of the handle's own; NULL restores the default. */
 int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, uint32_t *d_n_points,
                                  uint32_t capacity);
+/* The same for hit records alone (LS_OPT_EMIT_POINTS = 0: a sharded group rebuilds the points of the whole frame from the
+ * gathered records, include/lidarshooter_group.h): no point buffer exists, so while these buffers are installed
+ * LS_OPT_EMIT_POINTS = 1 is refused, and a trace with it set fails with LS_ERR_INVALID_ARGUMENT instead of writing 32 bytes
+ * per hit through a pointer that was never meant for them.  NULL d_hits restores the default. */
+int ls_tracer_set_hit_buffers(ls_tracer *tr, void *d_hits, uint32_t *d_n_points, uint32_t capacity);
 
 /* ---- options */
 #define LS_OPT_LEAF_SIZE 1      /* triangles per BVH leaf (1,2,4,8), default 1; takes effect at next commit  */
@@ -398,6 +403,8 @@ int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
 #define LS_INFO_FRAME_GRAPH_REPLAYS 11  /* frames issued as one graph launch                                              */
 #define LS_INFO_FRAME_GRAPH_PATCHES 12  /* kernel nodes patched with new arguments before a replay                        */
 #define LS_INFO_FRAME_GRAPH_LAST_PATCHED 13 /* bit i: launch i of the frame replayed last went out with new arguments     */
+#define LS_INFO_EMIT_POINTS 14       /* the current LS_OPT_EMIT_POINTS                                            */
+#define LS_INFO_FRAME_GRAPH_PATCH_WAITS 15 /* patches that first had to wait for the previous launch of their graph (the host ran more than three frames ahead) */
 long ls_get_info(ls_tracer *tr, int what);
 
 /* Mean stage durations (milliseconds, hipEvents on the handle's stream) over every frame recorded

@@ -109,7 +109,7 @@ public:
             _meshes.erase(_meshName);
             setGeometryCount(getGeometryCount() - 1);
         }
-        if (rc < -1) throw TraceException(__FILE__, ls_last_error(_handle), rc);   // the commit inside failed, as commitScene() reports it
+        if (rc < -1) throwCommitError(rc);   // the commit inside failed, as commitScene() reports it
         return rc;
     }
 
@@ -138,7 +138,7 @@ public:
     {
         std::lock_guard<std::mutex> lock(_mutex);
         const int rc = ls_commit_scene(_handle);
-        if (rc < -1) throw TraceException(__FILE__, ls_last_error(_handle), rc);
+        if (rc < -1) throwCommitError(rc);
         return rc;
     }
 
@@ -673,6 +673,15 @@ public:
 private:
 
     std::mutex _mutex;   // add/remove come from the GUI thread, update/commit/trace from the ROS spinner (mainwindow.cpp:153,320)
+    /// a failed commit: LS_ERR_OUT_OF_RANGE is the library refusing a mesh -- a triangle names a vertex the geometry does not
+    /// have; Embree would read it out of the shared buffers unchecked (EmbreeTracer.cpp:140-176), the GPU would fault --
+    /// which is what BadGeometryException (Exceptions.hpp:143-157) is for; anything else stays a TraceException
+    [[noreturn]] void throwCommitError(int rc)
+    {
+        if (rc == LS_ERR_OUT_OF_RANGE) throw BadGeometryException(__FILE__, ls_last_error(_handle), rc, RTC_GEOMETRY_TYPE_TRIANGLE);
+        throw TraceException(__FILE__, ls_last_error(_handle), rc);
+    }
+
     std::map<std::string, MeshState> _meshes;
     MeshPolicy _policy_ = MeshPolicy::UploadAlways;
     std::uint64_t _uploads = 0, _skipped = 0;

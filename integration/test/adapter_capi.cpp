@@ -50,8 +50,9 @@ const char* lsa_last_error(void);
 }
 #pragma GCC visibility pop
 
+// (-200: the adapter threw BadGeometryException -- the library refused a mesh)
 #define LSA_TRY(expr)                                                          \
-    try { return (expr); } catch (const std::exception& e) { g_error = e.what(); return -100; }
+    try { return (expr); } catch (const BadGeometryException& e) { g_error = e.what(); return -200; } catch (const std::exception& e) { g_error = e.what(); return -100; }
 
 #pragma GCC visibility push(default)
 extern "C" {

@@ -25,6 +25,7 @@ LS_OPT_UPLOAD_MODE = 13
 LS_OPT_FRAME_GRAPH = 14
 LS_OPT_EMIT_POINTS = 15
 LS_INFO_FRAME_GRAPH_LAST_PATCHED = 13
+LS_INFO_EMIT_POINTS, LS_INFO_FRAME_GRAPH_PATCH_WAITS = 14, 15
 LS_INFO_NEXT_SLOT, LS_INFO_FRAME_GRAPH_STATE, LS_INFO_FRAME_GRAPH_CAPTURES, LS_INFO_FRAME_GRAPH_REPLAYS, LS_INFO_FRAME_GRAPH_PATCHES = 8, 9, 10, 11, 12
 LS_GEOMETRY_TYPE_TRIANGLE, LS_GEOMETRY_TYPE_QUAD = 0, 1
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("direction", "<f4", 3), ("tmax", "<f4")])   # Ray.hpp:16-35
@@ -41,7 +42,7 @@ SYMBOLS = (
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
     "ls_total_channels", "ls_last_error", "ls_tracer_set_shard", "ls_tracer_set_stream",
-    "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
+    "ls_tracer_synchronize", "ls_tracer_flush", "ls_tracer_set_output_buffers", "ls_tracer_set_hit_buffers", "ls_expand_gathered_hits", "ls_expand_gathered_hits_on", "ls_cloud_to_world", "ls_tracer_set_option", "ls_get_timings",
     "ls_get_visit_counts", "ls_generate_rays", "ls_generate_rays_aos", "ls_geometry_type", "ls_tracer_order_after_last_frame", "ls_tracer_wait_event", "ls_tracer_next_frame_waits", "ls_trace_scene_begin", "ls_trace_scene_expand",
     "ls_frame_graph_begin", "ls_frame_graph_stream", "ls_frame_graph_end", "ls_frame_graph_reset",
     "ls_tracer_set_sensor", "ls_tracer_set_sensor_tables", "ls_expand_gathered_hits_sized",
@@ -145,6 +146,7 @@ def load() -> C.CDLL:
     L.ls_tracer_set_stream.argtypes = [vp, vp]
     L.ls_tracer_synchronize.argtypes = [vp]
     L.ls_tracer_set_output_buffers.argtypes = [vp, vp, vp, vp, u32]
+    L.ls_tracer_set_hit_buffers.argtypes = [vp, vp, vp, u32]
     L.ls_expand_gathered_hits.argtypes = [vp, vp, u32, u32, vp, vp, vp]
     L.ls_expand_gathered_hits_on.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
     L.ls_cloud_to_world.argtypes = [vp, f32p, f32p, vp, vp, vp, vp, vp, u32]
@@ -352,6 +354,9 @@ class Tracer:
     def setOutputBuffers(self, d_points: int | None, d_hits: int | None, d_n: int | None, capacity: int):
         return self._check(self.L.ls_tracer_set_output_buffers(self.h, d_points, d_hits, d_n, capacity),
                            "ls_tracer_set_output_buffers")
+
+    def setHitBuffers(self, d_hits: int | None, d_n: int | None, capacity: int):
+        return self._check(self.L.ls_tracer_set_hit_buffers(self.h, d_hits, d_n, capacity), "ls_tracer_set_hit_buffers")
 
     def expandGatheredHits(self, d_gathered: int, world: int, capacity: int, d_points: int, d_hits: int, d_n: int):
         return self._check(self.L.ls_expand_gathered_hits(self.h, d_gathered, world, capacity, d_points, d_hits, d_n),

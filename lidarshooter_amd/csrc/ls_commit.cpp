@@ -236,12 +236,46 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
     return LS_OK;
 }
 
+// Index uploads since the last commit: their maxima come back (one wait for all of them), and a geometry whose triangles
+// name a vertex it does not have fails the commit -- LS_ERR_OUT_OF_RANGE, nothing is built or traced over it, the handle
+// stays usable, new indices (or ls_remove_geometry) clear the condition.  Reference: shared buffers, no check
+// (EmbreeTracer.cpp:140-176); there a bad index is a wild host read, here it would be a device memory fault.
+static int check_geometry_indices(ls_tracer *tr)
+{
+    std::vector<Geometry *> pending;
+    for (auto &kv : tr->geoms)
+        if (kv.second.idx_unchecked && kv.second.d_idx_max) pending.push_back(&kv.second);
+    if (!pending.empty()) {
+        std::vector<uint32_t> maxima(pending.size(), 0u);
+        for (size_t i = 0; i < pending.size(); ++i)
+            LS_HIP(hipMemcpyAsync(&maxima[i], pending[i]->d_idx_max, 4, hipMemcpyDeviceToHost, tr->stream));
+        LS_HIP(hipStreamSynchronize(tr->stream));
+        for (size_t i = 0; i < pending.size(); ++i) {
+            Geometry &g = *pending[i];
+            g.idx_unchecked = false;
+            g.idx_bad = g.n_tris > 0 && maxima[i] >= g.n_verts;
+            g.idx_bad_value = maxima[i];
+        }
+    }
+    for (auto &kv : tr->geoms) {
+        const Geometry &g = kv.second;
+        if (g.idx_bad && g.has_idx)
+            return fail(tr, LS_ERR_OUT_OF_RANGE, ("geometry '" + g.name + "': vertex index " + std::to_string(g.idx_bad_value) + " in its triangles, " +
+                                                      std::to_string(g.n_verts) + " vertices registered -- refused (it would fault the device)").c_str());
+    }
+    return LS_OK;
+}
+
 int commit_locked(ls_tracer *tr)
 {
     tr->committed = false;
     tr->traced = false;
     tr->bvh_built = false;
     tr->scene_materialized = false;
+    {
+        const int rc = check_geometry_indices(tr);
+        if (rc) return rc;
+    }
     // layout: geometries with data, in geomID order, so that the global triangle id orders
     // triangles by (geomID, primID) -- the tie-break key of equal-t hits.
     std::vector<Geometry *> order;

@@ -42,8 +42,14 @@ __device__ __forceinline__ bool tri_test(V3 d, V3 v0, V3 e1, V3 e2, float NgC, f
     const float U = xor_sign(dot_fma(R, e2), sgn);
     const float V = xor_sign(dot_fma(R, e1), sgn);
     const float T = xor_sign(NgC, sgn);
-    const bool ok = (den != 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= absDen) & (0.0f < T);
-    if (ok) t = T / absDen;
+    bool ok = (den != 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= absDen) & (0.0f < T);
+    if (ok) {
+        t = T / absDen;
+        // a quotient that overflowed (coordinates of 1e18 metres: Ng . v0 is past FLT_MAX) is no hit: the oracle keeps a hit
+        // only if t < its running closest, which starts at +inf (ls_oracle.c:closest_brute) -- so nothing is ever hit "at
+        // infinity" (tests/test_gpu_parity.py::test_non_finite_and_huge_vertices)
+        ok = t < INFINITY;
+    }
     return ok;
 }
 

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -86,8 +87,10 @@ struct ls_group {
     // set b's frame (trace, gather, rebuild) lives on ONE stream, the tracer's slot stream b, and is one graph launch
     ncclComm_t comm_dup[kSets - 1] = {};
     bool per_set = false;
+    uint32_t arrangement_mine = 0, arrangement_common = 0;   // agree_on_arrangement: this rank's answer, the AND over the ranks
     uint32_t flags = 0;
     long frame_graph_before = 0;           // the tracer's LS_OPT_FRAME_GRAPH as the group found it
+    int emit_points_before = 1;            // ... and its LS_OPT_EMIT_POINTS
     bool frame_graph_set = false;          // ... and whether the group changed it
     uint32_t set_frame[kSets] = {};        // which frame each set holds
     bool set_valid[kSets] = {};
@@ -104,7 +107,7 @@ struct ls_group {
     bool used[kSets] = {};
     uint32_t capacity = 0, cloud_capacity = 0;
     size_t slot_bytes = 0;
-    uint8_t *slot[kSets] = {}, *gathered[kSets] = {}, *local_points = nullptr;
+    uint8_t *slot[kSets] = {}, *gathered[kSets] = {};
     uint8_t *cloud_points[kSets] = {}, *cloud_hits[kSets] = {};
     uint32_t *cloud_n[kSets] = {};
     std::string err;
@@ -194,7 +197,7 @@ void ls_group_destroy(ls_group *g)
             (void)ls_tracer_set_option(g->tr, LS_OPT_FRAME_GRAPH, (int)g->frame_graph_before);
         }
         (void)ls_tracer_set_output_buffers(g->tr, nullptr, nullptr, nullptr, 0);
-        (void)ls_tracer_set_option(g->tr, LS_OPT_EMIT_POINTS, 1);
+        (void)ls_tracer_set_option(g->tr, LS_OPT_EMIT_POINTS, g->emit_points_before);
         (void)ls_tracer_set_option(g->tr, LS_OPT_PIPELINE, (int)g->pipeline_before);
         (void)ls_tracer_set_stream(g->tr, nullptr);   // back on its own stream before the group's streams go
         if (g->full_turn) (void)ls_tracer_set_shard(g->tr, 0, g->full_turn);
@@ -213,7 +216,6 @@ void ls_group_destroy(ls_group *g)
     }
     for (GatherStat *&st : g->h_stat)
         if (st) { (void)hipHostFree(st); st = nullptr; }
-    (void)hipFree(g->local_points);
     if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
     delete g;
 }
@@ -239,6 +241,28 @@ ncclComm_t duplicate_comm(ls_group *g, hipStream_t s)
     (void)hipFree(d);
     if (ok) ok = R.CommInitRank(&dup, (int)g->world, u, (int)g->rank) == ncclSuccess;
     return ok ? dup : nullptr;
+}
+
+// What every rank decided for itself about the group's arrangement -- `mine`: bit 0 "I hold a communicator per buffer set",
+// bit 1 "my tracer runs three frames on three streams" -- gathered over the first communicator: -> the AND over the ranks, or
+// negative.  A rank alone in an arrangement would issue its collectives on another communicator than its peers and the group
+// would hang at its first frame: one of the two inputs is a timing measurement (ensure_slot_streams'
+// calibration), the other a library call that can fail on one rank only.
+int agree_on_arrangement(ls_group *g, uint32_t mine)
+{
+    uint32_t *d = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d), 4u * (g->world + 1u)) != hipSuccess) return LS_ERR_HIP;
+    std::vector<uint32_t> all(g->world, 0u);
+    bool ok = hipMemcpyAsync(d + g->world, &mine, 4, hipMemcpyHostToDevice, g->comm_stream) == hipSuccess &&
+              rccl().AllGather(d + g->world, d, 4, ncclUint8, g->comm, g->comm_stream) == ncclSuccess &&
+              hipMemcpyAsync(all.data(), d, 4u * g->world, hipMemcpyDeviceToHost, g->comm_stream) == hipSuccess &&
+              hipStreamSynchronize(g->comm_stream) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return LS_ERR_HIP;
+    uint32_t common = ~0u;
+    for (uint32_t v : all) common &= v;
+    if (g->flags & LS_GROUP_FLAG_DEBUG_PEER_REFUSES) common = 0u;
+    return (int)(common & 3u);
 }
 }  // namespace
 
@@ -298,9 +322,8 @@ int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, ui
                     if (c) { (void)rccl().CommDestroy(c); c = nullptr; }
             g->per_set = all;
         }
-        // (the shard's own 32-byte points are never written: LS_OPT_EMIT_POINTS = 0 below -- every rank rebuilds the whole
-        // frame's points from the gathered hit records; the pointer only has to be a valid one)
-        if (hipMalloc(reinterpret_cast<void **>(&g->local_points), 256) != hipSuccess) return bail(LS_ERR_HIP);
+        // (the shard's own 32-byte points are never written: LS_OPT_EMIT_POINTS = 0 below, hit buffers alone are installed
+        // per frame -- ls_tracer_set_hit_buffers -- and every rank rebuilds the whole frame's points from the gathered records)
         for (int i = 0; i < kSets; ++i) {
             if (hipMalloc(reinterpret_cast<void **>(&g->slot[i]), g->slot_bytes) != hipSuccess ||
                 hipMalloc(reinterpret_cast<void **>(&g->gathered[i]), g->slot_bytes * world) != hipSuccess)
@@ -325,9 +348,27 @@ int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, ui
     // collective stream waits for that frame alone (ls_tracer_order_after_last_frame), never for the tracer as a whole
     if (ls_tracer_set_option(tr, LS_OPT_PIPELINE, 2) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
     if (ls_tracer_set_shard(tr, first, n) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_INVALID_ARGUMENT); }
+    g->emit_points_before = ls_get_info(tr, LS_INFO_EMIT_POINTS) == 0 ? 0 : 1;
     if (mode == LS_GROUP_SHARDED && ls_tracer_set_option(tr, LS_OPT_EMIT_POINTS, 0) != LS_OK) { g->err = ls_last_error(tr); return bail(LS_ERR_HIP); }
-    // (every rank has the same device and library, so every rank arrives at the same answer here)
-    const bool three_streams = ls_get_info(tr, LS_INFO_PIPELINE_MODE) == 2;
+    // (hit buffers alone from the start -- every frame installs its own set's -- so that LS_OPT_EMIT_POINTS = 1 is refused for
+    // as long as the group holds the tracer)
+    if (mode == LS_GROUP_SHARDED && ls_tracer_set_hit_buffers(tr, g->slot[0] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[0]), g->capacity) != LS_OK) {
+        g->err = ls_last_error(tr);
+        return bail(LS_ERR_HIP);
+    }
+    bool three_streams = ls_get_info(tr, LS_INFO_PIPELINE_MODE) == 2;
+    if (mode == LS_GROUP_SHARDED && !(flags & LS_GROUP_FLAG_ONE_COMMUNICATOR)) {
+        // the arrangement is the GROUP's, not a rank's: every rank takes what all of them can do (agree_on_arrangement)
+        const int common = agree_on_arrangement(g, (g->per_set ? 1u : 0u) | (three_streams ? 2u : 0u));
+        if (common < 0) { g->err = "the ranks could not agree on the group's arrangement (all-gather over the first communicator failed)"; return bail(LS_ERR_HIP); }
+        g->arrangement_mine = (g->per_set ? 1u : 0u) | (three_streams ? 2u : 0u);
+        g->arrangement_common = (uint32_t)common;
+        if (!(common & 1) && g->per_set)
+            for (ncclComm_t &c : g->comm_dup)
+                if (c) { (void)rccl().CommDestroy(c); c = nullptr; }
+        g->per_set = (common & 1) != 0;
+        three_streams = three_streams && (common & 2);   // (a rank with three streams among ranks without runs the one-communicator path like them)
+    }
     g->per_set = g->per_set && three_streams;
     if (g->per_set && (flags & LS_GROUP_FLAG_SIZED_GATHER)) {
         g->sized = true;
@@ -409,8 +450,7 @@ int trace_per_set(ls_group *g, uint32_t frame_index)
             const int rc_size = size_gather(g, b);
             if (rc_size != LS_OK) return rc_size;
         }
-        if (ls_tracer_set_output_buffers(g->tr, g->local_points, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]),
-                                         g->capacity) != LS_OK)
+        if (ls_tracer_set_hit_buffers(g->tr, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]), g->capacity) != LS_OK)
             return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
         // (the tag names what the caller adds to the graph: this group, and how many bytes its collective moves)
         if (ls_frame_graph_begin(g->tr, reinterpret_cast<uintptr_t>(g) + (g->sized ? g->gcap : 0u)) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
@@ -495,8 +535,7 @@ int ls_group_trace(ls_group *g, uint32_t frame_index)
     g->set_valid[b] = true;
     // the set's previous frame (three frames ago) must have left its slot: the gather reads it on the other stream
     if (g->used[b] && ls_tracer_next_frame_waits(g->tr, g->ev_collected[b]) != LS_OK) return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
-    if (ls_tracer_set_output_buffers(g->tr, g->local_points, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]),
-                                     g->capacity) != LS_OK)
+    if (ls_tracer_set_hit_buffers(g->tr, g->slot[b] + LS_GROUP_SLOT_HEADER, reinterpret_cast<uint32_t *>(g->slot[b]), g->capacity) != LS_OK)
         return fail(g, LS_ERR_HIP, ls_last_error(g->tr));
     const int rc = ls_trace_scene_async(g->tr, frame_index, &f);
     if (rc < -1) return fail(g, rc, ls_last_error(g->tr));
@@ -532,17 +571,28 @@ int ls_group_cloud(ls_group *g, uint32_t frame_index, ls_frame *out)
     return LS_OK;
 }
 
+int ls_group_frame_status(ls_group *g, uint32_t frame_index)
+{
+    if (!g) return LS_ERR_INVALID_ARGUMENT;
+    if (!ls_group_owns_frame(g, frame_index)) return fail(g, LS_ERR_OUT_OF_RANGE, "this rank does not hold that frame");
+    for (int i = 0; i < kSets; ++i) {
+        if (!g->set_valid[i] || g->set_frame[i] != frame_index) continue;
+        if (!g->sized || !g->stat_pending[i]) return LS_OK;
+        const int t = read_stat(g, i, false, nullptr);
+        if (t == -1000) return fail(g, LS_ERR_NOT_COMMITTED, "that frame's rebuild has not finished: wait for it first (ls_group_synchronize)");
+        if (t < 0) return t;
+        return t == 1 ? fail(g, LS_ERR_OUT_OF_RANGE, "that frame's hits outgrew the sized gather: its cloud is incomplete (the following frames are sized up)") : LS_OK;
+    }
+    return fail(g, LS_ERR_OUT_OF_RANGE, "that frame's buffers have been reused (three frames are kept)");
+}
+
 long ls_group_download_cloud(ls_group *g, uint32_t frame_index, void *points32, void *hits, uint32_t capacity)
 {
     ls_frame f;
     int rc = ls_group_cloud(g, frame_index, &f);
     if (rc != LS_OK) return rc;
     if ((rc = ls_group_synchronize(g)) != LS_OK) return rc;
-    if (g->sized) {
-        for (int i = 0; i < kSets; ++i)
-            if (g->set_valid[i] && g->set_frame[i] == frame_index && g->stat_pending[i] && read_stat(g, i, false, nullptr) == 1)
-                return fail(g, LS_ERR_OUT_OF_RANGE, "that frame's hits outgrew the sized gather: its cloud is incomplete (the following frames are sized up)");
-    }
+    if ((rc = ls_group_frame_status(g, frame_index)) != LS_OK) return rc;
     uint32_t n = 0;
     LSG_HIP(hipMemcpy(&n, f.d_n_points, 4, hipMemcpyDeviceToHost));
     if (n > capacity) return fail(g, LS_ERR_OUT_OF_RANGE, "host buffers smaller than the cloud");
@@ -575,7 +625,16 @@ long ls_group_info(ls_group *g, int what)
     case LS_GROUP_INFO_PER_SET: return g->per_set ? 1 : 0;
     case LS_GROUP_INFO_FRAME_GRAPH: return g->tr ? ls_get_info(g->tr, LS_INFO_FRAME_GRAPH_STATE) : 0;
     case LS_GROUP_INFO_GATHER_CAPACITY: return g->sized ? (long)g->gcap : (long)g->capacity;
-    case LS_GROUP_INFO_TRUNCATED_FRAMES: return (long)g->truncated_frames;
+    case LS_GROUP_INFO_TRUNCATED_FRAMES: {
+        // those counted when their set was reused + the finished ones among the frames still held (not waited for here)
+        unsigned long long n = g->truncated_frames;
+        if (g->sized)
+            for (int i = 0; i < kSets; ++i)
+                if (g->set_valid[i] && g->stat_pending[i] && read_stat(g, i, false, nullptr) == 1) ++n;
+        return (long)n;
+    }
+    case LS_GROUP_INFO_ARRANGEMENT_MINE: return (long)g->arrangement_mine;
+    case LS_GROUP_INFO_ARRANGEMENT_COMMON: return (long)g->arrangement_common;
     default: return fail(g, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }

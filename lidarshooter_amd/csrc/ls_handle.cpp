@@ -165,13 +165,38 @@ static bool valid_tables(const ls_sensor_tables *st)
 // ITracer.cpp:48: EmbreeTracer::traceScene reads _config every frame, EmbreeTracer.cpp:299-307, so a swapped or
 // re-initialised LidarDevice takes effect at the next trace).  Everything in flight completes first; the shard goes back
 // to the full turn; a committed scene is committed again for the new sensor (the classic BVH lives in the sensor frame).
-static int sensor_changed(ls_tracer *tr)
+// the sensor fields take_sensor_* overwrite, kept until the new tables are on the device
+struct SensorFields {
+    uint32_t V, H;
+    std::vector<float> vertical, given_tables;
+    float h_begin, h_end, h_step, rinv[9], t[3];
+    explicit SensorFields(const ls_tracer *tr)
+        : V(tr->V), H(tr->H), vertical(tr->vertical), given_tables(tr->given_tables), h_begin(tr->h_begin), h_end(tr->h_end), h_step(tr->h_step)
+    {
+        std::memcpy(rinv, tr->rinv, sizeof(rinv));
+        std::memcpy(t, tr->t, sizeof(t));
+    }
+    void restore(ls_tracer *tr)
+    {
+        tr->V = V; tr->H = H;
+        tr->vertical.swap(vertical);
+        tr->given_tables.swap(given_tables);
+        tr->h_begin = h_begin; tr->h_end = h_end; tr->h_step = h_step;
+        std::memcpy(tr->rinv, rinv, sizeof(rinv));
+        std::memcpy(tr->t, t, sizeof(t));
+    }
+};
+
+// `before`: the handle's sensor as it was; the new one has been taken over already.  The tables go up FIRST: a failed
+// upload (hipMalloc, the copy) puts the old sensor back -- its tables are still on the device, its shard and frame graphs
+// untouched -- instead of leaving the new V and H over the old, smaller table buffer.
+static int sensor_changed(ls_tracer *tr, SensorFields &before)
 {
+    int rc = upload_tables(tr);
+    if (rc) { before.restore(tr); return rc; }
     frame_graph_destroy(tr);
     tr->az0 = 0;
     tr->naz = tr->H;
-    int rc = upload_tables(tr);
-    if (rc) return rc;
     check_projection_ok(tr);
     if (tr->engine == 2 && !tr->projection_ok) tr->engine = 0;   // (the projection engine was asked for and no longer applies)
     tr->keys_armed = tr->keys_b_armed = tr->keys_c_armed = false;
@@ -264,11 +289,15 @@ int ls_tracer_set_sensor(ls_tracer *tr, const ls_sensor_desc *sd)
     if (!sd || !sd->vertical_deg || sd->n_vertical == 0 || sd->h_count < 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "incomplete sensor descriptor");
     if ((unsigned long long)sd->n_vertical * sd->h_count > 0x7FFFFFFFull) return fail(tr, LS_ERR_OUT_OF_RANGE, "ray indices are 32-bit");
     if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open");
+    // (another sensor puts the handle back on the full turn: whoever installed output buffers sized them for the old raster,
+    // or for a shard of it -- a group -- and has to take them back first)
+    if (tr->ext_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "external output buffers are installed (a group holds this tracer?): reset them before changing the sensor");
     const int rc = flush_pipeline(tr);
     if (rc) return rc;
     LS_HIP(hipStreamSynchronize(tr->stream));
+    SensorFields before(tr);
     take_sensor_desc(tr, sd);
-    return sensor_changed(tr);
+    return sensor_changed(tr, before);
 }
 
 int ls_tracer_set_sensor_tables(ls_tracer *tr, const ls_sensor_tables *st)
@@ -277,11 +306,15 @@ int ls_tracer_set_sensor_tables(ls_tracer *tr, const ls_sensor_tables *st)
     if (!valid_tables(st)) return fail(tr, LS_ERR_INVALID_ARGUMENT, "incomplete sensor tables");
     if ((unsigned long long)st->n_vertical * st->h_count > 0x7FFFFFFFull) return fail(tr, LS_ERR_OUT_OF_RANGE, "ray indices are 32-bit");
     if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open");
+    // (another sensor puts the handle back on the full turn: whoever installed output buffers sized them for the old raster,
+    // or for a shard of it -- a group -- and has to take them back first)
+    if (tr->ext_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "external output buffers are installed (a group holds this tracer?): reset them before changing the sensor");
     const int rc = flush_pipeline(tr);
     if (rc) return rc;
     LS_HIP(hipStreamSynchronize(tr->stream));
+    SensorFields before(tr);
     take_sensor_tables(tr, st);
-    return sensor_changed(tr);
+    return sensor_changed(tr, before);
 }
 
 int ls_tracer_create_tables(const ls_sensor_tables *st, int hip_device, ls_tracer **out)
@@ -417,6 +450,8 @@ long ls_get_info(ls_tracer *tr, int what)
     case LS_INFO_FRAME_GRAPH_REPLAYS: return (long)tr->fg_replays;
     case LS_INFO_FRAME_GRAPH_PATCHES: return (long)tr->fg_patches;
     case LS_INFO_FRAME_GRAPH_LAST_PATCHED: return (long)tr->fg_last_patched;
+    case LS_INFO_EMIT_POINTS: return (long)tr->opt_emit_points;
+    case LS_INFO_FRAME_GRAPH_PATCH_WAITS: return (long)tr->fg_patch_waits;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }
@@ -424,6 +459,7 @@ long ls_get_info(ls_tracer *tr, int what)
 int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, uint32_t *d_n_points, uint32_t capacity)
 {
     LS_ENTER(tr);
+    tr->ext_hits_only = false;
     if (!d_points32) {
         tr->ext_points = tr->ext_hits = nullptr;
         tr->ext_n_points = nullptr;
@@ -435,6 +471,26 @@ int ls_tracer_set_output_buffers(ls_tracer *tr, void *d_points32, void *d_hits, 
     tr->ext_hits = d_hits;
     tr->ext_n_points = d_n_points;
     tr->ext_capacity = capacity;
+    return LS_OK;
+}
+
+int ls_tracer_set_hit_buffers(ls_tracer *tr, void *d_hits, uint32_t *d_n_points, uint32_t capacity)
+{
+    LS_ENTER(tr);
+    if (!d_hits) {
+        tr->ext_points = tr->ext_hits = nullptr;
+        tr->ext_n_points = nullptr;
+        tr->ext_capacity = 0;
+        tr->ext_hits_only = false;
+        return LS_OK;
+    }
+    if (!d_n_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "the count word is required");
+    if (tr->opt_emit_points) return fail(tr, LS_ERR_INVALID_ARGUMENT, "hit buffers alone need LS_OPT_EMIT_POINTS = 0 first");
+    tr->ext_points = d_hits;   // ("external buffers are installed"; never written: no pass emits points with LS_OPT_EMIT_POINTS = 0)
+    tr->ext_hits = d_hits;
+    tr->ext_n_points = d_n_points;
+    tr->ext_capacity = capacity;
+    tr->ext_hits_only = true;
     return LS_OK;
 }
 
@@ -498,6 +554,7 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
     }
     case LS_OPT_EMIT_POINTS:
         if (value < 0 || value > 1) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_EMIT_POINTS: 0 or 1");
+        if (value && tr->ext_hits_only) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_EMIT_POINTS = 1 while hit buffers alone are installed (ls_tracer_set_hit_buffers): there is no point buffer");
         tr->opt_emit_points = value;
         return LS_OK;
     case LS_OPT_FRAME_GRAPH: {

@@ -44,6 +44,11 @@ struct Geometry {
     const void *shared_raw = nullptr;       // ls_update_geometry_device_shared: caller-owned device buffers
     const uint32_t *shared_idx = nullptr;   // read in place by the kernels, never copied or freed
     bool has_verts = false, has_idx = false, idx_dirty = true;
+    // index validation: every index upload / hand-over launches k_index_max into d_idx_max; the next commit reads it back
+    uint32_t *d_idx_max = nullptr;
+    bool idx_unchecked = false;   // a reduction is in flight (or done) whose result no commit has looked at
+    bool idx_bad = false;         // the last check found an index >= n_verts: every commit fails until new indices arrive
+    uint32_t idx_bad_value = 0;
     // host uploads (ls_update_geometry): pinned staging, written by the copy pool, read by the DMA
     void *h_stage_v = nullptr, *h_stage_i = nullptr;
     size_t stage_v_cap = 0, stage_i_cap = 0;
@@ -177,6 +182,7 @@ struct ls_tracer {
     void *ext_points = nullptr, *ext_hits = nullptr;
     uint32_t *ext_n_points = nullptr;
     uint32_t ext_capacity = 0;
+    bool ext_hits_only = false;   // ls_tracer_set_hit_buffers: ext_points is only a marker, no point record may be written
     uint8_t *h_points = nullptr;
     ls_hit *h_hits = nullptr;
     size_t h_cap = 0;  // records
@@ -230,7 +236,7 @@ struct ls_tracer {
     uint32_t fg_slot = 0;
     lsi::FrameGraph fgraph[3];
     ls::LaunchSink fg_sink;
-    uint64_t fg_captures = 0, fg_replays = 0, fg_patches = 0;
+    uint64_t fg_captures = 0, fg_replays = 0, fg_patches = 0, fg_patch_waits = 0;   // (waits: a patch found its stream's previous frame still in flight)
     uint32_t fg_last_patched = 0;  // bit i: launch i of the frame replayed last went out with new arguments
     uint32_t last_slot = 0xFFFFFFFFu;   // the frame issued last: its stream of the three-stream rotation (none: it ran on `stream`)
     hipStream_t last_stream = nullptr;

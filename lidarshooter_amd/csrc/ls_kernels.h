@@ -166,6 +166,9 @@ static_assert(64 % LS_CULL_GROUP == 0, "a wave takes a whole number of groups");
 void launch_transform(hipStream_t s, const void *raw, uint32_t stride, uint32_t n, const float *affine12,
                       const float *rinv9, const float *t3, float *out_xyz, uint32_t *d_maxabs_bits);
 void launch_rebase(hipStream_t s, const uint32_t *idx, uint32_t n_idx, uint32_t vbase, uint32_t *out);
+// *d_max = the largest of idx[0 .. n) (0 for n = 0), stream-ordered: commitScene reads it back and refuses a geometry whose
+// triangles name vertices it does not have
+void launch_index_max(hipStream_t s, const uint32_t *idx, uint32_t n, uint32_t *d_max);
 // RTC_GEOMETRY_TYPE_QUAD (EmbreeTracer.cpp:179-198): quad (v0,v1,v2,v3) -> triangles (v0,v1,v3), (v2,v3,v1), Embree's split
 void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t n_quads, uint32_t *tri_idx);
 void launch_morton(hipStream_t s, const float *verts, const uint32_t *tris, uint32_t ntris,

@@ -73,6 +73,23 @@ __global__ __launch_bounds__(kBlock) void k_quads_to_triangles(const uint32_t *_
     o[3] = v2; o[4] = v3; o[5] = v1;
 }
 
+// Largest vertex index of a geometry's triangles (atomicMax into *out, zeroed by the launcher): checked against the
+// geometry's vertex count at the next commit.  The reference hands Embree shared buffers unchecked
+// (EmbreeTracer.cpp:140-176: a bad index reads host memory out of bounds -- undefined, usually survivable); here every
+// kernel that gathers vertices would take a device memory fault, and with it the process, so such a mesh is refused
+// before anything is launched over it.  12 MB of indices at a million triangles: a few microseconds, once per index upload.
+__global__ __launch_bounds__(kBlock) void k_index_max(const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ out)
+{
+    uint32_t m = 0;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) m = max(m, idx[j]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    __shared__ uint32_t s_m[kBlock / 64];
+    if ((threadIdx.x & 63u) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
+}
+
 __global__ __launch_bounds__(kBlock) void k_rebase(const uint32_t *__restrict__ idx, uint32_t n, uint32_t vbase,
                                                    uint32_t *__restrict__ out)
 {
@@ -1485,6 +1502,14 @@ void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t
 {
     if (!n_quads) return;
     hipLaunchKernelGGL(k_quads_to_triangles, dim3(blocks_for(n_quads)), dim3(kBlock), 0, s, quad_idx, n_quads, tri_idx);
+}
+
+void launch_index_max(hipStream_t s, const uint32_t *idx, uint32_t n, uint32_t *d_max)
+{
+    (void)hipMemsetAsync(d_max, 0, 4, s);
+    if (!n) return;
+    const uint32_t blocks = std::min<uint32_t>(blocks_for(n), 1024u);   // (at most 1 024 atomics on the one word)
+    hipLaunchKernelGGL(k_index_max, dim3(blocks), dim3(kBlock), 0, s, idx, n, d_max);
 }
 
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts, uint32_t *queue_heads)

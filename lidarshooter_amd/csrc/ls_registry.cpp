@@ -116,6 +116,18 @@ int stage_upload(ls_tracer *tr, void *&stage, size_t &stage_cap, hipEvent_t &ev,
     return LS_OK;
 }
 
+// the triangles' indices just changed (an upload, a hand-over, a quad conversion -- all enqueued on the handle's stream):
+// their maximum is reduced behind them; commit_locked looks at it
+int check_indices_later(ls_tracer *tr, Geometry &g)
+{
+    if (!g.d_idx_max) LS_HIP(hipMalloc(reinterpret_cast<void **>(&g.d_idx_max), 4));
+    ls::launch_index_max(tr->stream, g.idx(), g.n_tris * 3u, g.d_idx_max);
+    LS_HIP(hipGetLastError());
+    g.idx_unchecked = true;
+    g.idx_bad = false;
+    return LS_OK;
+}
+
 int update_common(ls_tracer *tr, const char *name, const float *affine, const void *verts, uint32_t stride,
                   const uint32_t *idx, hipMemcpyKind kind, bool shared = false)
 {
@@ -143,6 +155,7 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
             if (!g.has_idx) tr->layout_dirty = true;
             g.has_idx = true; g.idx_dirty = true; tr->tris_rebased = false; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true;
         } else if (idx) { g.shared_idx = idx; g.has_idx = true; g.idx_dirty = true; tr->tris_rebased = false; g.order_stale = true; g.blas_dirty = g.blas_topo_dirty = true; }
+        if (idx) return check_indices_later(tr, g);   // (the caller's buffer may hold anything: every hand-over is looked at)
         return LS_OK;
     }
     if (!verts && !idx) return LS_OK;   // transform only: nothing is copied, nothing to order
@@ -197,6 +210,7 @@ int update_common(ls_tracer *tr, const char *name, const float *affine, const vo
         if (!g.has_idx) tr->layout_dirty = true;
         g.has_idx = true;
         g.idx_dirty = true; tr->tris_rebased = false;
+        return check_indices_later(tr, g);
     }
     return LS_OK;
 }
@@ -209,6 +223,8 @@ void free_geometry(Geometry &g)
     if (g.d_idx) (void)hipFree(g.d_idx);
     if (g.d_quad_idx) (void)hipFree(g.d_quad_idx);
     g.d_quad_idx = nullptr;
+    if (g.d_idx_max) (void)hipFree(g.d_idx_max);
+    g.d_idx_max = nullptr;
     if (g.h_stage_v) (void)hipHostFree(g.h_stage_v);
     if (g.h_stage_i) (void)hipHostFree(g.h_stage_i);
     if (g.d_perm) (void)hipFree(g.d_perm);

@@ -518,9 +518,24 @@ int frame_graph_close(ls_tracer *tr)
         for (size_t i = 0; same_sequence && i < sk.n; ++i) same_sequence = sk.recs[i].func == fg.recs[i].func;
         if (!same_sequence) return frame_graph_discard(tr, fg, false);   // (the signature missed something: capture anew)
         tr->fg_last_patched = 0;
+        bool idle = false;
         for (size_t i = 0; i < sk.n; ++i) {
             ls::LaunchRecord &now = sk.recs[i];
             if (same_launch(now, fg.recs[i])) continue;
+            // A node's arguments are about to change while this exec's previous launch -- three frames back on this very
+            // stream -- may still be queued or running: nothing bounds how far the host runs ahead of the device, and whether
+            // a launched graph keeps a snapshot of its kernel arguments or reads the exec's (ROCm keeps a graph's kernel
+            // arguments in a device-side pool that SetParams rewrites in place) is the runtime's business.  So the stream is
+            // idle before the first patch: one query when it already is -- the steady state of a GPU-bound stream of frames,
+            // the host at most three frames ahead -- a wait otherwise.  Frames whose arguments did not change pay nothing.
+            if (!idle) {
+                if (hipStreamQuery(s) != hipSuccess) {
+                    (void)hipGetLastError();
+                    LS_HIP(hipStreamSynchronize(s));
+                    ++tr->fg_patch_waits;
+                }
+                idle = true;
+            }
             tr->fg_last_patched |= 1u << (i < 31 ? i : 31);
             void *argv[16];
             for (uint32_t a = 0; a < now.n_args; ++a) argv[a] = now.blob.data() + now.arg_off[a];
@@ -567,6 +582,8 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
     if ((rc = ensure_outputs(tr))) return rc;
     if (tr->ext_points && tr->ext_capacity < shard_rays(tr))
         return fail(tr, LS_ERR_OUT_OF_RANGE, "external output buffers smaller than the shard's ray count");
+    if (tr->ext_hits_only && tr->opt_emit_points)
+        return fail(tr, LS_ERR_INVALID_ARGUMENT, "hit buffers alone are installed (ls_tracer_set_hit_buffers) and LS_OPT_EMIT_POINTS is 1");
 
     hipStream_t s = tr->stream;   // three-stream mode switches to the frame's own stream below
     bool progress = false;

@@ -16,10 +16,10 @@ ID_BYTES, SLOT_HEADER = 128, 64
 SYMBOLS = ("ls_group_shard_columns", "ls_group_slot_capacity", "ls_group_slot_bytes", "ls_group_write_slot",
            "ls_group_decode_gathered", "ls_group_unique_id", "ls_group_create", "ls_group_destroy", "ls_group_trace",
            "ls_group_owns_frame", "ls_group_cloud", "ls_group_download_cloud", "ls_group_synchronize", "ls_group_last_error",
-           "ls_group_create_opts", "ls_group_info")
-FLAG_ONE_COMMUNICATOR, FLAG_NO_GRAPH, FLAG_SIZED_GATHER = 1, 2, 4
+           "ls_group_create_opts", "ls_group_info", "ls_group_frame_status")
+FLAG_ONE_COMMUNICATOR, FLAG_NO_GRAPH, FLAG_SIZED_GATHER, FLAG_DEBUG_PEER_REFUSES = 1, 2, 4, 0x100
 INFO_RCCL_VERSION, INFO_COMM_RANKS, INFO_COMM_DEVICE, INFO_COMMUNICATORS, INFO_PER_SET, INFO_FRAME_GRAPH = 1, 2, 3, 4, 5, 6
-INFO_GATHER_CAPACITY, INFO_TRUNCATED_FRAMES = 7, 8
+INFO_GATHER_CAPACITY, INFO_TRUNCATED_FRAMES, INFO_ARRANGEMENT_MINE, INFO_ARRANGEMENT_COMMON = 7, 8, 9, 10
 _lib = None
 
 
@@ -53,6 +53,7 @@ def load() -> C.CDLL:
     L.ls_group_owns_frame.argtypes = [vp, u32]
     L.ls_group_cloud.argtypes = [vp, u32, C.POINTER(capi.Frame)]
     L.ls_group_download_cloud.argtypes = [vp, u32, vp, vp, u32]
+    L.ls_group_frame_status.argtypes = [vp, u32]
     L.ls_group_download_cloud.restype = C.c_long
     L.ls_group_synchronize.argtypes = [vp]
     L.ls_group_last_error.argtypes = [vp]
@@ -125,6 +126,10 @@ class Group:
         if self.L.ls_group_cloud(self.g, frame, C.byref(f)) != 0:
             raise capi.LidarShooterHipError(self.L.ls_group_last_error(self.g).decode())
         return f
+
+    def frameStatus(self, frame: int) -> int:
+        """ls_group_frame_status: 0 complete, LS_ERR_OUT_OF_RANGE (-5) truncated / reused, LS_ERR_NOT_COMMITTED while it is still in flight"""
+        return int(self.L.ls_group_frame_status(self.g, frame))
 
     def download(self, frame: int):
         """-> (points uint8[n,32], hits uint32[n,4]) of that frame's whole cloud"""

@@ -163,6 +163,32 @@ def test_adapter_second_sensor_and_moving_mesh(adapterapi, oracle, sensors, mesh
 
 
 @pytest.mark.gpu
+def test_adapter_refuses_a_mesh_with_a_wild_index(adapterapi, oracle, sensors, meshes):
+    """A pcl::PolygonMesh whose polygons name a vertex its cloud does not hold: commitScene throws BadGeometryException
+    (Exceptions.hpp:143-157; the C shim returns -200 for it) instead of faulting the GPU; the tracer behind the ITracer::Ptr
+    stays usable -- the same name with a sound mesh traces the reference's 1668 points."""
+    s = sensors["0000"]
+    gv, gt = meshes["ground"]
+    bad = gt.copy()
+    bad[3, 2] = gv.shape[0] + 100
+    tr = adapterapi.AdapterTracer(CFG["0000"])
+    tr.meshFromArrays("mesh", gv, bad, point_step=16)
+    tr.addGeometry("mesh")
+    tr.updateGeometry("mesh")
+    assert tr.commitScene() == -200
+    assert "BadGeometry" in tr.L.lsa_last_error().decode() and "vertex index %d" % (gv.shape[0] + 100) in tr.L.lsa_last_error().decode()
+    assert tr.commitScene() == -200                              # it stays refused
+    assert tr.removeGeometry("mesh") == 0
+    tr.meshFromArrays("mesh", gv, gt, point_step=16)
+    tr.addGeometry("mesh")
+    tr.updateGeometry("mesh")
+    assert tr.commitScene() == 0 and tr.traceScene(0) == 0
+    want = oracle.trace_frame(s, [(0, gv, gt, oracle.IDENTITY_AFFINE)])["points"]
+    assert np.array_equal(_points(tr.cloud()), want) and want.shape[0] == 1668
+    tr.close()
+
+
+@pytest.mark.gpu
 def test_adapter_mesh_policies(adapterapi, oracle, sensors, meshes):
     """UploadAlways (default) sees an in-place edit of the cloud (MeshProjector.cpp:306-307) with the same header.
     SkipUnchanged is a contract: the same buffer, size, header.seq and header.stamp stand for the same vertices -> a

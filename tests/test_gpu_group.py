@@ -59,6 +59,61 @@ def test_group_one_rank(oracle, capi, sensors, meshes, mode_name, flags, pipelin
     tr.close()
 
 
+def test_group_arrangement_is_agreed_on_and_hit_buffers_refuse_points(oracle, capi, sensors, meshes):
+    """ADVICE round 4.  (1) The group's arrangement is the AND of what the ranks can do, gathered over the first
+    communicator: with LS_GROUP_FLAG_DEBUG_PEER_REFUSES the gathered answers read as if a peer could do neither, and this
+    rank -- which could -- runs the one-communicator path like that peer (its duplicates destroyed, no frame graphs), frames
+    still the oracle's.  (2) The group installs hit buffers alone: LS_OPT_EMIT_POINTS = 1 is refused while it is attached,
+    and the caller's own value of the option comes back at destroy."""
+    from lidarshooter_amd import groupapi
+    s = sensors["0000"]
+    tr = make_tracer(capi, s, "projection")
+    tr.addGeometry("ground", *[a.shape[0] for a in meshes["ground"]])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    g = groupapi.Group(tr, 1, 0, groupapi.SHARDED)
+    mine = g.info(groupapi.INFO_ARRANGEMENT_MINE)
+    assert g.info(groupapi.INFO_ARRANGEMENT_COMMON) == mine and bool(g.info(groupapi.INFO_PER_SET)) == (mine == 3)
+    assert tr.info(capi.LS_INFO_EMIT_POINTS) == 0
+    with pytest.raises(capi.LidarShooterHipError, match="hit buffers alone"):
+        tr.setOption(capi.LS_OPT_EMIT_POINTS, 1)
+    g.close()
+    assert tr.info(capi.LS_INFO_EMIT_POINTS) == 1
+    tr.setOption(capi.LS_OPT_EMIT_POINTS, 0)            # a caller that had it off gets it back off
+    g = groupapi.Group(tr, 1, 0, groupapi.SHARDED, flags=groupapi.FLAG_DEBUG_PEER_REFUSES)
+    assert g.info(groupapi.INFO_ARRANGEMENT_MINE) == mine and g.info(groupapi.INFO_ARRANGEMENT_COMMON) == 0
+    assert g.info(groupapi.INFO_PER_SET) == 0 and g.info(groupapi.INFO_COMMUNICATORS) == 1
+    assert tr.info(capi.LS_INFO_FRAME_GRAPH_STATE) == 0
+    for f in range(5):
+        assert tr.commitScene() == 0 and g.trace(f) == 0
+    for f in (2, 3, 4):
+        pts, hits = g.download(f)
+        assert np.array_equal(pts, ref["points"]) and np.array_equal(hits, ref["hits"])
+    g.close()
+    assert tr.info(capi.LS_INFO_EMIT_POINTS) == 0
+    tr.setOption(capi.LS_OPT_EMIT_POINTS, 1)
+    # hit buffers alone, by hand: a trace with points switched on is refused, not written through the marker pointer
+    import torch
+    dev = torch.device("cuda", 0)
+    hits_d = torch.zeros(16 * s.V * s.H, dtype=torch.uint8, device=dev)
+    n_d = torch.zeros(16, dtype=torch.int32, device=dev)
+    with pytest.raises(capi.LidarShooterHipError, match="EMIT_POINTS"):
+        tr.setHitBuffers(hits_d.data_ptr(), n_d.data_ptr(), s.V * s.H)
+    tr.setOption(capi.LS_OPT_EMIT_POINTS, 0)
+    tr.setHitBuffers(hits_d.data_ptr(), n_d.data_ptr(), s.V * s.H)
+    assert tr.commitScene() == 0
+    tr.traceSceneAsync(0)
+    tr.synchronize()
+    n = int(n_d[0].item())
+    assert n == ref["hits"].shape[0]
+    assert np.array_equal(hits_d.cpu().numpy()[:16 * n].view(np.uint32).reshape(n, 4), ref["hits"])
+    tr.setHitBuffers(None, None, 0)
+    tr.setOption(capi.LS_OPT_EMIT_POINTS, 1)
+    rc, pts, _ = tr.traceScene(1)
+    assert rc == 0 and np.array_equal(pts, ref["points"])
+    tr.close()
+
+
 @pytest.mark.parametrize("group,flags", [("sharded", 0), ("sharded", 1), ("interleaved", 0)])
 def test_lsbench_ranks_one(oracle, sensors, meshes, group, flags):
     """lsbench --ranks 1: the C++ harness through lidarshooter_group.h (fork per rank, id through a file, RCCL)."""
@@ -241,6 +296,11 @@ def test_group_sized_gather(oracle, capi, sensors, meshes):
     assert tr.commitScene() == 0 and g.trace(8) == 0
     with pytest.raises(capi.LidarShooterHipError, match="outgrew"):
         g.download(8)
+    # a caller that reads ls_group_cloud's device pointers itself asks ls_group_frame_status: truncated,
+    # and counted at once -- not only when the set is reused three frames later
+    g.cloud(8)
+    assert g.frameStatus(8) < 0 and g.frameStatus(7) == 0 and g.frameStatus(2) < 0   # (7: complete; 2: its buffers are long reused)
+    assert g.info(groupapi.INFO_TRUNCATED_FRAMES) == 1
     for f in range(9, 16):
         assert tr.commitScene() == 0 and g.trace(f) == 0
     assert g.info(groupapi.INFO_TRUNCATED_FRAMES) >= 3                        # frames 8 .. 10 were sized from frames 5 .. 7

@@ -1183,6 +1183,117 @@ def test_edge_cases(oracle, capi, sensors, engine):
     tr.close()
 
 
+def test_out_of_range_indices_are_refused(oracle, capi, sensors, meshes, engine):
+    """A triangle that names a vertex its geometry does not have.  Embree reads it out of the shared host buffers unchecked
+    (EmbreeTracer.cpp:140-176: undefined, usually survivable); every kernel here that gathers vertices would take a device
+    memory fault.  So the upload is looked at (one max-reduction behind every index upload / hand-over) and the commit is
+    REFUSED -- LS_ERR_OUT_OF_RANGE, nothing is built or launched over the mesh, a trace says "nothing committed" -- and the
+    handle stays usable: new indices or the removal of the geometry clear the condition.  (The fault itself is never
+    provoked: every case here must end in the error path.)"""
+    import torch
+    s = sensors["0000"]
+    v, t = meshes["ground"]
+    tr = make_tracer(capi, s, engine)
+    assert tr.addGeometry("ground", v.shape[0], t.shape[0]) == 0
+    for bad_value in (v.shape[0], v.shape[0] + 7, 0xFFFFFFF0):
+        bad = t.copy()
+        bad[50, 1] = bad_value
+        assert tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, v, bad) == 0     # (the upload itself is asynchronous)
+        for _ in range(2):                                                           # the condition stays until new indices arrive
+            with pytest.raises(capi.LidarShooterHipError, match="vertex index %d" % bad_value):
+                tr.commitScene()
+        rc, pts, hits = tr.traceScene(0)
+        assert rc == -1 and len(pts) == 0                                            # nothing committed: nothing traced
+    # a second, good geometry does not make the scene acceptable; removing the bad one does (ls_remove_geometry commits)
+    bv, bt = meshes["ben"]
+    assert tr.addGeometry("face", bv.shape[0], bt.shape[0]) == 1
+    tr.updateGeometry("face", oracle.IDENTITY_AFFINE, bv, bt)
+    with pytest.raises(capi.LidarShooterHipError, match="'ground'"):
+        tr.commitScene()
+    assert tr.removeGeometry("ground") == 0
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(1)
+    _assert_parity(oracle, s, tr, [(1, bv, bt, oracle.IDENTITY_AFFINE)], pts, hits)
+    # the mesh again with its own indices: the reference's 1781 points
+    assert tr.addGeometry("ground", v.shape[0], t.shape[0]) == 0
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, v, t)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(2)
+    assert len(pts) == 1781
+    # the hand-over path (the caller's device buffers are read in place: every hand-over is looked at)
+    dev = torch.device("cuda", 0)
+    dv = torch.from_numpy(v).to(dev)
+    bad = t.copy()
+    bad[0, 0] = 1 << 20
+    d_bad, d_good = torch.from_numpy(bad.view(np.int32)).to(dev), torch.from_numpy(t.view(np.int32)).to(dev)
+    tr.updateGeometryDeviceShared("ground", oracle.IDENTITY_AFFINE, dv.data_ptr(), 12, d_bad.data_ptr())
+    with pytest.raises(capi.LidarShooterHipError, match="vertex index 1048576"):
+        tr.commitScene()
+    tr.updateGeometryDeviceShared("ground", oracle.IDENTITY_AFFINE, dv.data_ptr(), 12, d_good.data_ptr())
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(3)
+    assert len(pts) == 1781
+    # quads: the four indices of every element are looked at (through the triangle pair they become)
+    quad_v = np.array([[30, -30, -2], [30, 30, -2], [-30, 30, -2], [-30, -30, -2]], np.float32)
+    assert tr.addGeometry("plate", 4, 1, geometry_type=capi.LS_GEOMETRY_TYPE_QUAD) == 2
+    tr.updateGeometry("plate", oracle.IDENTITY_AFFINE, quad_v, np.array([[0, 1, 2, 4]], np.uint32))
+    with pytest.raises(capi.LidarShooterHipError, match="'plate'"):
+        tr.commitScene()
+    tr.updateGeometry("plate", oracle.IDENTITY_AFFINE, quad_v, np.array([[0, 1, 2, 3]], np.uint32))
+    assert tr.commitScene() == 0
+    tr.close()
+
+
+def test_non_finite_and_huge_vertices(oracle, capi, sensors, meshes, engine):
+    """NaN / infinite / 1e18 coordinates reach the tracer as they are (the reference checks nothing:
+    MeshTransformer.cpp:142-205 multiplies whatever the cloud holds): the closest hits are the oracle's exhaustive ones,
+    bit for bit -- a triangle with a non-finite corner is hit by nobody, its neighbours are unaffected; a 1e18-metre
+    triangle under the sensor is hit like any other.  Also a quad with a repeated vertex (one of its two triangles is
+    degenerate)."""
+    s = sensors["0000"]
+    v, t = meshes["ground"]
+    cases = []
+    nan_shared = v.copy(); nan_shared[40] = np.nan                       # a vertex seven triangles share
+    cases.append(("nan shared", nan_shared, t))
+    nan_alone = np.concatenate([v, np.full((1, 3), np.nan, np.float32)])  # a vertex nobody uses
+    cases.append(("nan alone", nan_alone, t))
+    inf_x = v.copy(); inf_x[41, 0] = np.inf
+    cases.append(("inf", inf_x, t))
+    minus_inf = v.copy(); minus_inf[12] = (-np.inf, np.inf, 0.0)
+    cases.append(("-inf", minus_inf, t))
+    huge = np.concatenate([v, np.array([[-1e18, -1e18, -3.0], [1e18, -1e18, -3.0], [0.0, 1e18, -3.0]], np.float32)])
+    huge_t = np.concatenate([t, np.array([[v.shape[0], v.shape[0] + 1, v.shape[0] + 2]], np.uint32)])
+    cases.append(("1e18", huge, huge_t))
+    nan_component = v.copy(); nan_component[5, 2] = np.nan; nan_component[77, 1] = np.inf
+    cases.append(("mixed", nan_component, t))
+    seen_fewer = False
+    clean = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)])["points"].shape[0]
+    for name, vv, tt in cases:
+        for A in (oracle.IDENTITY_AFFINE, oracle.affine_from_components(np.array((1.0, -2.0, 0.1), np.float32), np.array((0.02, 0.0, 0.4), np.float32))):
+            tr = make_tracer(capi, s, engine)
+            assert tr.addGeometry("g", vv.shape[0], tt.shape[0]) == 0
+            tr.updateGeometry("g", A, vv, tt)
+            assert tr.commitScene() == 0, name
+            rc, pts, hits = tr.traceScene(0)
+            assert rc == 0, name
+            ref = _assert_parity(oracle, s, tr, [(0, vv, tt, A)], pts, hits)
+            seen_fewer = seen_fewer or ref["points"].shape[0] < clean
+            tr.close()
+    assert seen_fewer    # (the non-finite corners did take triangles out of the cloud)
+    # a quad with a repeated vertex next to the ground
+    quad_v = np.array([[30, -30, -2.5], [30, 30, -2.5], [-30, 30, -2.5], [-30, -30, -2.5]], np.float32)
+    quads = np.array([[0, 1, 1, 3], [1, 2, 3, 3]], np.uint32)
+    tr = make_tracer(capi, s, engine)
+    assert tr.addGeometry("ground", v.shape[0], t.shape[0]) == 0
+    assert tr.addGeometry("plate", 4, 2, geometry_type=capi.LS_GEOMETRY_TYPE_QUAD) == 1
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, v, t)
+    tr.updateGeometry("plate", oracle.IDENTITY_AFFINE, quad_v, quads)
+    assert tr.commitScene() == 0
+    rc, pts, hits = tr.traceScene(0)
+    _assert_parity(oracle, s, tr, [(0, v, t, oracle.IDENTITY_AFFINE), (1, quad_v, quads, oracle.IDENTITY_AFFINE)], pts, hits)
+    tr.close()
+
+
 def test_argument_errors(capi, sensors):
     s = sensors["0000"]
     tr = make_tracer(capi, s)
