@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 from lidarshooter_amd import capi, hostapi, shards, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r04"     # profiles/<tag>_<engine>_hbm.json: the rocprofv3 PMC summary this round's kernels were profiled into
+PROFILE_TAG = "r05"     # profiles/<tag>_<engine>_hbm.json: the rocprofv3 PMC summary this round's kernels were profiled into
 NODE_BYTES, TRI_BYTES, RAY_OUT_BYTES = 64, 48, 8  # DESIGN.md "algorithmic bytes" (BVH engine)
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 HOST_NUMA = None
@@ -329,6 +329,22 @@ def cpu_baseline(sensor, meshes, frames, total_rays):
     }
 
 
+def front_loaded(out: dict) -> dict:
+    """The same line with its short numeric fields first and last (a record that keeps only the head or the tail of the line still
+    shows them): the contract's scalars, the drop-in frame, the roofline's fractions, the CPU baseline's value -- the long
+    descriptive strings and objects sit in the middle."""
+    rf, cb = out.get("roofline") or {}, out.get("cpu_baseline") or {}
+    short = {k: out.get(k) for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                                     "ms_per_step_one_frame_in_flight", "ms_per_step_windows_of_1000", "dropin_ms_per_step", "dropin_static_ms_per_step",
+                                     "frames_per_s") if k in out}
+    short["roofline_frac"] = rf.get("frac")
+    short["roofline_kernel_ms"] = rf.get("kernel_ms")
+    short["roofline_issue_frac"] = (rf.get("secondary") or {}).get("issue_frac")
+    short["cpu_baseline_value"] = cb.get("value")
+    middle = {k: v for k, v in out.items() if k not in short}
+    return {**short, **middle, "summary": dict(short)}
+
+
 def spawn_ranks(args) -> int:
     """--gpus N without a launcher: start the N ranks as a fresh child process tree (torch.distributed.run) -- nothing in
     THIS process has touched a GPU yet (importing torch does not; torch.cuda.device_count() does not initialise one on
@@ -429,7 +445,7 @@ def main():
             out["also_measured"] = also
     if rank == 0:
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        os.write(result_fd, (json.dumps(front_loaded(out)) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
@@ -989,6 +1005,27 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                     traffic, traffic_src = k[key]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
         except Exception:
             pass
+    # What binds the kernel besides bytes (SURVEY.md 8d "secondary ceilings"): the committed SQ / TCC counter summary of the same
+    # kernel sources (tools/sq_profile.sh -> profiles/<tag>_<engine>_sq.json), same staleness rule as `traffic`
+    secondary = None
+    sq = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{engine}_sq.json")
+    if args.workload == "syn128x1m" and world == 1 and os.path.exists(sq):
+        try:
+            sj = json.load(open(sq))
+            if sj.get("kernel_source_sha") != sha:
+                secondary = {"source": f"{os.path.relpath(sq, ROOT)} is stale (taken from kernel sources {sj.get('kernel_source_sha')}, these are {sha}): not reported"}
+            else:
+                key = next((n for n in sj["kernels"] if n.split("<")[0] == kernel and not n.split("<")[-1].startswith("true")), None)
+                if key:
+                    d = sj["kernels"][key]["derived"]
+                    secondary = {"issue_frac": d.get("valu_issue_frac"), "lanes_active_per_valu": d.get("lanes_active_per_valu"), "l2_hit": d.get("l2_hit"),
+                                 "wave_cycles_waiting": d.get("wait"), "wave_cycles_issue_stalled": d.get("stall"), "valu_per_wave": d.get("valu_per_wave"),
+                                 "wave_life_us": d.get("wave_life_us"), "source": os.path.relpath(sq, ROOT),
+                                 "what": "issue_frac = VALU wave-instructions x 2 cycles / (1024 SIMDs x 2.3 GHz) / kernel time: the share of the kernel during which "
+                                         "the vector ALUs could have been issuing at all; lanes_active_per_valu of 64; l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS); the two "
+                                         "wave_cycles shares are SQ_WAIT_ANY (parked in s_waitcnt / barrier) and SQ_WAIT_INST_ANY (issue-stalled) over SQ_WAVE_CYCLES"}
+        except Exception:
+            pass
     one_ms = latency_frame_s * 1e3 if latency_frame_s is not None else ms_per_step
 
     out = {
@@ -1049,7 +1086,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                         "replays": tr.info(capi.LS_INFO_FRAME_GRAPH_REPLAYS), "patches": tr.info(capi.LS_INFO_FRAME_GRAPH_PATCHES)},
         "roofline": dict({
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "secondary": secondary,
             "kernel_ms": trace_ms, "kernel_launches_timed": tm["frames"],
             "kernel_timing": "ISOLATED kernel: its own begin / end timestamps (hipEvents attached to the dispatch with hipExtLaunchKernel, what rocprofv3 reports per dispatch; events recorded around a launch add ~3 us of barrier packets) with ONE frame in flight (frames do not overlap while it is timed), in a second pass of the same K frames; compare with ms_per_step_one_frame_in_flight, not with ms_per_step (frames overlap there), and with profiles/*_kernel_isolated.json (the same figure from the rocprofv3 trace of this command)",
             "ms_per_step_one_frame_in_flight": one_ms,

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
             if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
         }
         const uint32_t first = lo ? gt.tri_first[lo] : first0, geom = lo ? gt.geom_ids[lo] : geom0, shift = lo ? gt.prim_shift[lo] : shift0;
-        hits[dst] = make_uint4(v * tb.H + h, geom, (gid - first) >> shift, __float_as_uint(t));
+        if (hits) hits[dst] = make_uint4(v * tb.H + h, geom, (gid - first) >> shift, __float_as_uint(t));
     }
     if (!FROM_KEYS || !pg.host || block != 0u) return;
     // ---- ls_trace_scene_begin: the frame's very first pack workgroup tells the host how many points there will be, how

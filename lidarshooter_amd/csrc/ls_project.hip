@@ -1263,7 +1263,7 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
         const uint32_t mid = (lo + hi) >> 1;
         if (fa.gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
     }
-    hits[dst] = make_uint4(v * tb.H + h, fa.gt.geom_ids[lo], (gid - fa.gt.tri_first[lo]) >> fa.gt.prim_shift[lo], __float_as_uint(t));
+    if (hits) hits[dst] = make_uint4(v * tb.H + h, fa.gt.geom_ids[lo], (gid - fa.gt.tri_first[lo]) >> fa.gt.prim_shift[lo], __float_as_uint(t));
 }
 
 template <bool COUNT>

@@ -261,12 +261,12 @@ int ensure_outputs(ls_tracer *tr)
             if ((rc = ensure(tr, tr->hits_c, nr * 16))) return rc;
         }
         if (!tr->d_n_points_c) LS_HIP(hipMalloc(reinterpret_cast<void **>(&tr->d_n_points_c), 4));
-        {
-            const size_t cap1 = tr->pack_status_ms.cap;
-            if ((rc = ensure(tr, tr->pack_status_ms, 3 * ((nr + 255) / 256 + 8)))) return rc;
-            if (tr->pack_status_ms.cap != cap1) tr->keys_armed = false;   // (fresh memory: initialised with the keys)
-        }
         if ((rc = ensure_slot_streams(tr))) return rc;
+    }
+    if (use_projection(tr)) {   // the fused finish + pack launch's status words: one region per key set
+        const size_t cap1 = tr->pack_status_ms.cap;
+        if ((rc = ensure(tr, tr->pack_status_ms, 3 * ((nr + 255) / 256 + 8)))) return rc;
+        if (tr->pack_status_ms.cap != cap1) tr->keys_armed = false;   // (fresh memory: initialised with the keys)
     }
     if ((tr->opt_pipeline || tr->pipe_seq) && use_projection(tr)) {   // twins: needed as long as the rotation may stand on parity 1
         const size_t cap0 = tr->best_keys_b.cap;
@@ -767,6 +767,7 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             if (multi && tr->opt_frame_graph && !tr->fg_broken && (rc = frame_graph_open(tr, slot, s, frame_signature(tr, srcs, slot)))) return rc;
             // one launch per 16 geometries (the descriptors travel as kernel arguments)
             if (ride) mark(tr, 8, &ev_k1);
+            { static const int no_hits = tune_int("LS_PACK_NO_HITS", 0); if (no_hits && !readback) d_hits = nullptr; }   // (experiment: what the 16-byte hit records cost)
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list,
                                ev_k0, ev_k1);
             if (!ride) mark(tr, 8);
@@ -780,8 +781,9 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             // of-a-turn shard at SYN-1M: 10.9 - 15.9 -> 8.2 - 11.9 us per frame); inside a captured frame graph a node costs
             // the host nothing and the look-back's polls cost more than the second read of the keys (8.3 -> 9.1 us, 10.8 -> 12.0
             // at SYN-10M).
-            const bool graphed = tr->opt_frame_graph && !tr->fg_broken;
-            if (multi && !graphed && n_blocks <= fuse_blocks && tr->pack_status_ms.p) {
+            const bool graphed = multi && tr->opt_frame_graph && !tr->fg_broken;
+            static const int fuse_single = tune_int("LS_FUSE_FINISH_PACK_SINGLE", 0);   // (experiment: also with one frame in flight)
+            if ((multi || fuse_single) && !graphed && !progress && !stats && n_blocks <= fuse_blocks && tr->pack_status_ms.p) {
                 ls::FinishPackArgs fa;
                 std::memset(static_cast<void *>(&fa), 0, sizeof(fa));   // (padding too: the frame graph compares argument bytes)
                 fa.best = keys;

@@ -10,6 +10,7 @@ if os.environ.get("PROBE_PRELOAD") == "1":   # the library (and with it /opt/roc
 import numpy as np, torch
 from lidarshooter_amd import capi, hostapi
 import bench
+if os.environ.get("PROBE_NO_PIN") != "1": bench.pin_to_gpu_numa_node(0)   # (as bench.py does: the host's enqueue cost decides the three-stream frame time)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 sensor, meshes = bench.build_workload("syn128x1m")
@@ -29,6 +30,7 @@ for rep in range(reps):
     F = os.environ.get("PROBE_FLAGS", "")
     tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"])
     tr.setOption(capi.LS_OPT_ENGINE, 2)
+    if os.environ.get("PROBE_CULL"): tr.setOption(capi.LS_OPT_BLOCK_CULL, int(os.environ["PROBE_CULL"]))
     if "f1" in F: tr.setShard(0, H)
     if "f6" in F: outs_early = [torch.zeros(64 + 48 * cap, dtype=torch.uint8, device=dev) for _ in range(3)]
     if "f2" in F: tr.setOption(capi.LS_OPT_PIPELINE, mode)
