@@ -314,6 +314,7 @@ int commit_locked(ls_tracer *tr)
         // frames still in flight on the second stream read the old table
         if ((rc = flush_pipeline(tr))) return rc;
         LS_HIP(hipStreamSynchronize(tr->stream));
+        __atomic_store_n(tr->h_status + 1, 0u, __ATOMIC_RELAXED);   // (the survivor hint spoke for the old set of geometries)
         std::vector<uint32_t> table(tfirst);
         for (int id : ids) table.push_back((uint32_t)id);
         for (const Geometry *ge : order) table.push_back(ge->quad ? 1u : 0u);   // primID = triangle >> shift

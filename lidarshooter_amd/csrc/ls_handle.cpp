@@ -263,7 +263,7 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
     constexpr unsigned kHostWords = hipHostMallocMapped | hipHostMallocCoherent;
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_n_points), 16, kHostWords) != hipSuccess) return bail(LS_ERR_HIP);
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_status), 16, kHostWords) != hipSuccess) return bail(LS_ERR_HIP);
-    *tr->h_status = 0u;
+    tr->h_status[0] = tr->h_status[1] = tr->h_status[2] = tr->h_status[3] = 0u;   // [0] the sticky status, [1] the survivor hint (ls_trace.cpp)
     if (hipHostMalloc(reinterpret_cast<void **>(&tr->h_progress), sizeof(ls::HostProgress), kHostWords) != hipSuccess) return bail(LS_ERR_HIP);
     std::memset(tr->h_progress, 0, sizeof(ls::HostProgress));
 
@@ -391,6 +391,7 @@ int ls_tracer_set_shard(ls_tracer *tr, uint32_t first_az, uint32_t n_az)
     if (rc) return rc;
     tr->az0 = first_az;
     tr->naz = n_az;
+    __atomic_store_n(tr->h_status + 1, 0u, __ATOMIC_RELAXED);   // (the survivor hint spoke for the old shard; a frame still running may write it once more: a hint, not a promise)
     tr->traced = false;
     tr->keys_armed = false;
     tr->keys_b_armed = false;

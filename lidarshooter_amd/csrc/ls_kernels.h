@@ -239,6 +239,8 @@ struct ProgressArgs {
     HostProgress *host;   // pinned host memory; nullptr: no progress reporting
     uint32_t epoch;       // this frame's tag (never 0)
     uint32_t split;       // the pack pass's second launch starts at this ray block (the first one packs n_first points)
+    uint32_t *cull_hint;  // pinned host word (nullable): 1 + the fullest survivor-list segment of this frame's k_cull, written by the
+                          // workgroup that re-arms the counters -- what sizes the NEXT frames' k_project<CULLED> grid
 };
 
 // compact != 0: points are written as 16-byte records (x, y, z, ring) instead of the 32-byte PointCloud2 layout
@@ -275,6 +277,7 @@ struct FinishPackArgs {
     uint32_t *n_points;
     uint32_t n_blocks;              // ceil(rays / 256)
     uint32_t compact;               // points as 16-byte (x, y, z, ring) records (LS_OPT_HOST_OUTPUT = 2)
+    uint32_t *cull_hint;            // as ProgressArgs::cull_hint
 };
 // cull_list (nullable): room for project_cull_entries() words; the groups that survive k_cull are appended there per
 // geometry (counts in big_count[kCullCountAt + i], re-armed wherever big_count[0] is) and the waves of the culled
@@ -282,7 +285,8 @@ struct FinishPackArgs {
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
                     void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats,
                     const FinishPackArgs *rider = nullptr, uint32_t *cull_list = nullptr, hipEvent_t ev_start = nullptr,
-                    hipEvent_t ev_stop = nullptr);   // ev_*: ride on the k_project dispatch (its own begin / end timestamps)
+                    hipEvent_t ev_stop = nullptr,    // ev_*: ride on the k_project dispatch (its own begin / end timestamps)
+                    uint32_t survivors_hint = 0);    // 1 + the fullest survivor segment of a recent frame (0: unknown): sizes the culled grid
 uint32_t project_tris_per_wave(uint32_t ntris);   // 64 for big meshes, fewer for small ones (more waves than ntris / 64)
 uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs, bool sector);   // survivor-list words for the geometries with bounds (0: none, or too many for one launch)
 // one-off per topology: Morton order of the triangles (centroids in mesh space) -> perm (sorted position -> triangle),

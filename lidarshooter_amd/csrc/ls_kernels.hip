@@ -1081,6 +1081,7 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     const uint32_t block = blockIdx.x + block0;
     __shared__ uint32_t s_part[kBlock / 64];
     __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_hint[kBlock / 64];
     const uint32_t nq = tb.V * tb.naz;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
 
@@ -1122,8 +1123,17 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
         if (q == 0) big_count[0] = 0u;                                             // queue length
         // group-cull survivor counts (one per list segment): all of them, whatever the shard's size -- a shard of 256 rays
         // or fewer is ONE workgroup, which used to re-arm the first 256 of the 512 counters only
-        if (block == 0u)
-            for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) big_count[kCullCountAt + i * 16u] = 0u;
+        if (block == 0u) {
+            // (read before they go: the fullest segment tells the host how large the next frames' culled launch has to be)
+            uint32_t fullest = 0;
+            for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) {
+                fullest = max(fullest, big_count[kCullCountAt + i * 16u]);
+                big_count[kCullCountAt + i * 16u] = 0u;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) fullest = max(fullest, (uint32_t)__shfl_xor((int)fullest, off));
+            if (lane == 0) s_hint[w] = fullest;
+        }
     }
     const bool hit = gid != kInvalid;
     const unsigned long long m = __ballot(hit);
@@ -1132,6 +1142,8 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     for (uint32_t k = 0; k < w; ++k) base += s_wave[k];
     if (block == n_blocks - 1 && threadIdx.x == 0) *n_points = base + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (FROM_KEYS && block == 0u && threadIdx.x == 0 && pg.cull_hint)
+        __hip_atomic_store(pg.cull_hint, 1u + max(max(s_hint[0], s_hint[1]), max(s_hint[2], s_hint[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (hit) {
         const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         const uint32_t dst = base + rank;
@@ -1526,7 +1538,7 @@ void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid,
     hipLaunchKernelGGL(k_pack<false>, dim3(blocks_for(nq)), dim3(kBlock), 0, s, tb, t, gid,
                        static_cast<unsigned long long *>(nullptr), block_counts, static_cast<uint32_t *>(nullptr),
                        static_cast<uint32_t *>(nullptr), gt, reinterpret_cast<float4 *>(points32),
-                       reinterpret_cast<uint4 *>(hits), n_points, compact, 0u, blocks_for(nq), ProgressArgs{nullptr, 0u, 0u});
+                       reinterpret_cast<uint4 *>(hits), n_points, compact, 0u, blocks_for(nq), ProgressArgs{nullptr, 0u, 0u, nullptr});
 }
 
 void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
@@ -1540,7 +1552,7 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
     auto launch = [&](uint32_t block0, uint32_t count) {
         launch_k(k_pack<true>, dim3(count), dim3(kBlock), 0, s, tb, t, gid, keys, block_counts, next_block_counts, big_count, gt,
                  reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points, compact, block0, nb,
-                 progress ? *progress : ProgressArgs{nullptr, 0u, 0u});
+                 progress ? *progress : ProgressArgs{nullptr, 0u, 0u, nullptr});
     };
     if (!progress || !progress->host) { launch(0u, nb); return; }
     // two launches, each followed by a word for the host: a kernel's writes to pinned host memory are complete when the

@@ -25,7 +25,7 @@ struct LaunchRecord {
     dim3 grid, block;
     uint32_t shmem = 0;
     uint32_t n_args = 0;
-    uint32_t arg_off[16] = {};        // byte offset of argument i in blob; arg_off[n_args] = blob size
+    uint32_t arg_off[20] = {};        // byte offset of argument i in blob; arg_off[n_args] = blob size
     std::vector<uint8_t> blob;
 };
 
@@ -64,7 +64,7 @@ template <typename... KArgs, typename... Args>
 inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, uint32_t shmem, hipStream_t s, Args &&...args)
 {
     static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
-    static_assert(sizeof...(KArgs) < 16, "LaunchRecord::arg_off");
+    static_assert(sizeof...(KArgs) < 20, "LaunchRecord::arg_off");
     LaunchSink *sink = thread_sink();
     if (!sink || sink->mode == LaunchSink::kOff || sink->stream != s) {
         hipLaunchKernelGGL(kernel, grid, block, shmem, s, static_cast<KArgs>(args)...);

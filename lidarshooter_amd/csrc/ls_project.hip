@@ -1233,7 +1233,20 @@ __device__ __forceinline__ void finish_pack_body(const ProjectParams &pp, const 
         // stream mode: a slot's next frame follows in stream order), or those of the frame after the next (rider mode) -- and
         // a tag in device memory steps on (0 is what fresh status words carry: skipped).
         if (threadIdx.x == 0) fa.rearm_big_count[0] = 0u;
-        for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) fa.rearm_big_count[kCullCountAt + i * 16u] = 0u;
+        uint32_t fullest = 0;   // the fullest survivor segment, read before the counters go (ProgressArgs::cull_hint)
+        for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) {
+            fullest = max(fullest, fa.rearm_big_count[kCullCountAt + i * 16u]);
+            fa.rearm_big_count[kCullCountAt + i * 16u] = 0u;
+        }
+        if (fa.cull_hint && fa.rearm_big_count == fa.big_count) {   // (uniform; the counters re-armed are the ones this frame used)
+            uint32_t *s_hint = scratch + 28;                          // (four spare words between s_n and s_list)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) fullest = max(fullest, (uint32_t)__shfl_xor((int)fullest, off));
+            if (lane == 0) s_hint[w] = fullest;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store(fa.cull_hint, 1u + max(max(s_hint[0], s_hint[1]), max(s_hint[2], s_hint[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (fa.epoch_word && threadIdx.x == 0) *fa.epoch_word = epoch + 1u ? epoch + 1u : 1u;
     }
     if (bad) {
@@ -1385,7 +1398,8 @@ LinearMap linear_map(const GeomSource &src)
 
 // the geometries that carry group bounds, as one batch: false if there are none or more than a launch takes.
 // blocks = k_project's grid (worst case: every group survives), entries = survivor-list words, batch.cull_first[n] = k_cull's grid
-bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch, uint32_t &blocks, uint32_t &entries, bool sector, uint32_t grid_pct = 0)
+bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch, uint32_t &blocks, uint32_t &entries, bool sector, uint32_t grid_pct = 0,
+                       uint32_t survivors_hint = 0)
 {
     if (!grid_pct) grid_pct = cull_grid_pct();
     batch.n = 0;
@@ -1400,8 +1414,11 @@ bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch
     while (rounds < kCullMaxRounds && (all_groups + (unsigned long long)rounds * kBlock - 1) / ((unsigned long long)rounds * kBlock) > cull_resident_workgroups()) ++rounds;
     // Under an azimuth shard most workgroups end at their block bounds (k_cull's early out) and the ones that stay are as
     // long as their rounds, which a wave takes two at a time, each pair a memory round trip and a test behind the other: the
-    // few live workgroups of a shard do better with the shortest chain, whatever the number of workgroups that come and go
-    if (sector) { static const int r = lsi::tune_int("LS_CULL_SHARD_ROUNDS", 2); rounds = (uint32_t)std::min<int>(std::max(r, 2), (int)std::max(rounds, 2u)); }
+    // few live workgroups of a shard do better with a short chain -- but every workgroup that comes and goes is four waves
+    // to launch, and three frames overlap: the shortest chain is not the best either
+    // (rounds 2 / 4 / 8 at SYN-10M, an eighth of a turn, three frames in flight as graphs: the rank with the fewest triangles in
+    // its sector 10.4 / 10.2 / 10.9 us per frame, the one with the most 14.4 / 13.6 / 13.3 -- four)
+    if (sector) { static const int r = lsi::tune_int("LS_CULL_SHARD_ROUNDS", 4); rounds = (uint32_t)std::min<int>(std::max(r, 2), (int)std::max(rounds, 2u)); }
     batch.cull_rounds = rounds;
     const uint32_t per_wg = rounds * kBlock;
     for (uint32_t i = 0; i < n_srcs; ++i) {
@@ -1418,7 +1435,17 @@ bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch
         batch.seg_cap[batch.n] = seg_cap;
         batch.g[batch.n] = src;
         // k_project's workgroups per segment: room for cull_grid_pct() % of the groups to survive (a wave loops when more do)
-        const uint32_t seg_blocks = std::max(1u, (uint32_t)(((unsigned long long)(seg_cap / kGroupsPerWorkgroup) * grid_pct + 99u) / 100u));
+        uint32_t seg_blocks = std::max(1u, (uint32_t)(((unsigned long long)(seg_cap / kGroupsPerWorkgroup) * grid_pct + 99u) / 100u));
+        if (survivors_hint) {
+            // A recent frame's fullest segment held survivors_hint - 1 groups (read back without a wait: k_pack leaves the
+            // number in pinned host memory): a quarter of headroom on that, rounded up to an eighth of itself so that the
+            // grid -- a node parameter of a captured frame graph -- changes only when the scene does.  Never more than the
+            // percentage above gives; a segment that outgrows it is walked in rounds (project_body's loop).
+            const uint32_t need = ((survivors_hint - 1u) + (survivors_hint - 1u) / 4u + kGroupsPerWorkgroup - 1u) / kGroupsPerWorkgroup + 1u;
+            uint32_t q = 1u;
+            while (q * 16u <= need) q <<= 1;
+            seg_blocks = std::min(seg_blocks, (need + q - 1u) / q * q);
+        }
         batch.seg_blocks[batch.n] = seg_blocks;
         blocks += kCullSegs * seg_blocks;
         entries += kCullSegs * seg_cap;
@@ -1441,7 +1468,7 @@ uint32_t project_cull_entries(const GeomSource *srcs, uint32_t n_srcs, bool sect
 
 void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *srcs, uint32_t n_srcs, unsigned long long *best,
                     void *big, uint32_t big_capacity, uint32_t *big_count, unsigned long long *stats, const FinishPackArgs *rider,
-                    uint32_t *cull_list, hipEvent_t ev_start, hipEvent_t ev_stop)
+                    uint32_t *cull_list, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t survivors_hint)
 {
     if (!(pp.tb.V * pp.tb.naz)) return;
     TL_HOST_HOOK(s);
@@ -1500,7 +1527,8 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         uint32_t grid_pct = cull_grid_pct();
         if (pp.sector_on && pp.tb.H) grid_pct = std::max(4u, std::min(grid_pct, (uint32_t)((100ull * pp.tb.naz + pp.tb.H - 1u) / pp.tb.H)));
         { static const int shard_pct = lsi::tune_int("LS_PROJECT_SHARD_GRID_PCT", 0); if (shard_pct > 0 && pp.sector_on) grid_pct = (uint32_t)shard_pct; }
-        if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries, pp.sector_on != 0, grid_pct)) {
+        { static const int use_hint = lsi::tune_int("LS_PROJECT_GRID_HINT", 1); if (!use_hint) survivors_hint = 0; }
+        if (fill_culled_batch(srcs, n_srcs, batch, blocks, entries, pp.sector_on != 0, grid_pct, survivors_hint)) {
             const dim3 cgrid(batch.cull_first[batch.n]);
             CullBatch cb;
             std::memset(static_cast<void *>(&cb), 0, sizeof(cb));   // (argument bytes are compared frame to frame by the frame graph)

@@ -537,7 +537,7 @@ int frame_graph_close(ls_tracer *tr)
                 idle = true;
             }
             tr->fg_last_patched |= 1u << (i < 31 ? i : 31);
-            void *argv[16];
+            void *argv[20];
             for (uint32_t a = 0; a < now.n_args; ++a) argv[a] = now.blob.data() + now.arg_off[a];
             hipKernelNodeParams p;
             std::memset(&p, 0, sizeof(p));
@@ -613,14 +613,14 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         const bool pipelined = tr->opt_pipeline == 1 && !tr->opt_count && !tr->opt_timing;
         const bool multi = tr->opt_pipeline == 2 && !tr->opt_count && !tr->opt_timing;
         // ls_trace_scene_begin: the finish and pack passes report their progress to the host (one frame in flight only)
-        ls::ProgressArgs pg{nullptr, 0u, 0u};
+        ls::ProgressArgs pg{nullptr, 0u, 0u, nullptr};
         if (tr->progress_req && hv && compact && !pipelined && !multi && !tr->opt_count && !tr->opt_timing) {
             if (++tr->progress_epoch == 0u) tr->progress_epoch = 1u;
             // the pack pass's two launches split where the POINTS halved last frame (the upper rings mostly see sky);
             // a frame without a hint, or with another raster, splits the ray blocks in the middle
             if (tr->pack_split == 0u || tr->pack_split >= n_blocks || tr->pack_split_blocks != n_blocks) tr->pack_split = n_blocks / 2u;
             tr->pack_split_blocks = n_blocks;
-            pg = {tr->h_progress, tr->progress_epoch, tr->pack_split};
+            pg = {tr->h_progress, tr->progress_epoch, tr->pack_split, nullptr};
             progress = true;
         }
         if (!pipelined && !multi && (rc = flush_pipeline(tr))) return rc;
@@ -728,10 +728,16 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             }
         }
         const ls::GeomTable gt = geom_table(tr);
+        // how full the survivor segments of a recent culled frame were (k_pack / k_finish_pack leave 1 + the fullest one in
+        // pinned host memory, no wait): sizes this frame's k_project<CULLED> grid.  A scene that changes under it costs a frame
+        // or three of waves walking their segment in rounds, never a wrong cloud.  The geometry set it speaks for is the
+        // handle's: a new layout forgets it.
+        uint32_t *hint_word = tr->h_status + 1;
+        const uint32_t survivors_hint = any_culled ? __atomic_load_n(hint_word, __ATOMIC_RELAXED) : 0u;
         if (pipelined) {
             // one launch: this frame's k_project workgroups + the previous frame's finish + pack workgroups
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, nullptr,
-                               tr->pipe_pending ? &tr->pipe_fa : nullptr, cull_list);
+                               tr->pipe_pending ? &tr->pipe_fa : nullptr, cull_list, nullptr, nullptr, survivors_hint);
             if (++tr->pack_epoch == 0u) {   // the epoch tag wrapped: no stale status word may match
                 LS_HIP(hipMemsetAsync(tr->pack_status.p, 0, tr->pack_status.cap * 8, s));
                 tr->pack_epoch = 1u;
@@ -758,6 +764,7 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             fa.n_points = d_n;
             fa.n_blocks = n_blocks;
             fa.compact = compact;
+            fa.cull_hint = nullptr;   // (rider mode re-arms the counters of the frame after the next: nothing to read there)
             tr->pipe_pending = true;
             ++tr->pipe_seq;
             if (readback && (rc = flush_pipeline(tr))) return rc;
@@ -769,7 +776,7 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             if (ride) mark(tr, 8, &ev_k1);
             { static const int no_hits = tune_int("LS_PACK_NO_HITS", 0); if (no_hits && !readback) d_hits = nullptr; }   // (experiment: what the 16-byte hit records cost)
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, stats, nullptr, cull_list,
-                               ev_k0, ev_k1);
+                               ev_k0, ev_k1, survivors_hint);
             if (!ride) mark(tr, 8);
             // Three-stream mode, a shard of at most kFuseBlocks ray blocks: finish + pack as ONE launch (k_finish_pack: the
             // chained prefix of rider mode; a few hundred workgroups, all resident at once, publish within a microsecond of
@@ -781,7 +788,8 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
             // of-a-turn shard at SYN-1M: 10.9 - 15.9 -> 8.2 - 11.9 us per frame); inside a captured frame graph a node costs
             // the host nothing and the look-back's polls cost more than the second read of the keys (8.3 -> 9.1 us, 10.8 -> 12.0
             // at SYN-10M).
-            const bool graphed = multi && tr->opt_frame_graph && !tr->fg_broken;
+            static const int fuse_in_graph = tune_int("LS_FUSE_IN_GRAPH", 0);   // (experiment)
+            const bool graphed = multi && tr->opt_frame_graph && !tr->fg_broken && !fuse_in_graph;
             static const int fuse_single = tune_int("LS_FUSE_FINISH_PACK_SINGLE", 0);   // (experiment: also with one frame in flight)
             if ((multi || fuse_single) && !graphed && !progress && !stats && n_blocks <= fuse_blocks && tr->pack_status_ms.p) {
                 ls::FinishPackArgs fa;
@@ -801,6 +809,7 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                 fa.n_points = d_n;
                 fa.n_blocks = n_blocks;
                 fa.compact = compact;
+                fa.cull_hint = any_culled ? hint_word : nullptr;
                 ls::launch_finish_pack(s, pp, fa, nullptr);
                 mark(tr, 9);
                 mark(tr, 10);
@@ -808,8 +817,9 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                 ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
                 mark(tr, 9);
                 // (a frame that reports its progress sends 8-byte (ray, t) records: ls_trace_scene_expand rebuilds the points)
+                pg.cull_hint = any_culled ? hint_word : nullptr;
                 ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n,
-                                     progress ? 2u : compact, progress ? &pg : nullptr);
+                                     progress ? 2u : compact, &pg);
                 mark(tr, 10);
             }
             if (multi) {

@@ -1,10 +1,15 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, in one go (GPU box, repo root):  bash tools/final_measure.sh r04
-TAG=${1:-r04}
+# Everything profiles/ holds for a round (GPU box, repo root):  bash tools/final_measure.sh r05 [a|b|c|all]
+#   a: bench lines of the other workloads and modes, lsbench, the group through a one-rank communicator, shard costs, BVH at configs[4]
+#   b: the profiles (kernel stats, HBM bytes, SQ / TCC counters) and, behind them, the two headline lines that quote them
+#   c: soaks
+TAG=${1:-r05}
+PART=${2:-all}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
 mkdir -p gpurun_out/final
 : > gpurun_out/final/bench.err
+if [ "$PART" = a ] || [ "$PART" = all ]; then
 python bench.py --no-cpu-baseline --no-dropin --pipeline 1 > gpurun_out/final/bench_${TAG}_projection_mode1.json 2>> gpurun_out/final/bench.err
 python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m > gpurun_out/final/bench_${TAG}_projection_10m.json 2>> gpurun_out/final/bench.err
 python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m --no-cull > gpurun_out/final/bench_${TAG}_projection_10m_nocull.json 2>> gpurun_out/final/bench.err
@@ -30,10 +35,20 @@ LS_BENCH_FORCE_GROUP=1 python bench.py --no-cpu-baseline --no-dropin --group-fla
 (cd tools/micro && ./loads_probe) > gpurun_out/final/${TAG}_loads_probe_micro.txt 2>&1
 (cd tools/micro && ./atomic_rate) > gpurun_out/final/${TAG}_atomic_rate_micro.txt 2>&1
 (cd tools/micro && ./strided_h2d) > gpurun_out/final/${TAG}_strided_h2d_micro.txt 2>&1
-# what ONE of eight ranks does per frame (no collective): kernel times of an eighth-of-a-turn shard, SYN-1M and SYN-10M
-python tools/shard_cost.py 2 1,8 > gpurun_out/final/${TAG}_shard_cost_1m.txt 2>> gpurun_out/final/bench.err
-W=syn128x10m python tools/shard_cost.py 2 1,8 > gpurun_out/final/${TAG}_shard_cost_10m.txt 2>> gpurun_out/final/bench.err
+# what ONE of eight ranks does per frame (no collective): every rank of an eighth-of-a-turn split, SYN-1M and SYN-10M, streamed
+# through the C++ loop (one / three frames in flight / three as frame graphs); then the shard's kernels under rocprofv3
+python tools/shard_cost.py 2 1,8 all > gpurun_out/final/${TAG}_shard_cost_1m.txt 2>> gpurun_out/final/bench.err
+W=syn128x10m python tools/shard_cost.py 2 1,8 all > gpurun_out/final/${TAG}_shard_cost_10m.txt 2>> gpurun_out/final/bench.err
+SPECS="1m_one:syn128x1m:2:one 1m_graph:syn128x1m:2:graph 10m_one:syn128x10m:2:one 10m_graph:syn128x10m:2:graph" bash tools/shard_profile.sh ${TAG} > /dev/null 2>&1
+grep -v "calls       [0-9] \|calls      [1-9][0-9] " gpurun_out/shard_prof_${TAG}/summary.txt > gpurun_out/final/${TAG}_shard_kernels.txt
 python tools/dropin_bench.py 50 > gpurun_out/final/dropin_${TAG}.json 2>> gpurun_out/final/bench.err
+# BASELINE configs[4] on the BVH engine at its own size: build, poses, refit of the moving instance, classic refit of all 10 M
+python tools/bvh_cfg5_cost.py 60 > gpurun_out/final/${TAG}_bvh_cfg5_cost.json 2>> gpurun_out/final/bench.err
+for ph in build poses refit_ben classic; do echo "== $ph"; PHASE=$ph bash tools/rocprof_kernels.sh cfg5_$ph tools/bvh_cfg5_cost.py 30 | sort -k5 -n -r | head -16; tail -1 gpurun_out/rp_cfg5_$ph/stdout.log; done > gpurun_out/final/${TAG}_bvh_cfg5_kernels.txt 2>&1
+find gpurun_out/rp_cfg5_* -name "*kernel_trace.csv" -delete
+python bench.py --workload cfg5 --engine bvh --no-cpu-baseline --no-dropin > gpurun_out/final/bench_${TAG}_bvh_cfg5.json 2>> gpurun_out/final/bench.err
+fi
+if [ "$PART" = b ] || [ "$PART" = all ]; then
 bash tools_profile.sh ${TAG} > gpurun_out/final/profile.log 2>&1
 python tools/prof_summary.py gpurun_out/prof_${TAG} gpurun_out/final/${TAG}_projection > gpurun_out/final/prof_summary.log 2>&1
 python3 - gpurun_out/prof_${TAG}/stats_one gpurun_out/final/${TAG}_projection_kernel_stats_one_in_flight.csv <<'PY'
@@ -54,8 +69,12 @@ cp gpurun_out/prof_${TAG}/bench_stats.json gpurun_out/final/${TAG}_projection_be
 BENCH_ARGS="--engine bvh --no-dropin" bash tools_pmc.sh ${TAG}_bvh "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/final/pmc_bvh.log 2>&1
 bash tools/bvh_stats.sh ${TAG} > gpurun_out/final/bvh_stats.log 2>&1
 python tools/pmc_to_hbm.py gpurun_out/pmc_${TAG}_bvh/summary.txt gpurun_out/final/${TAG}_bvh_hbm.json "bench.py --engine bvh (instanced hierarchies: nothing built per frame)" >> gpurun_out/final/pmc_bvh.log 2>&1
-# the two headline lines last: they read `roofline.traffic` from the profiles just taken (same kernel sources, same box)
-cp gpurun_out/final/${TAG}_projection_hbm.json gpurun_out/final/${TAG}_bvh_hbm.json profiles/
+# what binds the kernels: SQ / TCC counters of the three per-frame paths and of an eighth-of-a-turn shard
+bash tools/sq_profile.sh ${TAG} > gpurun_out/final/sq_profile.log 2>&1
+cp gpurun_out/sq_${TAG}/*_sq.txt gpurun_out/sq_${TAG}/*_sq.json gpurun_out/final/ 2>/dev/null
+for f in projection projection_10m bvh shard_1m shard_10m; do [ -f gpurun_out/final/${f}_sq.txt ] && mv gpurun_out/final/${f}_sq.txt gpurun_out/final/${TAG}_${f}_sq.txt; [ -f gpurun_out/final/${f}_sq.json ] && mv gpurun_out/final/${f}_sq.json gpurun_out/final/${TAG}_${f}_sq.json; done
+# the two headline lines last: they read `roofline.traffic` and `roofline.secondary` from the profiles just taken (same kernel sources, same box)
+cp gpurun_out/final/${TAG}_projection_hbm.json gpurun_out/final/${TAG}_bvh_hbm.json gpurun_out/final/${TAG}_projection_sq.json gpurun_out/final/${TAG}_bvh_sq.json profiles/
 python bench.py > gpurun_out/final/${TAG}_projection_bench.json 2>> gpurun_out/final/bench.err
 python bench.py --engine bvh --no-dropin > gpurun_out/final/${TAG}_bvh_bench.json 2>> gpurun_out/final/bench.err
 python bench.py --engine bvh --no-dropin --no-cpu-baseline --classic-bvh > gpurun_out/final/bench_${TAG}_bvh_classic.json 2>> gpurun_out/final/bench.err
@@ -70,5 +89,10 @@ tail -2 gpurun_out/rp_${TAG}_rebuild/stdout.log >> gpurun_out/final/${TAG}_bvh_r
 # and a refit per frame (classic hierarchy, poses restated): transform, leaves + range tree, k_refit_nodes
 bash tools/rocprof_kernels.sh ${TAG}_refit tools/refit_cost.py 50 > gpurun_out/final/${TAG}_bvh_refit_kernels.txt 2>&1
 tail -2 gpurun_out/rp_${TAG}_refit/stdout.log >> gpurun_out/final/${TAG}_bvh_refit_kernels.txt
+fi
+if [ "$PART" = c ] || [ "$PART" = all ]; then
+{ python tests/analysis/soak.py 60; python tests/analysis/soak_bvh.py 60; python tests/analysis/soak_shard.py 120
+  for fl in 0 4 2; do python tests/analysis/soak_group.py 40 $fl; done; } > gpurun_out/final/${TAG}_soak.txt 2>&1
+fi
 ls gpurun_out/final
 tail -3 gpurun_out/final/bench.err
