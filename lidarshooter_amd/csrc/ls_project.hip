@@ -222,7 +222,11 @@ __device__ __forceinline__ void test_cell(const ProjectParams &pp, const ChanTab
 {
     // LidarDevice.cpp:310-316: d = (sin(theta)cos(phi), sin(theta)sin(phi), cos(theta))
     const float st = ct.sin_theta[v];
-    const float2 cs = ct.cols ? ct.cols[h - pp.tb.az0] : pp.tb.cs_phi[h];   // (uniform: a cell trip of a small shard waits for no global load)
+#ifdef LS_EXP_COLS_LDS
+    const float2 cs = ct.cols ? ct.cols[h - pp.tb.az0] : pp.tb.cs_phi[h];   // (experiment, tools/exp_build.sh: a small shard's column directions from LDS)
+#else
+    const float2 cs = pp.tb.cs_phi[h];
+#endif
     const V3 d = {st * cs.x, st * cs.y, ct.cos_theta[v]};
     float t;
     if (tri_test(d, v0, e1, e2, NgC, t)) {
@@ -292,7 +296,11 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 #define TL_HOST_HOOK(s)
 #endif
 
-template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
+// DEAL (with CULLED): a segment's survivors are dealt to its waves at a stride instead of taken in runs (azimuth shards).  A
+// template argument, not a flag read at run time: behind a uniform branch the list entry's read-ahead (it goes out together
+// with the segment's count) turned into a dependent load and the full raster's culled launch at ten million triangles took
+// 36.3 us instead of 33.9.
+template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED, bool DEAL = false>
 __device__ __forceinline__ void project_body(const ProjectParams &pp, const GeomBatch &batch, uint32_t block_idx, ProjectLds &lds,
                                              float *s_chan /* LDS_TABLES: tan_up, tan_dn, sin_theta, cos_theta, perm */,
                                              unsigned long long *__restrict__ best, BigItem *__restrict__ big,
@@ -340,16 +348,16 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         // dependent ones (count -> entry -> corners), which is what this kernel's waves spend their time in.  Positions
         // behind the count hold survivors of earlier frames or nothing: read (inside the segment), never used
         seg_list = cull_list + batch.list_first[gi] + (size_t)seg * batch.seg_cap[gi];
-        if (!pp.cull_deal) first_entry = seg_list[min(rank * kPerWave + lane / kCullGroup, batch.seg_cap[gi] - 1u)];
+        if (!DEAL) first_entry = seg_list[min(rank * kPerWave + lane / kCullGroup, batch.seg_cap[gi] - 1u)];
         n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)big_count[kCullCountAt + (gi * kCullSegs + seg) * 16u]);
-        // DEALT (pp.cull_deal, azimuth shards): the segment's n_live survivors go to its W = ceil(n_live / kPerWave) waves like
+        // DEALT (DEAL, azimuth shards): the segment's n_live survivors go to its W = ceil(n_live / kPerWave) waves like
         // cards -- wave r takes entries r, r + W, r + 2 W ... -- instead of kPerWave consecutive ones each.  Consecutive
         // survivors are Morton neighbours; a shard's few hundred waves leave the chip three quarters empty, so its kernel
         // is as long as its heaviest wave, and the waves that hold nothing but the sector's nearest ground walked 12 trips of
         // 64 cells where the mean is 2.4 (tests/analysis/shard_balance.py: dealt, the heaviest walks 4).  Costs the memory
         // round trip the read-ahead above saves (the stride needs the count first)
-        n_deal = pp.cull_deal ? (n_live + kPerWave - 1u) / kPerWave : 0u;
-        if (pp.cull_deal ? seg_block * (kBlock / 64) >= n_deal : seg_block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
+        n_deal = DEAL ? (n_live + kPerWave - 1u) / kPerWave : 0u;
+        if (DEAL ? seg_block * (kBlock / 64) >= n_deal : seg_block * (kBlock / 64) * kPerWave >= n_live) return;   // uniform over the workgroup: before any barrier
     }
     // ---- which triangle this lane takes, and its loads, BEFORE the channel tables are staged: index load -> vertex
     //      gather is a chain of two memory round trips, the staging (global -> LDS, then a workgroup barrier) a third
@@ -361,7 +369,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
         if (COUNT && rank == 0 && lane == 0) atomicAdd(&stats[1], (unsigned long long)n_live);   // counts[2]: surviving groups
         // (a full turn's wave takes consecutive survivors; taking them at a stride, as the unculled path's spread runs do,
         // was within noise at 10 M triangles and puts the count in front of the entry load again)
-        if (pp.cull_deal) {
+        if (DEAL) {
             live_wave = rank < n_deal;
             const uint32_t e = (lane / kCullGroup) * n_deal + rank;
             if (live_wave && e < n_live) k = seg_list[e] * kCullGroup + (lane % kCullGroup);
@@ -418,6 +426,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             s_chan[4 * V + i] = __uint_as_float(pp.chan_perm[i]);
         }
         ct = {s_chan, s_chan + V, s_chan + 2 * V, s_chan + 3 * V, reinterpret_cast<const uint32_t *>(s_chan + 4 * V), nullptr};
+#ifdef LS_EXP_COLS_LDS
         if (pp.cols_lds) {
             // a small shard's column directions too (behind the channel tables, eight-byte aligned): 4 KB for an eighth of
             // 4 096 columns.  The full raster's 32 KB would cost the kernel its residency (+4 KB of LDS per
@@ -426,6 +435,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
             for (uint32_t i = threadIdx.x; i < pp.tb.naz; i += kBlock) s_cols[i] = pp.tb.cs_phi[pp.tb.az0 + i];
             ct.cols = s_cols;
         }
+#endif
         __syncthreads();
     }
     if (!live_wave) return;   // (no barrier follows)
@@ -535,8 +545,8 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     if (COUNT && lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);
     if (!CULLED) break;
     rank += batch.seg_blocks[gi] * (kBlock / 64);   // the segment's next wave-load that nobody else takes
-    if (pp.cull_deal ? rank >= n_deal : rank * kPerWave >= n_live) break;
-    const uint32_t e = pp.cull_deal ? (lane / kCullGroup) * n_deal + rank : rank * kPerWave + lane / kCullGroup;
+    if (DEAL ? rank >= n_deal : rank * kPerWave >= n_live) break;
+    const uint32_t e = DEAL ? (lane / kCullGroup) * n_deal + rank : rank * kPerWave + lane / kCullGroup;
     k = e < n_live ? seg_list[e] * kCullGroup + (lane % kCullGroup) : 0xFFFFFFFFu;
     load_corners();
     }
@@ -544,7 +554,7 @@ __device__ __forceinline__ void project_body(const ProjectParams &pp, const Geom
     TL_END(block_idx, w, lane, total);
 }
 
-template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED>
+template <bool COUNT, bool LDS_TABLES, bool MULTI, bool CULLED, bool DEAL = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_project(ProjectParams pp, GeomBatch batch,
                                                     unsigned long long *__restrict__ best, BigItem *__restrict__ big,
                                                     uint32_t big_capacity, uint32_t *__restrict__ big_count,
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k
 {
     __shared__ ProjectLds lds;
     extern __shared__ __attribute__((aligned(16))) float s_chan[];
-    project_body<COUNT, LDS_TABLES, MULTI, CULLED>(pp, batch, blockIdx.x, lds, s_chan, best, big, big_capacity, big_count, stats, cull_list);
+    project_body<COUNT, LDS_TABLES, MULTI, CULLED, DEAL>(pp, batch, blockIdx.x, lds, s_chan, best, big, big_capacity, big_count, stats, cull_list);
 }
 
 
@@ -921,7 +931,7 @@ __device__ __forceinline__ bool group_meets_raster(const ProjectParams &pp, cons
 constexpr uint32_t kCullMaxRounds = 8;
 constexpr uint32_t kCullMaxPerBlock = kCullMaxRounds * kBlock;
 
-template <bool LDS_TABLES, bool COUNT, bool LUT /* needs LDS_TABLES */>
+template <bool LDS_TABLES, bool COUNT, bool LUT /* needs LDS_TABLES */, bool SECTOR /* an azimuth shard: pp.sector_on */>
 __global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, CullBatch batch, uint32_t *__restrict__ list, uint32_t *__restrict__ counts,
                                                  unsigned long long *__restrict__ stats)
 {
@@ -946,12 +956,13 @@ __global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, CullBatch bat
     // table staging and a barrier's worth of time.
     static_assert(kCullMaxRounds * (kBlock / 64) <= 32, "the workgroup's block bounds fit the lanes of one wave, their ballot a word");
     const float4 *__restrict__ block_boxes = src.boxes + 2 * (size_t)n_groups;
-    const uint32_t my_block = g0 / kCullBlockGroups + lane;
-    const bool has_block = lane < rounds * (kBlock / 64) && my_block < n_blocks;
+    // (the full turn has no such early out: there a wave looks at its own blocks only -- lane `it` holds round `it`'s)
+    const uint32_t my_block = SECTOR ? g0 / kCullBlockGroups + lane : g0 / kCullBlockGroups + lane * (kBlock / 64) + w;
+    const bool has_block = (SECTOR ? lane < rounds * (kBlock / 64) : lane < rounds) && my_block < n_blocks;
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
     if (has_block) { c0 = block_boxes[2 * (size_t)my_block]; c1 = block_boxes[2 * (size_t)my_block + 1]; }
     const LinearMap &m = src.m;
-    if (pp.sector_on && !__any(has_block && !box_out_of_sector(pp, m, c0, c1))) return;   // (the same in all four waves: no barrier is left waiting)
+    if (SECTOR && !__any(has_block && !box_out_of_sector(pp, m, c0, c1))) return;   // (the same in all four waves: no barrier is left waiting)
     const uint32_t V = pp.tb.V;
     ChanQuery cq = {pp.chan_tan_up, pp.chan_tan_dn, pp.chan_lut, pp.lut_t0, pp.lut_scale, V};
     if (threadIdx.x == 0) s_n = 0;
@@ -973,8 +984,9 @@ __global__ __launch_bounds__(kBlock) void k_cull(ProjectParams pp, CullBatch bat
     __syncthreads();
     const bool block_alive = group_meets_raster<LUT>(pp, cq, m, c0, c1);
     const uint32_t alive_all = (uint32_t)__ballot(has_block && block_alive);
-    uint32_t alive = 0;   // bit `it`: this wave's block of round `it`
-    for (uint32_t it = 0; it < rounds; ++it) alive |= ((alive_all >> (it * (kBlock / 64) + w)) & 1u) << it;
+    uint32_t alive = SECTOR ? 0u : alive_all & ((1u << rounds) - 1u);   // bit `it`: this wave's block of round `it`
+    if (SECTOR)
+        for (uint32_t it = 0; it < rounds; ++it) alive |= ((alive_all >> (it * (kBlock / 64) + w)) & 1u) << it;
     // the rounds whose block is alive, two at a time: both rounds' bound loads go out first, then the two tests -- straight-
     // line code -- interleave (an odd round out is tested on its own: its partner is a predicated-off copy of itself)
     if (COUNT && lane == 0 && alive) atomicAdd(&stats[2], (unsigned long long)(__popc(alive) * kCullBlockGroups));   // counts[3]: group bounds read
@@ -1499,10 +1511,10 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
         const bool timed = ev_start || ev_stop;
         hipEvent_t e0 = ev_start;
         ev_start = nullptr;   // the first k_project launch of the frame starts the clock, the last one stops it
-#define LS_LAUNCH(C, L, M, K) do { \
-            if (timed) hipExtLaunchKernelGGL((k_project<C, L, M, K>), grid, dim3(kBlock), (L) ? (uint32_t)lds : 0u, s, e0, ev_stop, 0u, pp, batch, best, bq, big_capacity, big_count, stats, list); \
-            else launch_k(k_project<C, L, M, K>, grid, dim3(kBlock), (L) ? (uint32_t)lds : 0u, s, pp, batch, best, bq, big_capacity, big_count, stats, list); } while (0)
-#define LS_LAUNCH_K(C, L, M) do { if (culled) LS_LAUNCH(C, L, M, true); else LS_LAUNCH(C, L, M, false); } while (0)
+#define LS_LAUNCH(C, L, M, K, D) do { \
+            if (timed) hipExtLaunchKernelGGL((k_project<C, L, M, K, D>), grid, dim3(kBlock), (L) ? (uint32_t)lds : 0u, s, e0, ev_stop, 0u, pp, batch, best, bq, big_capacity, big_count, stats, list); \
+            else launch_k(k_project<C, L, M, K, D>, grid, dim3(kBlock), (L) ? (uint32_t)lds : 0u, s, pp, batch, best, bq, big_capacity, big_count, stats, list); } while (0)
+#define LS_LAUNCH_K(C, L, M) do { if (culled && pp.cull_deal) LS_LAUNCH(C, L, M, true, true); else if (culled) LS_LAUNCH(C, L, M, true, false); else LS_LAUNCH(C, L, M, false, false); } while (0)
         if (lt) {
             if (stats) { if (multi) LS_LAUNCH_K(true, true, true); else LS_LAUNCH_K(true, true, false); }
             else { if (multi) LS_LAUNCH_K(false, true, true); else LS_LAUNCH_K(false, true, false); }
@@ -1547,13 +1559,15 @@ void launch_project(hipStream_t s, const ProjectParams &pp, const GeomSource *sr
             const uint32_t clds = lt ? (uint32_t)(2 * ((size_t)pp.tb.V + 2) * sizeof(float) + (lut ? kCullLutBuckets * sizeof(uint16_t) : 0)) : 0u;
             uint32_t *counts = big_count + kCullCountAt;
             // (ev_start: the cull pass belongs to the timed stage, the clock starts with it)
-#define LS_CULL(L, C, U) do { \
-                if (ev_start) hipExtLaunchKernelGGL((k_cull<L, C, U>), cgrid, dim3(kBlock), clds, s, ev_start, nullptr, 0u, pp, cb, cull_list, counts, stats); \
-                else launch_k(k_cull<L, C, U>, cgrid, dim3(kBlock), clds, s, pp, cb, cull_list, counts, stats); } while (0)
+#define LS_CULL_S(L, C, U, S) do { \
+                if (ev_start) hipExtLaunchKernelGGL((k_cull<L, C, U, S>), cgrid, dim3(kBlock), clds, s, ev_start, nullptr, 0u, pp, cb, cull_list, counts, stats); \
+                else launch_k(k_cull<L, C, U, S>, cgrid, dim3(kBlock), clds, s, pp, cb, cull_list, counts, stats); } while (0)
+#define LS_CULL(L, C, U) do { if (pp.sector_on) LS_CULL_S(L, C, U, true); else LS_CULL_S(L, C, U, false); } while (0)
             if (lut) { if (stats) LS_CULL(true, true, true); else LS_CULL(true, false, true); }
             else if (lt) { if (stats) LS_CULL(true, true, false); else LS_CULL(true, false, false); }
             else { if (stats) LS_CULL(false, true, false); else LS_CULL(false, false, false); }
 #undef LS_CULL
+#undef LS_CULL_S
             ev_start = nullptr;
             launch(batch, blocks, cull_list);
             culled_done = true;

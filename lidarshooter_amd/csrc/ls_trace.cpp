@@ -89,7 +89,7 @@ ls::ProjectParams project_params(const ls_tracer *tr)
     static const int deal = tune_int("LS_PROJECT_CULL_DEAL", -1);
     pp.cull_deal = deal >= 0 ? deal : pp.sector_on;
     static const int cols_lds = tune_int("LS_PROJECT_COLS_LDS", -1);
-    // (off: measured on an eighth of a turn -- at SYN-1M 0.1 - 0.4 us off a frame, at SYN-10M 2 us ON the rank with the
+    // (a build option, -DLS_EXP_COLS_LDS, and off: measured on an eighth of a turn -- at SYN-1M 0.1 - 0.4 us off a frame, at SYN-10M 2 us ON the rank with the
     // most triangles in its sector: the 4 KB cost two resident workgroups per CU, and its grid is thousands of workgroups
     // that come and go.  Kept behind the experiment knob.)
     pp.cols_lds = cols_lds > 0 && tr->naz <= ls::kColsLdsMax && tr->V <= 2048u ? 1 : 0;
