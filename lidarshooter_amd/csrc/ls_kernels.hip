@@ -81,7 +81,18 @@ __global__ __launch_bounds__(kBlock) void k_quads_to_triangles(const uint32_t *_
 __global__ __launch_bounds__(kBlock) void k_index_max(const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ out)
 {
     uint32_t m = 0;
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) m = max(m, idx[j]);
+    // sixteen bytes per load, four loads in flight per lane (a 256-workgroup grid: 256 atomics on the one word), when the
+    // array is aligned for it -- the library's own copies are; a caller's array handed over in place need not be
+    const uint32_t n4 = (reinterpret_cast<uintptr_t>(idx) & 15u) == 0 ? n / 4u : 0u;
+    const uint4 *__restrict__ idx4 = reinterpret_cast<const uint4 *>(idx);
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    for (; j + 3u * stride < n4; j += 4u * stride) {
+        const uint4 a = idx4[j], b = idx4[j + stride], c = idx4[j + 2u * stride], d = idx4[j + 3u * stride];
+        m = max(max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))), max(m, max(max(max(c.x, c.y), max(c.z, c.w)), max(max(d.x, d.y), max(d.z, d.w)))));
+    }
+    for (; j < n4; j += stride) { const uint4 a = idx4[j]; m = max(m, max(max(a.x, a.y), max(a.z, a.w))); }
+    for (j = 4u * n4 + blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) m = max(m, idx[j]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
     __shared__ uint32_t s_m[kBlock / 64];
@@ -1520,7 +1531,7 @@ void launch_index_max(hipStream_t s, const uint32_t *idx, uint32_t n, uint32_t *
 {
     (void)hipMemsetAsync(d_max, 0, 4, s);
     if (!n) return;
-    const uint32_t blocks = std::min<uint32_t>(blocks_for(n), 1024u);   // (at most 1 024 atomics on the one word)
+    const uint32_t blocks = std::min<uint32_t>(blocks_for((n + 3u) / 4u), 256u);
     hipLaunchKernelGGL(k_index_max, dim3(blocks), dim3(kBlock), 0, s, idx, n, d_max);
 }
 

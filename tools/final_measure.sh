@@ -94,5 +94,9 @@ if [ "$PART" = c ] || [ "$PART" = all ]; then
 { python tests/analysis/soak.py 60; python tests/analysis/soak_bvh.py 60; python tests/analysis/soak_shard.py 120
   for fl in 0 4 2; do python tests/analysis/soak_group.py 40 $fl; done; } > gpurun_out/final/${TAG}_soak.txt 2>&1
 fi
+# (gpurun copies back 64 MiB at most: the raw traces and counter dumps have been condensed into gpurun_out/final by now)
+find gpurun_out -type f \( -name "*kernel_trace.csv" -o -name "*counter_collection.csv" -o -name "*.rocpd" -o -name "*.db" \) -not -path "*/final/*" -delete
+find gpurun_out -type f -size +4M -not -path "*/final/*" -delete
+du -sh gpurun_out
 ls gpurun_out/final
 tail -3 gpurun_out/final/bench.err
