@@ -42,7 +42,8 @@ void fill_tables(ls_tracer *tr, std::vector<float> &tab)
     float *up = tab.data() + 2 * (size_t)V + 2 * (size_t)H, *dn = up + V;
     for (uint32_t i = 0; i < V; ++i) {
         const double chi = tr->vertical[perm[i]];
-        const double hi = chi + kProjectMarginDeg, lo = chi - kProjectMarginDeg;
+        static const double emargin = tune_int("LS_ELEV_MARGIN_MICRODEG", (int)std::lround(kProjectElevMarginDeg * 1e6)) * 1e-6;
+        const double hi = chi + emargin, lo = chi - emargin;
         float tu = hi >= 90.0 ? INFINITY : (hi <= -90.0 ? -INFINITY : static_cast<float>(std::tan(hi * M_PI / 180.0)));
         float td = lo <= -90.0 ? -INFINITY : (lo >= 90.0 ? INFINITY : static_cast<float>(std::tan(lo * M_PI / 180.0)));
         up[i] = std::nextafter(tu, INFINITY);

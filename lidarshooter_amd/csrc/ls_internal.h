@@ -293,7 +293,15 @@ inline void release(DevBuf<T> &b)
     b.cap = 0;
 }
 
-constexpr float kProjectMarginDeg = 0.005f;  // ~8.7e-5 rad: 5x the polynomial atan2 error (1e-3 deg) + table / test rounding
+constexpr float kProjectMarginDeg = 0.005f;  // AZIMUTH slack of the footprints, ~8.7e-5 rad: 5x the polynomial atan2 error (1e-3 deg) + table / test rounding
+// ELEVATION slack of the channel tables (tan(chi +- margin), fill_tables): what it has to cover is the distance between a
+// channel's nominal elevation and the elevation of the ray the kernels actually build for it -- theta = float((90 - chi) pi / 180)
+// is off by half an ulp of ~1.5 rad (6e-8 rad), sinf / cosf by an ulp each, |(cos phi, sin phi)| by 1.2e-7 relative: under
+// 3e-7 rad = 1.7e-5 degrees in all (the quotients of the band test and k_cull's remainder carry their own relative slack).
+// Until round 5 the azimuth's 0.005 degrees stood here too: 1.7e-4 rad over both sides of every ring, 3 % of the ring
+// spacing of SYN-128 -- a sixth of all the footprints k_project expanded at SYN-1M and a quarter of the groups k_cull kept at
+// SYN-10M were that margin's.
+constexpr float kProjectElevMarginDeg = 2e-4f;
 
 inline bool use_projection(const ls_tracer *tr) { return tr->engine == 2 || (tr->engine == 0 && tr->projection_ok); }
 inline uint32_t shard_rays(const ls_tracer *tr) { return tr->V * tr->naz; }
