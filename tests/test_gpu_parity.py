@@ -1294,6 +1294,61 @@ def test_non_finite_and_huge_vertices(oracle, capi, sensors, meshes, engine):
     tr.close()
 
 
+def test_triangles_whose_corner_lies_on_a_ray(oracle, capi, sensors, engine):
+    """The footprint bounds of the projection engine are supersets with explicit slack; the tightest of them is the elevation
+    slack of the channel tables (2e-4 degrees since round 5, ls_internal.h: kProjectElevMarginDeg).  Here every triangle has its
+    highest or its lowest corner ON a ray of the raster -- t * direction in float32, then carried into the world frame and
+    back by the library's transform, so the corner sits within a few 1e-7 rad of the ring, on either side -- and thin slivers
+    hang between two neighbouring columns of one ring.  Whether such a ray hits is decided by the exact test's rounding; the
+    footprint must contain it either way: ids and t equal to the oracle's exhaustive answer, on both engines."""
+    base = sensors["0000"]
+    from lidarshooter_amd import synth
+    for V, H, vertical in ((128, 1024, synth.syn_vertical(128)),
+                           # rings within half a degree of the horizon, one exactly on it: tan(elevation) ~ 0, where the band
+                           # test's RELATIVE slack is worth nothing and the tables' margin alone keeps the footprint a superset
+                           (65, 1024, np.linspace(-0.5, 0.5, 65, dtype=np.float32))):
+        _corner_on_ray_case(oracle, capi, engine, base, V, H, np.asarray(vertical, np.float32))
+
+
+def _corner_on_ray_case(oracle, capi, engine, base, V, H, vertical):
+    if True:
+        s = oracle.Sensor(uid="graze", vertical=vertical, h_begin=np.float32(0.0), h_end=np.float32(360.0), h_count=H,
+                          R=base.R, Rinv=base.Rinv, t=base.t)
+    dirs = oracle.ray_dirs(s).astype(np.float64)
+    R = s.R.reshape(3, 3).astype(np.float64)
+    rng = np.random.default_rng(77)
+    tris_sensor = []
+    for k in range(640):
+        v, h = k % V, int(rng.integers(1, H - 2))
+        d = dirs[v * H + h]
+        r = float(rng.uniform(4.0, 70.0))
+        apex = (np.float32(r) * d.astype(np.float32)).astype(np.float64)        # on the ray, as the kernels form t * direction
+        side = np.cross(d, [0.0, 0.0, 1.0]); side /= np.linalg.norm(side)
+        down = np.cross(side, d); down /= np.linalg.norm(down)                   # towards lower elevation, across the ray
+        if down[2] > 0: down = -down
+        w = r * float(rng.uniform(2e-4, 2e-2))
+        sign = 1.0 if k % 3 else -1.0                                            # the corner on the ray is the highest / the lowest
+        if k % 5 == 4:   # a sliver between this column's ray and the next one's, both corners on rays of the same ring
+            other = (np.float32(r * float(rng.uniform(0.98, 1.02))) * dirs[v * H + h + 1].astype(np.float32)).astype(np.float64)
+            third = 0.5 * (apex + other) + sign * down * w
+            tris_sensor.append([apex, other, third])
+        else:
+            tris_sensor.append([apex, apex + sign * down * w + side * w * float(rng.uniform(0.2, 1.0)), apex + sign * down * w - side * w * float(rng.uniform(0.2, 1.0))])
+    tri = np.array(tris_sensor, np.float64).reshape(-1, 3)
+    verts = (tri @ R.T + s.t.astype(np.float64)).astype(np.float32)              # v_world = R v_sensor + t
+    idx = np.arange(verts.shape[0], dtype=np.uint32).reshape(-1, 3)
+    tr = make_tracer(capi, s, engine)
+    assert tr.addGeometry("graze", verts.shape[0], idx.shape[0]) == 0
+    for A in (oracle.IDENTITY_AFFINE, oracle.affine_from_components(np.array((0.3, -0.2, 0.05), np.float32), np.array((0.0, 0.0, 0.7), np.float32))):
+        tr.updateGeometry("graze", A, verts, idx)
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(0)
+        assert rc == 0
+        ref = _assert_parity(oracle, s, tr, [(0, verts, idx, A)], pts, hits)
+        assert ref["points"].shape[0] > 300
+    tr.close()
+
+
 def test_argument_errors(capi, sensors):
     s = sensors["0000"]
     tr = make_tracer(capi, s)
