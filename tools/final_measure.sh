@@ -79,10 +79,10 @@ python bench.py > gpurun_out/final/${TAG}_projection_bench.json 2>> gpurun_out/f
 python bench.py --engine bvh --no-dropin > gpurun_out/final/${TAG}_bvh_bench.json 2>> gpurun_out/final/bench.err
 python bench.py --engine bvh --no-dropin --no-cpu-baseline --classic-bvh > gpurun_out/final/bench_${TAG}_bvh_classic.json 2>> gpurun_out/final/bench.err
 # SYN-10M: kernel averages of the culled stage (k_cull + k_project), what it reads and keeps, its HBM-side traffic
-W=syn128x10m bash tools/rocprof_kernels.sh ${TAG}_10m tools/shard_cost.py 2 1 > gpurun_out/final/${TAG}_projection_10m_kernels.txt 2>&1
+W=syn128x10m MODES=one bash tools/rocprof_kernels.sh ${TAG}_10m tools/shard_cost.py 2 1 > gpurun_out/final/${TAG}_projection_10m_kernels.txt 2>&1   # (one frame in flight: every dispatch alone)
 cp gpurun_out/rp_${TAG}_10m/${TAG}_10m_kernel_stats.csv gpurun_out/final/${TAG}_projection_10m_kernel_stats.csv
 python tools/cull_stats.py syn128x10m 1 >> gpurun_out/final/${TAG}_projection_10m_kernels.txt 2>> gpurun_out/final/bench.err
-W=syn128x10m bash tools/pmc_tool.sh ${TAG}_10m "FETCH_SIZE" "WRITE_SIZE" -- tools/shard_cost.py 2 1 > gpurun_out/final/${TAG}_projection_10m_pmc.txt 2>&1
+W=syn128x10m MODES=one bash tools/pmc_tool.sh ${TAG}_10m "FETCH_SIZE" "WRITE_SIZE" -- tools/shard_cost.py 2 1 > gpurun_out/final/${TAG}_projection_10m_pmc.txt 2>&1
 # BVH engine: a full rebuild of SYN-1M every frame (instanced and classic): the build kernels, the hand-written sort among them
 bash tools/rocprof_kernels.sh ${TAG}_rebuild tools/rebuild_cost.py > gpurun_out/final/${TAG}_bvh_rebuild_kernels.txt 2>&1
 tail -2 gpurun_out/rp_${TAG}_rebuild/stdout.log >> gpurun_out/final/${TAG}_bvh_rebuild_kernels.txt
