@@ -33,11 +33,17 @@ int materialize_scene(ls_tracer *tr, bool with_maxabs, bool keep_indices)
     return LS_OK;
 }
 
-// Group culling pays when k_project is bandwidth-bound.  Measured on MI355X (128 x 4096 rays, rocprofv3): at 10 M
-// triangles the frame drops from 87 to 59 us (three frames in flight); at 1 M k_project itself drops from 21 to 15.6 us
-// (43 % of the groups survive, its lanes are 2.3 x denser) but the cull pass in front of it takes ~10 us of pure
-// latency (table staging, bound loads, one contended atomic per workgroup), and an 8-way azimuth shard's 8.5 + 9.7 us
-// lose against 12.8 us without it.  auto = geometries of 2 M triangles or more.
+// When group culling pays (round 5's kernels, one MI355X, SYN-128; profiles/r05_*, EXPERIMENTS.md E7):
+//   * full raster, 10 M triangles: k_cull 14.6 + k_project<CULLED> 30.5 us against 84 us of frame without it -- on;
+//   * full raster, 1 M triangles: the cull pass and the dependent launch behind it cost more than the skipped triangles save,
+//     with the survivors dealt to the waves too (frame 16.8 us against 15.9 with three frames in flight, 29.3 against 25.8 with
+//     one) -- off;
+//   * an azimuth shard narrower than half a turn (what a rank of a sharded group traces): k_cull ends seven workgroups in eight
+//     at their block bounds and k_project reads the sector's survivors only -- an eighth of a turn at 1 M triangles streams in
+//     8.5 - 9.3 us per frame with it (k_cull 5.3 + k_project 8.6 us) against 8.2 - 12.6 without (k_project alone 11.5 us: it
+//     streams the whole mesh and throws seven triangles in eight away after their loads) -- on from 512 k triangles, below which
+//     a mesh is a handful of waves either way.
+// auto = geometries of 2 M triangles or more; of 512 k or more under such a shard.
 bool cull_enabled(const ls_tracer *tr, const Geometry &g)
 {
     if (tr->opt_block_cull != 2) return tr->opt_block_cull != 0;
