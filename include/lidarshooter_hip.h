@@ -173,7 +173,12 @@ void ls_affine_from_components(const float lin[3], const float ang[3], float aff
  * OptixTracer.cpp:263-275, :517-571).  Fixes the geometry layout (global triangle ids in (geomID,
  * primID) order); with the BVH engine it also transforms every geometry into the sensor frame and
  * builds the BVH on the device (the projection engine has nothing to build).  Returns 0, or -1 on an
- * empty scene (OptixTracer.cpp:266-267). */
+ * empty scene (OptixTracer.cpp:266-267).  A geometry whose index buffer changed since the last commit is
+ * checked here (one max-reduction over the indices on the device, read back): LS_ERR_OUT_OF_RANGE when a
+ * triangle names a vertex the geometry does not have -- the message (ls_last_error) names geometry and
+ * index; nothing is built, ls_trace_scene is refused until a commit succeeds, and new indices for that
+ * geometry (or ls_remove_geometry) clear the condition.  Non-finite or huge
+ * vertex COORDINATES are not an error: such triangles are never hit (as in the reference's ray test). */
 int ls_commit_scene(ls_tracer *tr);
 
 /* ---- ITracer::traceScene (ITracer.hpp:94; EmbreeTracer.cpp:297-367; OptixTracer.cpp:277-358).
@@ -326,8 +331,9 @@ int ls_tracer_set_hit_buffers(ls_tracer *tr, void *d_hits, uint32_t *d_n_points,
 #define LS_OPT_BLOCK_CULL 10    /* projection engine, meshes of 524 288 triangles or more: keep the mesh in Morton order with a
                                  *    bound per 4 triangles and drop, before their indices are read, the groups that no ring
                                  *    of the raster and no column of the shard can meet.  0 off, 1 on, 2 (default) auto: on for
-                                 *    geometries of 2 000 000 triangles or more (where the kernel is bandwidth-bound).
-                                 *    Identical results.                                                                  */
+                                 *    geometries of 2 000 000 triangles or more (where the kernel is bandwidth-bound), and
+                                 *    from 524 288 triangles when the handle is an azimuth shard narrower than the raster
+                                 *    (ls_tracer_set_shard: most groups then lie outside the sector).  Identical results.  */
 #define LS_OPT_UPLOAD_MODE 13   /* ls_update_geometry from host memory: 1 (default) one copy straight from the caller's pageable
                                  *    memory at PCIe rate, the call returns when the memory has been read; 0: worker threads
                                  *    stage it through pinned memory chunk by chunk, the call never waits for the device
