@@ -345,6 +345,55 @@ def front_loaded(out: dict) -> dict:
     return {**short, **middle, "summary": dict(short)}
 
 
+class Watchdog:
+    """N > 1 only.  The multi-rank RCCL path -- a communicator per buffer set, three collectives in flight, a collective
+    inside a captured HIP graph -- has never run on hardware (the build pool gives one GPU; DESIGN.md section 8 "untested because
+    it cannot be here").  A wait on a stuck collective cannot be cancelled, so a phase that does not finish in time ends the
+    job instead of holding the node until somebody else's limit: every rank says which phase it was, rank 0 still prints
+    ONE line -- the measurements that did finish (the frame-interleaved split is measured first for that reason: nothing
+    is exchanged on its frame path), `value` taken from them, and an "error" field that says what did not -- and the ranks
+    leave with os._exit (0 when there is such a line, 3 when there is nothing to report)."""
+
+    def __init__(self, result_fd: int, rank: int):
+        import threading
+        self.result_fd, self.rank = result_fd, rank
+        self.lock = threading.Lock()
+        self.deadline, self.what, self.seconds, self.fallback = None, None, 0.0, None
+        t = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        t.start()
+
+    def arm(self, what: str, seconds: float, fallback=None):
+        with self.lock:
+            self.what, self.seconds, self.fallback = what, seconds, fallback
+            self.deadline = time.monotonic() + seconds
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                what, seconds, fallback = self.what, self.seconds, self.fallback
+            if late:
+                self._expire(what, seconds, fallback)
+
+    def _expire(self, what, seconds, fallback):
+        msg = (f"'{what}' did not finish within {seconds:.0f} s on rank {self.rank}: taken to be hung (a collective that never "
+               "completes cannot be waited out); the job ends here")
+        print("bench.py watchdog: " + msg, file=sys.stderr, flush=True)
+        if self.rank == 0:
+            if fallback is not None:
+                line = dict(fallback)
+                line["error"] = msg + f"; `value` is the measurement that did finish ({fallback['config']['parallelism']})"
+                os.write(self.result_fd, (json.dumps(front_loaded(line)) + "\n").encode())
+        else:
+            time.sleep(3.0)   # rank 0 writes its line before a launcher that sees a rank leave ends the others
+        os._exit(0 if fallback is not None else 3)
+
+
 def spawn_ranks(args) -> int:
     """--gpus N without a launcher: start the N ranks as a fresh child process tree (torch.distributed.run) -- nothing in
     THIS process has touched a GPU yet (importing torch does not; torch.cuda.device_count() does not initialise one on
@@ -427,8 +476,8 @@ def main():
     else:
         # N > 1, one scene: two ways to spread a stream of frames over the GPUs, both measured, args.multi is `value`;
         # the sharded split is measured on SYN-10M too (where a shard is work-bound), reported next to it
-        other = "sharded" if args.multi == "interleaved" else "interleaved"
-        out = measure(args, rank, world, device, dev_index, rehearsal, args.multi)
+        # The interleaved split first (no collective on its frame path), then the sharded ones under the watchdog: if a
+        # multi-rank collective hangs, the line still carries what was measured and says what was not.
         keys = ("value", "unit", "ms_per_step", "frames_per_s", "scaling", "gathered_points_rank0", "host_enqueue_ms_per_step", "timing")
 
         def brief(m):
@@ -436,11 +485,21 @@ def main():
             b["workload"] = m["config"]["workload"]
             b["parallelism"] = m["config"]["parallelism"]
             return b
-        also = [brief(measure(args, rank, world, device, dev_index, rehearsal, other))]
+        dog = Watchdog(result_fd, rank)
+        limit = float(os.environ.get("LS_BENCH_WATCHDOG_S", "240"))
+        dog.arm("frames interleaved over the ranks", limit)
+        inter = measure(args, rank, world, device, dev_index, rehearsal, "interleaved")
+        dog.arm("azimuth shards + all-gather, " + args.workload, limit, inter)
+        shard = measure(args, rank, world, device, dev_index, rehearsal, "sharded")
+        out, also = (shard, [brief(inter)]) if args.multi == "sharded" else (inter, [brief(shard)])
         if args.workload == "syn128x1m" and not rehearsal:
             big = argparse.Namespace(**vars(args))
             big.workload = "syn128x10m"
+            partial = dict(out)
+            partial["also_measured"] = list(also)
+            dog.arm("azimuth shards + all-gather, syn128x10m", limit, partial)
             also.append(brief(measure(big, rank, world, device, dev_index, rehearsal, "sharded")))
+        dog.disarm()
         if rank == 0:
             out["also_measured"] = also
     if rank == 0:
@@ -454,6 +513,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
     """One measurement.  multi: None (single GPU, or cfg5's replicas), "sharded" (azimuth sectors + one all-gather of
     hit-record slots per frame: a frame's latency is what is split) or "interleaved" (rank g traces the whole raster of
     frames f with f mod N == g, nothing is exchanged on the frame path: the stream's throughput is what is multiplied)."""
+    if multi and os.environ.get("LS_BENCH_DEBUG_STALL") == multi:   # (tests: what the watchdog does about a phase that hangs)
+        time.sleep(1e6)
     sensor, meshes = build_workload(args.workload, rank)
     pipeline_arg = args.pipeline
     if args.pipeline == 0:

@@ -230,6 +230,24 @@ def test_bench_two_ranks_rehearsal_without_a_launcher():
     assert rec["rehearsal_gloo_shared_gpu"] is True
 
 
+def test_bench_two_ranks_watchdog_reports_what_finished():
+    """The sharded phase of `bench.py --gpus 2` made to hang (LS_BENCH_DEBUG_STALL): the watchdog ends both ranks, rank 0's ONE
+    line carries the frame-interleaved measurement that did finish -- labelled as such -- and an "error" that names the phase
+    (the multi-rank RCCL path has never run on hardware: a hang there must not hold an 8-GPU node until somebody's limit)."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"LS_BENCH_REHEARSAL": "1", "LS_BENCH_DEBUG_STALL": "sharded", "LS_BENCH_WATCHDOG_S": "45"})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--workload", "xt32",
+                          "--no-cpu-baseline", "--min-ms", "5", "--prime-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert "azimuth shards + all-gather" in rec["error"] and "interleaved" in rec["config"]["parallelism"]
+    assert "watchdog" in out.stderr
+
+
 @pytest.mark.parametrize("flags", [0, 1])
 def test_group_empty_scene_and_back(oracle, capi, sensors, meshes, flags):
     """OptixTracer.cpp:263-288 through the group: a frame of an empty scene traces nothing (-1) and still travels -- an empty

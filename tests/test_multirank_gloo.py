@@ -148,3 +148,33 @@ def test_bench_never_reports_fewer_gpus_than_asked_for():
     # a launcher whose world disagrees with --gpus is refused as well
     rc, lines, err = _bench(["--gpus", "4", "--spawn-check"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
     assert rc != 0 and lines == []
+
+
+def test_bench_watchdog_ends_a_hung_phase_and_still_reports():
+    """bench.py's N > 1 watchdog (the multi-rank RCCL path has never run on hardware): a phase that does not finish in time
+    ends the process from a second thread; rank 0 prints the measurements that did finish as ONE line with an "error"
+    field (exit code 0), or nothing and exit code 3 when there is nothing to report; another rank prints nothing."""
+    import json
+    import subprocess
+    import sys
+    prog = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(1, int(sys.argv[1])); "
+            "fb = {'value': 5.0, 'unit': 'Mrays/s', 'n_gpus': 2, 'config': {'workload': 'w', 'parallelism': 'frames interleaved'}} if sys.argv[2] == '1' else None; "
+            "d.arm('phase one', 30.0); d.arm('azimuth shards + all-gather', 0.5, fb); time.sleep(60)") % ROOT
+    def run(rank, with_fallback):
+        return subprocess.run([sys.executable, "-c", prog, str(rank), "1" if with_fallback else "0"], capture_output=True, text=True, timeout=120)
+    out = run(0, True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["value"] == 5.0 and "azimuth shards + all-gather" in rec["error"] and "frames interleaved" in rec["error"]
+    assert rec["summary"]["value"] == 5.0                      # (the line keeps bench.py's front-loaded shape)
+    assert "watchdog" in out.stderr
+    out = run(0, False)
+    assert out.returncode == 3 and out.stdout.strip() == "" and "did not finish within" in out.stderr
+    out = run(1, True)
+    assert out.returncode == 0 and out.stdout.strip() == ""   # only rank 0 reports
+    # a phase that finishes: disarm, nothing happens
+    prog2 = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(1, 0); d.arm('quick', 0.5); d.disarm(); time.sleep(1.5); print('alive')") % ROOT
+    out = subprocess.run([sys.executable, "-c", prog2], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "alive"
