@@ -381,8 +381,20 @@ class Watchdog:
                 self._expire(what, seconds, fallback)
 
     def _expire(self, what, seconds, fallback):
-        msg = (f"'{what}' did not finish within {seconds:.0f} s on rank {self.rank}: taken to be hung (a collective that never "
-               "completes cannot be waited out); the job ends here")
+        self._end(f"'{what}' did not finish within {seconds:.0f} s on rank {self.rank}: taken to be hung (a collective that never "
+                  "completes cannot be waited out); the job ends here", fallback)
+
+    def failed(self, error: BaseException):
+        """The armed phase raised on this rank (a communicator that could not be made, a refused capture): its peers are, or
+        soon will be, inside collectives this rank will never join -- same ending, without waiting for the deadline."""
+        import traceback
+        traceback.print_exc()
+        with self.lock:
+            self.deadline = None
+            what, fallback = self.what, self.fallback
+        self._end(f"'{what}' raised on rank {self.rank}: {error!r}; the job ends here", fallback)
+
+    def _end(self, msg, fallback):
         print("bench.py watchdog: " + msg, file=sys.stderr, flush=True)
         if self.rank == 0:
             if fallback is not None:
@@ -490,7 +502,10 @@ def main():
         dog.arm("frames interleaved over the ranks", limit)
         inter = measure(args, rank, world, device, dev_index, rehearsal, "interleaved")
         dog.arm("azimuth shards + all-gather, " + args.workload, limit, inter)
-        shard = measure(args, rank, world, device, dev_index, rehearsal, "sharded")
+        try:
+            shard = measure(args, rank, world, device, dev_index, rehearsal, "sharded")
+        except (Exception, SystemExit) as e:
+            dog.failed(e)
         out, also = (shard, [brief(inter)]) if args.multi == "sharded" else (inter, [brief(shard)])
         if args.workload == "syn128x1m" and not rehearsal:
             big = argparse.Namespace(**vars(args))
@@ -498,7 +513,10 @@ def main():
             partial = dict(out)
             partial["also_measured"] = list(also)
             dog.arm("azimuth shards + all-gather, syn128x10m", limit, partial)
-            also.append(brief(measure(big, rank, world, device, dev_index, rehearsal, "sharded")))
+            try:
+                also.append(brief(measure(big, rank, world, device, dev_index, rehearsal, "sharded")))
+            except (Exception, SystemExit) as e:
+                dog.failed(e)
         dog.disarm()
         if rank == 0:
             out["also_measured"] = also
@@ -515,6 +533,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
     frames f with f mod N == g, nothing is exchanged on the frame path: the stream's throughput is what is multiplied)."""
     if multi and os.environ.get("LS_BENCH_DEBUG_STALL") == multi:   # (tests: what the watchdog does about a phase that hangs)
         time.sleep(1e6)
+    if multi and os.environ.get("LS_BENCH_DEBUG_RAISE") == f"{multi}:{rank}":   # (tests: ... or that raises on one rank)
+        raise RuntimeError("LS_BENCH_DEBUG_RAISE")
     sensor, meshes = build_workload(args.workload, rank)
     pipeline_arg = args.pipeline
     if args.pipeline == 0:

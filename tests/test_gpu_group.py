@@ -246,6 +246,18 @@ def test_bench_two_ranks_watchdog_reports_what_finished():
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert "azimuth shards + all-gather" in rec["error"] and "interleaved" in rec["config"]["parallelism"]
     assert "watchdog" in out.stderr
+    # ... and the phase raising on ONE rank (a communicator that could not be made there): that rank leaves, its peer's
+    # collective fails or times out, rank 0 reports the same way
+    env.pop("LS_BENCH_DEBUG_STALL")
+    env["LS_BENCH_DEBUG_RAISE"] = "sharded:1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--workload", "xt32",
+                          "--no-cpu-baseline", "--min-ms", "5", "--prime-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "azimuth shards + all-gather" in rec["error"]
+    assert "LS_BENCH_DEBUG_RAISE" in out.stderr
 
 
 @pytest.mark.parametrize("flags", [0, 1])

@@ -174,6 +174,14 @@ def test_bench_watchdog_ends_a_hung_phase_and_still_reports():
     assert out.returncode == 3 and out.stdout.strip() == "" and "did not finish within" in out.stderr
     out = run(1, True)
     assert out.returncode == 0 and out.stdout.strip() == ""   # only rank 0 reports
+    # a phase that raises on this rank ends the same way, at once
+    prog3 = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(1, 0); "
+             "d.arm('azimuth shards + all-gather', 600.0, {'value': 7.0, 'config': {'workload': 'w', 'parallelism': 'frames interleaved'}})\n"
+             "try:\n    raise RuntimeError('no communicator')\nexcept Exception as e:\n    d.failed(e)\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", prog3], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert rec["value"] == 7.0 and "raised on rank 0" in rec["error"] and "no communicator" in rec["error"]
     # a phase that finishes: disarm, nothing happens
     prog2 = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(1, 0); d.arm('quick', 0.5); d.disarm(); time.sleep(1.5); print('alive')") % ROOT
     out = subprocess.run([sys.executable, "-c", prog2], capture_output=True, text=True, timeout=120)
