@@ -77,6 +77,56 @@ for rep in range(reps):
             if gap: time.sleep(gap)
             t0 = time.perf_counter(); run(0, 200); wsync(); ws5.append((time.perf_counter() - t0) / 200 * 1e6)
         print("windows of 200: median %.2f" % float(np.median(ws5)))
+    if os.environ.get("PROBE_KSWEEP"):   # what a window of K frames costs beyond K steady steps: K = 1 is a frame's whole latency + the wait
+        # the three slot streams (the stream of the frame issued last, three frames running), for a wait that polls them
+        hip = C.CDLL("libamdhip64.so.7")
+        hip.hipStreamQuery.argtypes = [C.c_void_p]
+        slot_streams = []
+        for i in range(3):
+            run(i, 1)
+            sp = C.c_void_p()
+            assert tr.L.ls_frame_graph_stream(tr.h, C.byref(sp), None, None) == 0
+            slot_streams.append(sp.value)
+        torch.cuda.synchronize(dev)
+        print("slot streams:", ["%x" % (x or 0) for x in slot_streams])
+        for poll in (0, 1, 0, 1):
+            for K in [int(x) for x in os.environ["PROBE_KSWEEP"].split(",")]:
+                el, en = [], []
+                for w in range(40):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter(); run(0, K); t1 = time.perf_counter()
+                    if poll:
+                        for sp in slot_streams:
+                            while hip.hipStreamQuery(sp) != 0: pass
+                    torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                    el.append((t2 - t0) * 1e6); en.append((t1 - t0) * 1e6)
+                print("%s window of %3d frames: median %.1f us (min %.1f), enqueue %.1f us, per frame %.2f" % ("polled " if poll else "blocked", K, float(np.median(el)), min(el), float(np.median(en)), float(np.median(el)) / K), flush=True)
+    if os.environ.get("PROBE_PER_FRAME"):   # the host's enqueue time of every frame of a window that starts on an idle device
+        K = int(os.environ["PROBE_PER_FRAME"])
+        rows = []
+        for w in range(30):
+            torch.cuda.synchronize(dev)
+            ts = [time.perf_counter()]
+            for i in range(K):
+                run(i, 1); ts.append(time.perf_counter())
+            torch.cuda.synchronize(dev); t_end = time.perf_counter()
+            rows.append([(ts[i + 1] - ts[i]) * 1e6 for i in range(K)] + [(t_end - ts[-1]) * 1e6, (t_end - ts[0]) * 1e6])
+        if os.environ.get("PROBE_PER_FRAME_SPLIT"):   # the same windows through the loop that clocks its three calls
+            HL.lsh_stream_frames_timed.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(f32p), C.POINTER(C.c_uint), C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]
+            ns3 = (C.c_double * 3)()
+            split = []
+            for w in range(30):
+                torch.cuda.synchronize(dev)
+                one = []
+                for i in range(K):
+                    assert HL.lsh_stream_frames_timed(tr.h, names, aff, na, len(meshes), i, 1, ns3) == 0
+                    one.append([ns3[0] * 1e-3, ns3[1] * 1e-3, ns3[2] * 1e-3])
+                torch.cuda.synchronize(dev)
+                split.append(one)
+            m3 = np.median(np.array(split), axis=0)
+            print("pose / commit / trace us per frame of the window: " + " ".join("%.1f/%.1f/%.1f" % tuple(x) for x in m3[:8]), flush=True)
+        med = np.median(np.array(rows), axis=0)
+        print("per-frame enqueue us (median of 30 windows of %d): %s | final wait %.1f | window %.1f" % (K, " ".join("%.1f" % x for x in med[:K]), med[K], med[K + 1]), flush=True)
     ws, enq = [], []
     K = int(os.environ.get("PROBE_WINDOW", "1000"))   # frames per timed window
     for w in range(int(os.environ.get("PROBE_WINDOWS", "5"))):
