@@ -1119,8 +1119,18 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     uint32_t first0 = 0, geom0 = 0, shift0 = 0;   // slot 0: the only one of a one-mesh scene
     if (gt.n) { first0 = gt.tri_first[0]; geom0 = gt.geom_ids[0]; shift0 = gt.prim_shift[0]; }
 
+    // (eight of a thread's counts requested at a time -- all of them for a raster of up to 2 048 blocks: as a plain loop the last
+    // blocks of the grid, which start last and add up the most, walked four dependent round trips of two loads; 15.35 -> 15.05 us
+    // per frame with three in flight, 24.9 -> 24.6 with one; starting those blocks first as well: no further gain)
     uint32_t acc = 0;
-    for (uint32_t r = threadIdx.x; r < block; r += kBlock) acc += block_counts[r];
+    constexpr uint32_t kCountsAhead = 8;
+    for (uint32_t r0 = threadIdx.x; r0 < block; r0 += kCountsAhead * kBlock) {
+        uint32_t c[kCountsAhead];
+#pragma unroll
+        for (uint32_t k = 0; k < kCountsAhead; ++k) c[k] = r0 + k * kBlock < block ? block_counts[r0 + k * kBlock] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kCountsAhead; ++k) acc += c[k];
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
 
@@ -1192,10 +1202,15 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     const uint32_t chunk = (n_blocks + kBlock - 1u) / kBlock;
     const uint32_t c0 = min(threadIdx.x * chunk, n_blocks), c1 = min(c0 + chunk, n_blocks);
     uint32_t mine = 0, mine_first = 0;
-    for (uint32_t i = c0; i < c1; ++i) {
-        const uint32_t c = block_counts[i];
-        mine += c;
-        if (i < pg.split) mine_first += c;
+    for (uint32_t i0 = c0; i0 < c1; i0 += kCountsAhead) {   // (the chunk's loads side by side: this workgroup's word is what the host waits for)
+        uint32_t c[kCountsAhead];
+#pragma unroll
+        for (uint32_t k = 0; k < kCountsAhead; ++k) c[k] = i0 + k < c1 ? block_counts[i0 + k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kCountsAhead; ++k) {
+            mine += c[k];
+            if (i0 + k < pg.split) mine_first += c[k];
+        }
     }
     uint32_t incl = mine;
 #pragma unroll
@@ -1292,6 +1307,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_slots(SensorTables tb, const 
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= world * cap) return;
     const uint32_t r = i / cap, j = i - r * cap;
+    // (the record is requested before the headers are looked at -- record j < cap of slot r lies inside what travelled whether
+    // the slot holds that many hits or not --, so that the kernel is two round trips deep, not three)
+    const uint4 rec = reinterpret_cast<const uint4 *>(gathered + (size_t)r * slot_words + 16)[j];
     uint32_t off = 0, total = 0, most = 0;
     for (uint32_t k = 0; k < world; ++k) {
         const uint32_t c_true = gathered[(size_t)k * slot_words], c = min(c_true, cap);
@@ -1308,7 +1326,6 @@ __global__ __launch_bounds__(kBlock) void k_expand_slots(SensorTables tb, const 
         }
     }
     if (j >= min(gathered[(size_t)r * slot_words], cap)) return;
-    const uint4 rec = reinterpret_cast<const uint4 *>(gathered + (size_t)r * slot_words + 16)[j];
     const uint32_t v = rec.x / tb.H, h = rec.x - v * tb.H;
     const float t = __uint_as_float(rec.w);
     const float st = tb.sin_theta[v];
