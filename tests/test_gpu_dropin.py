@@ -547,3 +547,43 @@ def test_two_step_trace_on_an_azimuth_shard(oracle, capi, sensors, meshes):
         seen += pts.shape[0]
     assert seen == ref["points"].shape[0] and seen > 0
     tr.close()
+
+
+def test_raster_beyond_2048_ray_blocks(oracle, capi, sensors):
+    """160 x 4096 rays = 2 560 blocks of 256: k_pack asks for a thread's block counts eight at a time, which covers the
+    2 048 blocks of the headline raster in one go -- here the loop comes round a second time, and the workgroup that publishes
+    the two-step trace's hit count owns chunks of ten counts.  One-step on both engines, two-step, and three frames in flight,
+    all against the BVH oracle."""
+    import torch
+    from lidarshooter_amd import synth
+    v, t = synth.grid_mesh(300, 200)
+    s = _syn_sensor(oracle, sensors, V=160, H=4096)
+    assert (s.V * s.H + 255) // 256 == 2560
+    ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True)
+    assert ref["points"].shape[0] > 100000
+    for engine_name in ("projection", "bvh"):
+        tr = make_tracer(capi, s, engine_name)
+        tr.addGeometry("grid", v.shape[0], t.shape[0])
+        tr.updateGeometry("grid", oracle.IDENTITY_AFFINE, v, t)
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(0)
+        assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])
+        rc, pts = tr.traceSceneTwoStep(1)
+        assert rc == 0 and np.array_equal(pts, ref["points"])
+        if engine_name == "projection":
+            tr.setOption(capi.LS_OPT_PIPELINE, 2)
+            cap = s.V * s.H
+            bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0"), torch.zeros(16 * cap, dtype=torch.uint8, device="cuda:0"),
+                     torch.zeros(4, dtype=torch.int32, device="cuda:0")) for _ in range(3)]
+            for i in range(9):
+                p, h, n = bufs[i % 3]
+                assert tr.commitScene() == 0
+                tr.setOutputBuffers(p.data_ptr(), h.data_ptr(), n.data_ptr(), cap)
+                tr.traceSceneAsync(i)
+            tr.synchronize()
+            for p, h, n in bufs:
+                cnt = int(n[0].item())
+                assert cnt == ref["points"].shape[0]
+                assert np.array_equal(p.cpu().numpy()[:32 * cnt].reshape(cnt, 32), ref["points"])
+                assert np.array_equal(h.cpu().numpy()[:16 * cnt].view(np.uint32).reshape(cnt, 4), ref["hits"])
+        tr.close()
