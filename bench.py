@@ -479,11 +479,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    if world == 1 and os.environ.get("LS_BENCH_FORCE_GROUP") == "1":
-        # one-GPU check of the N > 1 default path: the sharded split through include/lidarshooter_group.h with a one-rank
-        # RCCL communicator (every line of the C group driver below runs; never a reported number)
-        out = measure(args, rank, world, device, dev_index, rehearsal, "sharded", force_group=True)
-    elif world == 1 or args.workload == "cfg5":
+    # LS_BENCH_FORCE_GROUP=1 on one GPU: the N > 1 path below, every phase of it, through include/lidarshooter_group.h with a
+    # one-rank RCCL communicator (every line of the C group driver runs; never a reported number)
+    force_group = world == 1 and os.environ.get("LS_BENCH_FORCE_GROUP") == "1"
+    if (world == 1 and not force_group) or args.workload == "cfg5":
         out = measure(args, rank, world, device, dev_index, rehearsal, None)
     else:
         # N > 1, one scene: two ways to spread a stream of frames over the GPUs, both measured, args.multi is `value`;
@@ -500,13 +499,33 @@ def main():
         dog = Watchdog(result_fd, rank)
         limit = float(os.environ.get("LS_BENCH_WATCHDOG_S", "240"))
         dog.arm("frames interleaved over the ranks", limit)
-        inter = measure(args, rank, world, device, dev_index, rehearsal, "interleaved")
-        dog.arm("azimuth shards + all-gather, " + args.workload, limit, inter)
+        inter = measure(args, rank, world, device, dev_index, rehearsal, "interleaved", force_group=force_group)
+        # The sharded split in two arrangements, the plain one first ("keep ONE_COMMUNICATOR as the default
+        # until a run with two or more ranks exists" -- it is not the default, but it is what the line falls back on): one
+        # communicator, the collective on a stream of its own behind an event, plain launches -- how RCCL is used
+        # everywhere; then the arrangement --group-flags asks for (default: a communicator and a stream per buffer set,
+        # the frame one captured graph), whose multi-rank collectives inside a captured graph nobody has run yet.
+        plain = None
+        if args.multi_driver == "c" and not rehearsal and args.group_flags != 1:
+            safe = argparse.Namespace(**vars(args))
+            safe.group_flags = 1
+            dog.arm("azimuth shards + all-gather on one communicator, " + args.workload, limit, inter)
+            try:
+                plain = measure(safe, rank, world, device, dev_index, rehearsal, "sharded", force_group=force_group)
+            except (Exception, SystemExit) as e:
+                dog.failed(e)
+        fallback = inter
+        if plain is not None and args.multi == "sharded":
+            fallback = dict(plain)
+            fallback["also_measured"] = [brief(inter)]
+        dog.arm("azimuth shards + all-gather" + (", per-set communicators and frame graphs, " if plain is not None else ", ") + args.workload, limit, fallback)
         try:
-            shard = measure(args, rank, world, device, dev_index, rehearsal, "sharded")
+            shard = measure(args, rank, world, device, dev_index, rehearsal, "sharded", force_group=force_group)
         except (Exception, SystemExit) as e:
             dog.failed(e)
         out, also = (shard, [brief(inter)]) if args.multi == "sharded" else (inter, [brief(shard)])
+        if plain is not None:
+            also.insert(0, brief(plain))
         if args.workload == "syn128x1m" and not rehearsal:
             big = argparse.Namespace(**vars(args))
             big.workload = "syn128x10m"
@@ -514,7 +533,7 @@ def main():
             partial["also_measured"] = list(also)
             dog.arm("azimuth shards + all-gather, syn128x10m", limit, partial)
             try:
-                also.append(brief(measure(big, rank, world, device, dev_index, rehearsal, "sharded")))
+                also.append(brief(measure(big, rank, world, device, dev_index, rehearsal, "sharded", force_group=force_group)))
             except (Exception, SystemExit) as e:
                 dog.failed(e)
         dog.disarm()
@@ -707,6 +726,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
             if n > 0 and HL.lsh_stream_frames(h, sf_names, sf_aff, sf_n, len(fast_meshes), sf_p, sf_h, sf_c, 3, cap, first, n) < 0:
                 raise RuntimeError(tr.last_error())
 
+    group_last_frame = [0]
     if cgroup:
         HL = hostapi.load()
         HL.lsh_group_stream_frames.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(f32p), C.POINTER(C.c_uint), C.c_uint,
@@ -723,6 +743,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                     registered.add(nm)
             if n > 0 and HL.lsh_group_stream_frames(grp.g, h, gsf_names, gsf_aff, gsf_n, len(fast_meshes), first, n) < 0:
                 raise RuntimeError(tr.last_error() + " / " + grp.L.ls_group_last_error(grp.g).decode())
+            if n > 0:
+                group_last_frame[0] = first + n - 1      # (the group keeps three frames: the one downloaded at the end is this one)
 
     def update_and_trace(i, copy):
         if single and not copy:
@@ -1159,7 +1181,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         "hits_per_frame_rank0": n_hits,
         "points_sha256": points_sha,
         # N > 1: points of the whole frame as rebuilt from the gathered slots on rank 0 (= the 1-GPU hit count)
-        "gathered_points_rank0": None if single else (int(grp.download(args.steps - 1)[0].shape[0]) if cgroup else int(cloud_n[0].item())),
+        "gathered_points_rank0": None if single else (int(grp.download(group_last_frame[0])[0].shape[0]) if cgroup else int(cloud_n[0].item())),
         "rehearsal_gloo_shared_gpu": True if rehearsal else None,
         "rccl": rccl_out,
         "host_numa": HOST_NUMA,

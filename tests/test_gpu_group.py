@@ -230,6 +230,29 @@ def test_bench_two_ranks_rehearsal_without_a_launcher():
     assert rec["rehearsal_gloo_shared_gpu"] is True
 
 
+def test_bench_every_phase_of_the_multi_rank_flow_through_a_one_rank_communicator():
+    """LS_BENCH_FORCE_GROUP=1: bench.py's N > 1 flow on one GPU, phase by phase -- frames interleaved, the sharded split on one
+    communicator (the arrangement the line falls back on), the sharded split with per-set communicators and frame graphs
+    (`value`), under the watchdog -- through include/lidarshooter_group.h with a one-rank RCCL communicator.  Every cloud the
+    reference's 1781 points."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LS_BENCH_FORCE_GROUP"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--workload", "xt32",
+                          "--no-cpu-baseline", "--no-dropin", "--min-ms", "5", "--prime-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert "error" not in rec and rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["gathered_points_rank0"] == 1781                                  # OptixTracer_test.cpp:122-169
+    assert rec["rccl"]["communicators"] == 3 and "ONE captured HIP graph launch" in rec["config"]["parallelism"]
+    also = rec["also_measured"]
+    assert len(also) == 2
+    assert "collective stream" in also[0]["parallelism"] and also[0]["gathered_points_rank0"] == 1781 and also[0]["value"] > 0
+    assert also[1]["parallelism"] == "single GPU" and also[1]["value"] > 0      # (frames "interleaved" over one GPU)
+
+
 def test_bench_two_ranks_watchdog_reports_what_finished():
     """The sharded phase of `bench.py --gpus 2` made to hang (LS_BENCH_DEBUG_STALL): the watchdog ends both ranks, rank 0's ONE
     line carries the frame-interleaved measurement that did finish -- labelled as such -- and an "error" that names the phase
