@@ -1428,9 +1428,11 @@ bool fill_culled_batch(const GeomSource *srcs, uint32_t n_srcs, GeomBatch &batch
     // long as their rounds, which a wave takes two at a time, each pair a memory round trip and a test behind the other: the
     // few live workgroups of a shard do better with a short chain -- but every workgroup that comes and goes is four waves
     // to launch, and three frames overlap: the shortest chain is not the best either
-    // (rounds 2 / 4 / 8 at SYN-10M, an eighth of a turn, three frames in flight as graphs: the rank with the fewest triangles in
-    // its sector 10.4 / 10.2 / 10.9 us per frame, the one with the most 14.4 / 13.6 / 13.3 -- four)
-    if (sector) { static const int r = lsi::tune_int("LS_CULL_SHARD_ROUNDS", 4); rounds = (uint32_t)std::min<int>(std::max(r, 2), (int)std::max(rounds, 2u)); }
+    // (an eighth of a turn at SYN-10M, three frames in flight as graphs, ranks 0 / 4 / 5 -- the sector with the fewest triangles and
+    // the two with the most: 4 rounds 9.9 / 12.1 / 12.9 us per frame, the full turn's own 5: 10.4 / 11.8 / 12.5, 6: 10.1 / 12.6 / 12.9, 8: 10.8 / 12.4 /
+    // 12.9; at SYN-1M the full turn's own 2: 8.4 / 8.2 / 8.6, 4: 8.6 / 9.7 / 11.0, 8: 10.5 / 10.6 / 11.5.  A group's frame is its slowest
+    // rank's: a shard takes the full turn's choice -- one resident round of workgroups -- as it is)
+    if (sector) { static const int r = lsi::tune_int("LS_CULL_SHARD_ROUNDS", 0); if (r) rounds = (uint32_t)std::min<int>(std::max(r, 2), (int)kCullMaxRounds); }
     batch.cull_rounds = rounds;
     const uint32_t per_wg = rounds * kBlock;
     for (uint32_t i = 0; i < n_srcs; ++i) {
