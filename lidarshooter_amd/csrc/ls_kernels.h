@@ -250,7 +250,7 @@ void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid,
 void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
                       const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
                       const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact = 0,
-                      const ProgressArgs *progress = nullptr);
+                      const ProgressArgs *progress = nullptr, uint32_t rays_per_lane = 1);
 // projection engine: per-geometry streaming kernel, big-footprint kernel, resolve (+ row counts)
 size_t project_big_item_bytes();
 void launch_project_init(hipStream_t s, const ProjectParams &pp, unsigned long long *best, uint32_t *big_count,
@@ -304,7 +304,10 @@ void launch_finish_pack(hipStream_t s, const ProjectParams &pp, const FinishPack
 // per ray: gather the queued big-footprint triangles, then hits per 256-ray block
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
                            uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,
-                           unsigned long long *stats);
+                           unsigned long long *stats, uint32_t rays_per_lane = 1);
+// rays_per_lane (here and in launch_pack_keys; 1, 2, 4, pack also 8): frames that overlap on three streams are bound by wave
+// slots, and these two passes then run as fewer, fatter waves -- project_rays_per_lane() says how fat for a raster
+inline uint32_t project_rays_per_lane(uint32_t ray_blocks) { return ray_blocks >= 2048u ? 8u : ray_blocks >= 1024u ? 4u : ray_blocks >= 512u ? 2u : 1u; }
 // one idle wave for `ticks` x 10 ns (stream / hardware-queue calibration)
 void launch_spin(hipStream_t s, unsigned long long ticks);
 // sensor -> world transform of a packed cloud (m.a = A, m.rinv = R, m.t = t); max_points bounds the grid

@@ -1242,6 +1242,109 @@ __global__ __launch_bounds__(kBlock) void k_pack(SensorTables tb, float *__restr
     }
 }
 
+// k_pack<true> with RPT rays per lane (thread t takes rays t, t + 256, ... of its workgroup's RPT x 256): fewer, fatter waves for
+// the frames that overlap on three streams, where the device is short of wave slots (k_project_finish_wide, ls_project.hip, has
+// the measurements).  Everything k_pack<true> does except the progress reports of a two-step trace, which is one frame in flight.
+template <uint32_t RPT>
+__global__ __launch_bounds__(kBlock) void k_pack_wide(SensorTables tb, unsigned long long *__restrict__ keys,
+                                                      const uint32_t *__restrict__ block_counts, uint32_t *__restrict__ next_block_counts,
+                                                      uint32_t *__restrict__ big_count, GeomTable gt, float4 *__restrict__ points,
+                                                      uint4 *__restrict__ hits, uint32_t *__restrict__ n_points, uint32_t compact,
+                                                      uint32_t n_blocks, uint32_t *cull_hint)
+{
+    __shared__ uint32_t s_part[kBlock / 64];
+    __shared__ uint32_t s_cnt[RPT][kBlock / 64];
+    __shared__ uint32_t s_hint[kBlock / 64];
+    const uint32_t nq = tb.V * tb.naz;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t wg = blockIdx.x, block0 = wg * RPT;           // the first of this workgroup's 256-ray blocks
+    const uint32_t q0 = block0 * kBlock + threadIdx.x;
+    unsigned long long key[RPT];
+    uint32_t v[RPT], h[RPT];
+    float st[RPT], ctv[RPT];
+    float2 cs[RPT];
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        const uint32_t q = q0 + j * kBlock;
+        key[j] = q < nq ? keys[q] : ~0ull;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        const uint32_t qq = min(q0 + j * kBlock, nq - 1u);
+        v[j] = qq / tb.naz;
+        h[j] = tb.az0 + (qq - v[j] * tb.naz);
+        st[j] = tb.sin_theta[v[j]];
+        ctv[j] = tb.cos_theta[v[j]];
+        cs[j] = tb.cs_phi[h[j]];
+    }
+    uint32_t first0 = 0, geom0 = 0, shift0 = 0;
+    if (gt.n) { first0 = gt.tri_first[0]; geom0 = gt.geom_ids[0]; shift0 = gt.prim_shift[0]; }
+    uint32_t acc = 0;
+    constexpr uint32_t kCountsAhead = 8;
+    for (uint32_t r0 = threadIdx.x; r0 < block0; r0 += kCountsAhead * kBlock) {
+        uint32_t c[kCountsAhead];
+#pragma unroll
+        for (uint32_t k = 0; k < kCountsAhead; ++k) c[k] = r0 + k * kBlock < block0 ? block_counts[r0 + k * kBlock] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kCountsAhead; ++k) acc += c[k];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    unsigned long long m[RPT];
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        if (key[j] != ~0ull) keys[q0 + j * kBlock] = ~0ull;   // re-arm
+        m[j] = __ballot(key[j] != ~0ull);
+        if (lane == 0) s_cnt[j][w] = (uint32_t)__popcll(m[j]);
+    }
+    if (threadIdx.x < RPT && block0 + threadIdx.x < n_blocks) next_block_counts[block0 + threadIdx.x] = 0u;
+    if (q0 == 0) big_count[0] = 0u;
+    if (wg == 0u) {
+        uint32_t fullest = 0;
+        for (uint32_t i = threadIdx.x; i < kCullCounters; i += kBlock) {
+            fullest = max(fullest, big_count[kCullCountAt + i * 16u]);
+            big_count[kCullCountAt + i * 16u] = 0u;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) fullest = max(fullest, (uint32_t)__shfl_xor((int)fullest, off));
+        if (lane == 0) s_hint[w] = fullest;
+    }
+    if (lane == 0) s_part[w] = acc;
+    __syncthreads();
+    uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (wg == gridDim.x - 1u && threadIdx.x == 0) {
+        uint32_t total = base;
+        for (uint32_t j = 0; j < RPT; ++j) total += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+        *n_points = total;
+    }
+    if (wg == 0u && threadIdx.x == 0 && cull_hint)
+        __hip_atomic_store(cull_hint, 1u + max(max(s_hint[0], s_hint[1]), max(s_hint[2], s_hint[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        uint32_t before = base;
+        for (uint32_t k = 0; k < w; ++k) before += s_cnt[j][k];
+        base += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+        if (key[j] == ~0ull) continue;
+        const uint32_t dst = before + (uint32_t)__popcll(m[j] & ((1ull << lane) - 1ull));
+        const uint32_t gid = (uint32_t)key[j];
+        const float t = __uint_as_float((uint32_t)(key[j] >> 32));
+        if (compact == 3u) {
+        } else if (compact) {
+            points[dst] = make_float4(t * (st[j] * cs[j].x), t * (st[j] * cs[j].y), t * ctv[j], __int_as_float((int)v[j]));
+        } else {
+            points[2 * (size_t)dst] = make_float4(t * (st[j] * cs[j].x), t * (st[j] * cs[j].y), t * ctv[j], 0.0f);
+            points[2 * (size_t)dst + 1] = make_float4(64.0f, __int_as_float((int)v[j]), 0.0f, 0.0f);
+        }
+        uint32_t lo = 0, hi = gt.n;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (gt.tri_first[mid] <= gid) lo = mid; else hi = mid;
+        }
+        const uint32_t first = lo ? gt.tri_first[lo] : first0, geom = lo ? gt.geom_ids[lo] : geom0, shift = lo ? gt.prim_shift[lo] : shift0;
+        if (hits) hits[dst] = make_uint4(v[j] * tb.H + h[j], geom, (gid - first) >> shift, __float_as_uint(t));
+    }
+}
+
 // one word for the host, in stream order (ls_trace_scene_expand polls it)
 __global__ void k_signal(uint32_t *word, uint32_t value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -1572,7 +1675,7 @@ void launch_pack(hipStream_t s, const SensorTables &tb, float *t, uint32_t *gid,
 void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long *keys, float *t, uint32_t *gid,
                       const uint32_t *block_counts, uint32_t *next_block_counts, uint32_t *big_count,
                       const GeomTable &gt, uint8_t *points32, void *hits, uint32_t *n_points, uint32_t compact,
-                      const ProgressArgs *progress)
+                      const ProgressArgs *progress, uint32_t rays_per_lane)
 {
     const uint32_t nq = tb.V * tb.naz;
     if (!nq) return;
@@ -1582,6 +1685,18 @@ void launch_pack_keys(hipStream_t s, const SensorTables &tb, unsigned long long 
                  reinterpret_cast<float4 *>(points32), reinterpret_cast<uint4 *>(hits), n_points, compact, block0, nb,
                  progress ? *progress : ProgressArgs{nullptr, 0u, 0u, nullptr});
     };
+    if (rays_per_lane >= 2u && (!progress || !progress->host) && compact != 2u) {
+        uint32_t *hint = progress ? progress->cull_hint : nullptr;
+        float4 *p4 = reinterpret_cast<float4 *>(points32);
+        uint4 *h4 = reinterpret_cast<uint4 *>(hits);
+        if (rays_per_lane >= 8u)
+            launch_k(k_pack_wide<8>, dim3((nb + 7u) / 8u), dim3(kBlock), 0, s, tb, keys, block_counts, next_block_counts, big_count, gt, p4, h4, n_points, compact, nb, hint);
+        else if (rays_per_lane >= 4u)
+            launch_k(k_pack_wide<4>, dim3((nb + 3u) / 4u), dim3(kBlock), 0, s, tb, keys, block_counts, next_block_counts, big_count, gt, p4, h4, n_points, compact, nb, hint);
+        else
+            launch_k(k_pack_wide<2>, dim3((nb + 1u) / 2u), dim3(kBlock), 0, s, tb, keys, block_counts, next_block_counts, big_count, gt, p4, h4, n_points, compact, nb, hint);
+        return;
+    }
     if (!progress || !progress->host) { launch(0u, nb); return; }
     // two launches, each followed by a word for the host: a kernel's writes to pinned host memory are complete when the
     // kernel is, so the word that follows it in the stream says "these records have arrived" without a fence per wave

@@ -1116,6 +1116,102 @@ __global__ __launch_bounds__(kBlock) void k_project_finish(ProjectParams pp, uns
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// The finish pass with RPT rays per lane (thread t takes rays t, t + 256, ... of its workgroup's RPT x 256), for frames that
+// overlap on three streams.  There the device is short of WAVE SLOTS -- six and nine frames in flight are no faster than three
+// (tools/two_handles_probe.py) -- and what a frame costs is the sum over its waves of how long each holds its slot.  A wave of
+// this pass holds it for one memory round trip whatever it carries: a quarter of the waves with four key loads in flight each
+// 15.2 -> 14.8 us per frame; k_pack_wide (ls_kernels.hip) the same way 14.8 -> 13.4.  A frame ALONE is slower like this
+// (24.3 -> 25.4 us: fewer waves to hide the latency behind), so ls_trace.cpp asks for it in three-stream mode only, and only
+// while a workgroup per CU is left (a shard's 256 ray blocks stay as they are).
+template <uint32_t RPT>
+__global__ __launch_bounds__(kBlock) void k_project_finish_wide(ProjectParams pp, unsigned long long *__restrict__ best,
+                                                                const BigItem *__restrict__ big, uint32_t big_capacity,
+                                                                const uint32_t *__restrict__ big_count, uint32_t *__restrict__ block_counts)
+{
+    __shared__ uint32_t s_cnt[RPT][kBlock / 64];
+    __shared__ uint32_t s_box[4][kBlock / 64];
+    __shared__ uint16_t s_list[kCullChunk];
+    __shared__ uint32_t s_n;
+    const SensorTables &tb = pp.tb;
+    const uint32_t n = tb.V * tb.naz, n_blocks = (n + kBlock - 1u) / kBlock;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t q0 = blockIdx.x * RPT * kBlock + threadIdx.x;
+    const uint32_t n_big = min(*big_count, big_capacity);
+    unsigned long long key[RPT];
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        const uint32_t q = q0 + j * kBlock;
+        key[j] = q < n ? best[q] : ~0ull;
+    }
+    if (n_big) {   // uniform
+        for (uint32_t j = 0; j < RPT; ++j) {
+            const uint32_t q = q0 + j * kBlock;
+            uint32_t rank = 0, h = 0, rmin = 0xFFFFFFFFu, rmax = 0, cmin = 0xFFFFFFFFu, cmax = 0;
+            V3 d = {0.f, 0.f, 0.f};
+            if (q < n) {
+                const uint32_t v = q / tb.naz;
+                h = tb.az0 + (q - v * tb.naz);
+                rank = pp.chan_rank[v];
+                const float st = tb.sin_theta[v];
+                const float2 cs = tb.cs_phi[h];
+                d = {st * cs.x, st * cs.y, tb.cos_theta[v]};
+                rmin = rmax = rank;
+                cmin = cmax = h;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                rmin = min(rmin, (uint32_t)__shfl_xor(rmin, off)); rmax = max(rmax, (uint32_t)__shfl_xor(rmax, off));
+                cmin = min(cmin, (uint32_t)__shfl_xor(cmin, off)); cmax = max(cmax, (uint32_t)__shfl_xor(cmax, off));
+            }
+            __syncthreads();
+            if (lane == 0) { s_box[0][w] = rmin; s_box[1][w] = rmax; s_box[2][w] = cmin; s_box[3][w] = cmax; }
+            __syncthreads();
+            rmin = min(min(s_box[0][0], s_box[0][1]), min(s_box[0][2], s_box[0][3]));
+            rmax = max(max(s_box[1][0], s_box[1][1]), max(s_box[1][2], s_box[1][3]));
+            cmin = min(min(s_box[2][0], s_box[2][1]), min(s_box[2][2], s_box[2][3]));
+            cmax = max(max(s_box[3][0], s_box[3][1]), max(s_box[3][2], s_box[3][3]));
+            for (uint32_t base = 0; base < n_big; base += kCullChunk) {
+                if (threadIdx.x == 0) s_n = 0;
+                __syncthreads();
+                const uint32_t m = min(kCullChunk, n_big - base);
+                for (uint32_t k = threadIdx.x; k < m; k += kBlock) {
+                    const BigItem &it = big[base + k];
+                    const bool rows = it.i0 <= rmax && it.i0 + it.nch > rmin;
+                    const bool cols = (it.na && it.h0a <= cmax && it.h0a + it.na > cmin) || (it.nb && it.h0b <= cmax && it.h0b + it.nb > cmin);
+                    if (rows && cols) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)k;
+                }
+                __syncthreads();
+                const uint32_t cnt = s_n;
+                if (q < n) {
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        const BigItem &it = big[base + s_list[k]];
+                        if (rank - it.i0 >= it.nch) continue;
+                        if (h - it.h0a >= it.na && h - it.h0b >= it.nb) continue;
+                        float t;
+                        if (tri_test(d, {it.v0[0], it.v0[1], it.v0[2]}, {it.e1[0], it.e1[1], it.e1[2]}, {it.e2[0], it.e2[1], it.e2[2]},
+                                     it.NgC, t)) {
+                            const unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | it.gid;
+                            key[j] = k2 < key[j] ? k2 : key[j];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (q < n) best[q] = key[j];
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < RPT; ++j) {
+        const unsigned long long m = __ballot(key[j] != ~0ull);
+        if (lane == 0) s_cnt[j][w] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < RPT) {
+        const uint32_t b = blockIdx.x * RPT + threadIdx.x;
+        if (b < n_blocks) block_counts[b] = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LS_OPT_PIPELINE: finish + pack of one frame as a single set of workgroups that can ride in the same
 // launch as the next frame's k_project (k_frame) -- one launch per frame instead of three, and the
@@ -1321,7 +1417,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k
 
 void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long long *best, const void *big,
                            uint32_t big_capacity, const uint32_t *big_count, uint32_t *block_counts,
-                           unsigned long long *stats)
+                           unsigned long long *stats, uint32_t rays_per_lane)
 {
     const uint32_t n = pp.tb.V * pp.tb.naz;
     if (!n) return;
@@ -1329,6 +1425,12 @@ void launch_project_finish(hipStream_t s, const ProjectParams &pp, unsigned long
     if (stats)
         hipLaunchKernelGGL(k_project_finish<true>, grid, dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big),
                            big_capacity, big_count, block_counts, stats);
+    else if (rays_per_lane >= 4u)
+        launch_k(k_project_finish_wide<4>, dim3((grid.x + 3u) / 4u), dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big), big_capacity,
+                 big_count, block_counts);
+    else if (rays_per_lane >= 2u)
+        launch_k(k_project_finish_wide<2>, dim3((grid.x + 1u) / 2u), dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big), big_capacity,
+                 big_count, block_counts);
     else
         launch_k(k_project_finish<false>, grid, dim3(kBlock), 0, s, pp, best, static_cast<const BigItem *>(big),
                  big_capacity, big_count, block_counts, stats);

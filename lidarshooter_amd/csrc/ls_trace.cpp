@@ -814,12 +814,16 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                 mark(tr, 9);
                 mark(tr, 10);
             } else {
-                ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats);
+                // three-stream mode: the two passes as fewer, fatter waves (the device is short of wave slots there, not alone:
+                // 15.2 -> 13.4 us per frame with three in flight, 24.3 -> 25.4+ with one -- ls_project.hip, k_project_finish_wide)
+                static const int rpl_env = tune_int("LS_PROJECT_RAYS_PER_LANE", 0);   // (experiment: 1 switches it off)
+                const uint32_t rpl = multi && !progress && !stats ? (rpl_env ? (uint32_t)rpl_env : ls::project_rays_per_lane(n_blocks)) : 1u;
+                ls::launch_project_finish(s, pp, keys, bigq, tr->big_capacity, big_count, counts, stats, rpl);
                 mark(tr, 9);
                 // (a frame that reports its progress sends 8-byte (ray, t) records: ls_trace_scene_expand rebuilds the points)
                 pg.cull_hint = any_culled ? hint_word : nullptr;
                 ls::launch_pack_keys(s, tb, keys, tr->hit_t.p, tr->hit_gid.p, counts, next_counts, big_count, gt, d_points, d_hits, d_n,
-                                     progress ? 2u : compact, &pg);
+                                     progress ? 2u : compact, &pg, rpl);
                 mark(tr, 10);
             }
             if (multi) {

@@ -549,18 +549,21 @@ def test_two_step_trace_on_an_azimuth_shard(oracle, capi, sensors, meshes):
     tr.close()
 
 
-def test_raster_beyond_2048_ray_blocks(oracle, capi, sensors):
+@pytest.mark.parametrize("V,H,blocks", [(160, 4096, 2560), (161, 4090, 2573), (131, 4000, 2047), (67, 4001, 1048), (40, 4099, 641)])
+def test_raster_beyond_2048_ray_blocks(oracle, capi, sensors, V, H, blocks):
     """160 x 4096 rays = 2 560 blocks of 256: k_pack asks for a thread's block counts eight at a time, which covers the
     2 048 blocks of the headline raster in one go -- here the loop comes round a second time, and the workgroup that publishes
     the two-step trace's hit count owns chunks of ten counts.  One-step on both engines, two-step, and three frames in flight,
-    all against the BVH oracle."""
+    all against the BVH oracle.  The other rasters are for the frames in flight: there the finish and pack passes take 8 / 4 /
+    2 rays per lane (from 2 048 / 1 024 / 512 ray blocks: k_project_finish_wide, k_pack_wide), and these block counts leave the
+    last workgroup a part of its span, the last block a part of its rays."""
     import torch
     from lidarshooter_amd import synth
     v, t = synth.grid_mesh(300, 200)
-    s = _syn_sensor(oracle, sensors, V=160, H=4096)
-    assert (s.V * s.H + 255) // 256 == 2560
+    s = _syn_sensor(oracle, sensors, V=V, H=H)
+    assert (s.V * s.H + 255) // 256 == blocks
     ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True)
-    assert ref["points"].shape[0] > 100000
+    assert ref["points"].shape[0] > 30000
     for engine_name in ("projection", "bvh"):
         tr = make_tracer(capi, s, engine_name)
         tr.addGeometry("grid", v.shape[0], t.shape[0])
@@ -572,6 +575,7 @@ def test_raster_beyond_2048_ray_blocks(oracle, capi, sensors):
         assert rc == 0 and np.array_equal(pts, ref["points"])
         if engine_name == "projection":
             tr.setOption(capi.LS_OPT_PIPELINE, 2)
+            assert tr.info(capi.LS_INFO_PIPELINE_MODE) == 2
             cap = s.V * s.H
             bufs = [(torch.zeros(32 * cap, dtype=torch.uint8, device="cuda:0"), torch.zeros(16 * cap, dtype=torch.uint8, device="cuda:0"),
                      torch.zeros(4, dtype=torch.int32, device="cuda:0")) for _ in range(3)]
