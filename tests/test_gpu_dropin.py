@@ -562,12 +562,20 @@ def test_raster_beyond_2048_ray_blocks(oracle, capi, sensors, V, H, blocks):
     v, t = synth.grid_mesh(300, 200)
     s = _syn_sensor(oracle, sensors, V=V, H=H)
     assert (s.V * s.H + 255) // 256 == blocks
-    ref = oracle.trace_frame(s, [(0, v, t, oracle.IDENTITY_AFFINE)], use_bvh=True)
+    scene = [(0, v, t, oracle.IDENTITY_AFFINE)]
+    if blocks == 2047:   # two geometries (a quad mesh among them: primID = triangle >> 1): the hit records' (geomID, primID) look-up
+        qv = np.array([[-30, -30, 1.5], [30, -30, 1.5], [30, 30, 2.5], [-30, 30, 2.5], [0, 0, 6.0]], np.float32)
+        qi = np.array([[0, 1, 2, 3], [0, 1, 4, 4]], np.uint32)
+        scene.append((1, qv, qi, oracle.IDENTITY_AFFINE))
+    ref = oracle.trace_frame(s, scene, use_bvh=True)
     assert ref["points"].shape[0] > 30000
     for engine_name in ("projection", "bvh"):
         tr = make_tracer(capi, s, engine_name)
         tr.addGeometry("grid", v.shape[0], t.shape[0])
         tr.updateGeometry("grid", oracle.IDENTITY_AFFINE, v, t)
+        if len(scene) > 1:
+            assert tr.addGeometry("quads", scene[1][1].shape[0], scene[1][2].shape[0], capi.LS_GEOMETRY_TYPE_QUAD) == 1
+            tr.updateGeometry("quads", oracle.IDENTITY_AFFINE, scene[1][1], scene[1][2])
         assert tr.commitScene() == 0
         rc, pts, hits = tr.traceScene(0)
         assert rc == 0 and np.array_equal(pts, ref["points"]) and np.array_equal(_hits_array(hits), ref["hits"])

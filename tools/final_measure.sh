@@ -91,7 +91,7 @@ bash tools/rocprof_kernels.sh ${TAG}_refit tools/refit_cost.py 50 > gpurun_out/f
 tail -2 gpurun_out/rp_${TAG}_refit/stdout.log >> gpurun_out/final/${TAG}_bvh_refit_kernels.txt
 fi
 if [ "$PART" = c ] || [ "$PART" = all ]; then
-{ python tests/analysis/soak.py 60; python tests/analysis/soak_bvh.py 60; python tests/analysis/soak_shard.py 120
+{ python tests/analysis/soak.py 60; python tests/analysis/soak_bvh.py 60; python tests/analysis/soak_shard.py 120; python tests/analysis/soak_wide.py 60
   for fl in 0 4 2; do python tests/analysis/soak_group.py 40 $fl; done; } > gpurun_out/final/${TAG}_soak.txt 2>&1
 fi
 # (gpurun copies back 64 MiB at most: the raw traces and counter dumps have been condensed into gpurun_out/final by now)
