@@ -43,6 +43,7 @@ PROFILE_TAG = "r05"     # profiles/<tag>_<engine>_hbm.json: the rocprofv3 PMC su
 NODE_BYTES, TRI_BYTES, RAY_OUT_BYTES = 64, 48, 8  # DESIGN.md "algorithmic bytes" (BVH engine)
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 HOST_NUMA = None
+SHIM = False
 
 
 def parse_args():
@@ -352,7 +353,9 @@ class Watchdog:
     job instead of holding the node until somebody else's limit: every rank says which phase it was, rank 0 still prints
     ONE line -- the measurements that did finish (the frame-interleaved split is measured first for that reason: nothing
     is exchanged on its frame path), `value` taken from them, and an "error" field that says what did not -- and the ranks
-    leave with os._exit (0 when there is such a line, 3 when there is nothing to report)."""
+    leave with os._exit: 4 when there is such a line (a job whose watchdog fired did NOT succeed -- ADVICE round 5 -- but its
+    line is there to be read), 3 when there is nothing to report."""
+    EXIT_WITH_LINE, EXIT_WITHOUT = 4, 3
 
     def __init__(self, result_fd: int, rank: int):
         import threading
@@ -403,7 +406,7 @@ class Watchdog:
                 os.write(self.result_fd, (json.dumps(front_loaded(line)) + "\n").encode())
         else:
             time.sleep(3.0)   # rank 0 writes its line before a launcher that sees a rank leave ends the others
-        os._exit(0 if fallback is not None else 3)
+        os._exit(self.EXIT_WITH_LINE if fallback is not None else self.EXIT_WITHOUT)
 
 
 def spawn_ranks(args) -> int:
@@ -412,7 +415,7 @@ def spawn_ranks(args) -> int:
     this image either) -- and hand the child's stdout (rank 0's one JSON line) through.  Returns the child's exit code."""
     import socket
     import subprocess
-    rehearsal = os.environ.get("LS_BENCH_REHEARSAL") == "1"
+    rehearsal = os.environ.get("LS_BENCH_REHEARSAL") == "1" or os.environ.get("LS_BENCH_SHIM") == "1"
     if not rehearsal and not args.spawn_check:
         n = torch.cuda.device_count()
         if n < args.gpus:
@@ -468,13 +471,23 @@ def main():
     # LS_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo -- only to rehearse the N > 1 code path on
     # a one-GPU box (RCCL refuses two ranks on one device); never used for a reported number
     rehearsal = os.environ.get("LS_BENCH_REHEARSAL") == "1"
-    dev_index = 0 if rehearsal else local_rank
+    # LS_BENCH_SHIM=1 (tests/test_gpu_group_shim.py): the ranks share GPU 0 too, but the frames go through the C group driver
+    # like on a real node -- its collectives on tests/shim/librccl_shim.so (LS_GROUP_RCCL_LIBRARY), torch.distributed's control
+    # plane on gloo.  Every phase of the N > 1 flow meets a real peer; the line is labelled and is never a number to quote.
+    global SHIM
+    SHIM = os.environ.get("LS_BENCH_SHIM") == "1" and world > 1
+    if SHIM:
+        if not os.environ.get("LS_GROUP_RCCL_LIBRARY"):
+            raise SystemExit("LS_BENCH_SHIM=1 needs LS_GROUP_RCCL_LIBRARY=<tests/shim/librccl_shim.so>")
+        if args.group_flags == 0:
+            args.group_flags = 2   # (the shim refuses a collective on a capturing stream: per-set communicators, plain launches)
+    dev_index = 0 if (rehearsal or SHIM) else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     global HOST_NUMA
     HOST_NUMA = pin_to_gpu_numa_node(dev_index) if os.environ.get("LS_BENCH_NO_PIN") != "1" else {"pinned": False, "why": "LS_BENCH_NO_PIN=1"}
     if world > 1:
-        if rehearsal:
+        if rehearsal or SHIM:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
@@ -624,8 +637,11 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                 raise SystemExit("ls_group_unique_id failed (no RCCL?)")
             uid = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=device)
         if world > 1:
+            uid = uid.cpu() if dist.get_backend() == "gloo" else uid
             dist.broadcast(uid, src=0)
         grp = groupapi.Group(tr, world, rank, groupapi.SHARDED, bytes(uid.cpu().numpy().tobytes()), flags=args.group_flags)
+        if bool(grp.info(groupapi.INFO_COLLECTIVES_ARE_A_SHIM)) != SHIM:
+            raise SystemExit("the group's collective library and LS_BENCH_SHIM disagree: a shim run must be labelled, a real one must not use it")
         rccl_info = grp.rccl()
         count_words = None
     else:
@@ -1131,6 +1147,10 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
             pass
     one_ms = latency_frame_s * 1e3 if latency_frame_s is not None else ms_per_step
 
+    if cgroup:   # the whole frame's cloud as this rank holds it after the gather + rebuild (the group keeps three frames)
+        import hashlib
+        gathered_cloud = grp.download(group_last_frame[0])[0]
+        points_sha = hashlib.sha256(gathered_cloud.tobytes()).hexdigest()
     out = {
         "metric": {"syn128x1m": "Mrays/s (LiDAR frame = updateGeometry + commitScene + traceScene incl. point packing, 128ch x 4096az over 1M tris; "
                                 "geometry resident in HBM, every mesh's pose restated per frame; cloud left in HBM -- the frame with vertices "
@@ -1140,7 +1160,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                    "xt32": "Mrays/s (XT-32 over ground+ben)"}[args.workload],
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if independent else "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" + (" (LS_BENCH_SHIM: %d ranks on ONE device, collectives through tests/shim -- a test of semantics, not a measurement)" % world if SHIM else ""),
         "config": {"workload": {"syn128x1m": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)",
                                 "syn128x10m": "SYN-128 x SYN-10M (9,998,244 tris)",
                                 "cfg5": "8-pose SYN-128 ring x (SYN-10M + ben.stl animated by trajectory.json), replicas only",
@@ -1181,7 +1201,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         "hits_per_frame_rank0": n_hits,
         "points_sha256": points_sha,
         # N > 1: points of the whole frame as rebuilt from the gathered slots on rank 0 (= the 1-GPU hit count)
-        "gathered_points_rank0": None if single else (int(grp.download(group_last_frame[0])[0].shape[0]) if cgroup else int(cloud_n[0].item())),
+        "gathered_points_rank0": None if single else (int(gathered_cloud.shape[0]) if cgroup else int(cloud_n[0].item())),
         "rehearsal_gloo_shared_gpu": True if rehearsal else None,
         "rccl": rccl_out,
         "host_numa": HOST_NUMA,

@@ -1,7 +1,9 @@
 /*
  * lidarshooter_group.h -- one LiDAR frame over the GPUs of a node, from C or C++ (no Python, no PyTorch): the
  * multi-GPU part of SURVEY.md section 8(e) behind the C ABI of lidarshooter_hip.h.  One process per GPU; the
- * collective is RCCL (librccl.so.1, loaded at ls_group_create; xGMI between the GPUs of a node).
+ * collective is RCCL (librccl.so.1, loaded at ls_group_create; xGMI between the GPUs of a node).  The environment variable
+ * LS_GROUP_RCCL_LIBRARY, when set, names the library to load instead (an absolute path: a site's own RCCL build); a library
+ * named there and not loadable is an error (LS_ERR_NO_DEVICE), never a silent fall-back.
  *
  * The reference has no multi-GPU path ("no NCCL / MPI / Gloo"); this is new surface.  Two ways
  * to spread a stream of frames over `world` GPUs, every GPU holding the whole scene:
@@ -81,9 +83,10 @@ int ls_group_create(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_
 /* The arrangement (per-set communicators, frames as graphs) is agreed on by the ranks at create: each rank says what it can do
  * -- its communicator duplicates exist, its tracer found three concurrent streams (a timing calibration) -- the answers are
  * gathered over the first communicator and every rank takes the AND (LS_GROUP_INFO_ARRANGEMENT_MINE / _COMMON): a rank that
- * fell back alone would issue its collectives on another communicator than its peers and the group would hang.
- *   LS_GROUP_FLAG_DEBUG_PEER_REFUSES  test only: the gathered answers are treated as if a peer had answered "neither" */
-#define LS_GROUP_FLAG_DEBUG_PEER_REFUSES 0x100u
+ * fell back alone would issue its collectives on another communicator than its peers and the group would hang.  How the
+ * duplicates are made (ncclCommSplit, or a second id broadcast over the first communicator) is agreed on the same way before
+ * the first of them, and every rank attempts every duplicate whatever became of the one before: no rank ever skips a
+ * collective its peers are in.  (Flag 0x100 is a test hook: lidarshooter_hip_debug.h.) */
 int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, uint32_t rank, int mode, uint32_t flags, ls_tracer *tr,
                          ls_group **out);
 void ls_group_destroy(ls_group *g);
@@ -117,6 +120,8 @@ int ls_group_synchronize(ls_group *g);
                                            * the finished ones among the (at most three) frames still held                            */
 #define LS_GROUP_INFO_ARRANGEMENT_MINE 9    /* what this rank could do: bit 0 a communicator per set, bit 1 three concurrent streams  */
 #define LS_GROUP_INFO_ARRANGEMENT_COMMON 10 /* the AND over all ranks: what the group runs                                            */
+#define LS_GROUP_INFO_COLLECTIVES_ARE_A_SHIM 11 /* 1: LS_GROUP_RCCL_LIBRARY named tests/shim/librccl_shim.so (several ranks on ONE
+                                                 * device through shared memory: semantics, not speed) -- a run on it must say so   */
 long ls_group_info(ls_group *g, int what);
 const char *ls_group_last_error(const ls_group *g);
 

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define LS_ABI_VERSION 3
+/* 4 (round 6): + ls_tracer_set_hit_buffers, ls_group_frame_status, LS_INFO_EMIT_POINTS, LS_INFO_FRAME_GRAPH_PATCH_WAITS,
+ *    ls_source_hash, LS_GROUP_INFO_ARRANGEMENT_*; ls_tracer_set_sensor* is refused while external output buffers are
+ *    installed; ls_commit_scene can return LS_ERR_OUT_OF_RANGE; the test hooks left this header for lidarshooter_hip_debug.h.
+ *    The bindings (capi.py, groupapi.py, integration/HipTracer.hpp) check it against ls_abi_version() at load. */
+#define LS_ABI_VERSION 4
 
 typedef struct ls_tracer ls_tracer;
 
@@ -223,6 +227,10 @@ uint32_t ls_total_channels(ls_tracer *tr);
 
 const char *ls_last_error(ls_tracer *tr);
 int ls_abi_version(void);
+/* Sixteen hex digits: SHA-256 over the library's sources (every .hip / .h / .cpp file of csrc: file name then contents, in sorted order)
+ * as they were when THIS binary was built.  bench.py prints it next to the hash of the sources it finds, so that a stale
+ * .so cannot speak for newer sources (the library is built in-tree and travels to the GPU box as a binary). */
+const char *ls_source_hash(void);
 
 /* ---- multi-GPU: restrict this handle to the azimuth columns [first_az, first_az + n_az) of every
  * channel.  Ray indices in ls_hit stay global.  Default: the full revolution. */
@@ -315,8 +323,7 @@ int ls_tracer_set_hit_buffers(ls_tracer *tr, void *d_hits, uint32_t *d_n_points,
 #define LS_OPT_READBACK_HITS 8  /* synchronous ls_trace_scene: 1 (default) ls_frame.hits is filled; 0: the 16-byte
                                  *    hit records stay on the device (ls_frame.hits = NULL, d_hits valid) -- the ITracer
                                  *    adapter only needs the 32-byte points.                                   */
-#define LS_OPT_DEBUG_FAULT 9    /* test hook: 1 makes the next pipelined frame publish a wrong epoch, so that the
-                                 *    chained prefix gives up and the device status word is raised (one frame).  */
+/*      option 9 is a test hook (lidarshooter_hip_debug.h: LS_OPT_DEBUG_FAULT); not part of this surface             */
 #define LS_OPT_BVH_REFIT 11     /* BVH engine: 1 (default) a commit after which only vertices / poses differ refits the
                                  *    hierarchy (OptixTracer.cpp:532-535 OPERATION_UPDATE): no key pass, no sort; 0: always
                                  *    a full build.  Identical results.                                                   */

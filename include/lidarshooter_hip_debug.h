@@ -12,6 +12,15 @@
 extern "C" {
 #endif
 
+/* ---- fault injection (values live in the option / flag spaces of the public headers, their names do not) --------- */
+/* ls_tracer_set_option: 1 makes the next pipelined frame publish a wrong epoch, so that the chained prefix gives up and
+ * the device status word is raised (one frame). */
+#define LS_OPT_DEBUG_FAULT 9
+/* ls_group_create_opts (include/lidarshooter_group.h): the gathered arrangement answers are treated as if a peer had
+ * answered "neither" -- a one-rank test takes the disagreement path.  (With two real ranks tests/shim/ makes a peer that
+ * really refuses.) */
+#define LS_GROUP_FLAG_DEBUG_PEER_REFUSES 0x100u
+
 /* Dense per-ray results of the last trace, host buffers of n_rays entries (shard-local order
  * q = v*n_az + (h-first_az)): t (< 0 = miss) and global triangle id (0xFFFFFFFF = miss). */
 int ls_debug_dense_hits(ls_tracer *tr, float *t, uint32_t *gid);

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LS_LIB_PATH: kernel-variant experiments (tools/) load another build of the same library
 LIB_PATH = os.environ.get("LS_LIB_PATH") or os.path.join(_HERE, "liblidarshooter_hip.so")
 INVALID = 0xFFFFFFFF
+ABI_VERSION = 4   # include/lidarshooter_hip.h: LS_ABI_VERSION (checked at load)
 
 LS_OPT_LEAF_SIZE, LS_OPT_TIMING, LS_OPT_COUNT_VISITS, LS_OPT_ENGINE, LS_OPT_PIPELINE = 1, 2, 3, 5, 6
 LS_OPT_HOST_OUTPUT, LS_OPT_READBACK_HITS, LS_OPT_DEBUG_FAULT, LS_OPT_BLOCK_CULL, LS_OPT_BVH_REFIT = 7, 8, 9, 10, 11
@@ -37,7 +38,7 @@ STAGES = ("transform", "morton", "sort", "leaves", "range_tree", "hierarchy", "t
 
 # every symbol include/lidarshooter_hip.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = (
-    "ls_abi_version", "ls_tracer_create", "ls_tracer_create_tables", "ls_tracer_destroy", "ls_parallel_copy", "ls_expand_points", "ls_get_info", "ls_affine_from_components", "ls_add_geometry", "ls_remove_geometry",
+    "ls_abi_version", "ls_source_hash", "ls_tracer_create", "ls_tracer_create_tables", "ls_tracer_destroy", "ls_parallel_copy", "ls_expand_points", "ls_get_info", "ls_affine_from_components", "ls_add_geometry", "ls_remove_geometry",
     "ls_update_geometry", "ls_update_geometry_components", "ls_update_geometry_device",
     "ls_update_geometry_device_shared", "ls_update_geometry_transform", "ls_commit_scene", "ls_trace_scene", "ls_trace_scene_async",
     "ls_geometry_count", "ls_geometry_id", "ls_vertex_count", "ls_element_count", "ls_total_rays",
@@ -105,6 +106,10 @@ def load() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, u32, i32, f32p, u32p = C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.ls_abi_version.restype = i32
+    if L.ls_abi_version() != ABI_VERSION:   # (a stale .so next to a newer binding, or the other way round)
+        raise LidarShooterHipError(f"{LIB_PATH} speaks ABI {L.ls_abi_version()}, this binding {ABI_VERSION}: rebuild (make -C lidarshooter_amd/csrc)")
+    L.ls_source_hash.argtypes = []
+    L.ls_source_hash.restype = C.c_char_p
     L.ls_tracer_create.argtypes = [C.POINTER(SensorDesc), i32, C.POINTER(vp)]
     L.ls_tracer_create_tables.argtypes = [C.POINTER(SensorTables), i32, C.POINTER(vp)]
     L.ls_tracer_set_sensor.argtypes = [vp, C.POINTER(SensorDesc)]

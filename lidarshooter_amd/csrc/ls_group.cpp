@@ -2,6 +2,7 @@
 // node, one process per GPU, RCCL for the one collective (loaded with dlopen so that the slot arithmetic below works,
 // and is tested, on machines without a GPU or without RCCL).
 #include "../../include/lidarshooter_group.h"
+#include "../../include/lidarshooter_hip_debug.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -9,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,15 +35,25 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     std::string err;
+    bool is_shim = false;   // tests/shim/librccl_shim.so (reported by ls_group_info: a run on it is labelled, never mistaken for RCCL)
     bool load()
     {
         if (lib) return true;
+        // LS_GROUP_RCCL_LIBRARY: the collective library a site wants instead of the one the loader finds (a path; a site's own
+        // RCCL build -- and tests/shim/librccl_shim.so, which stands in for RCCL where one device must serve two ranks).  Named
+        // and not found is an error, never a silent fall-back on another library.
+        const char *forced = std::getenv("LS_GROUP_RCCL_LIBRARY");
+        if (forced && *forced) {
+            lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) { err = std::string("LS_GROUP_RCCL_LIBRARY=") + forced + ": " + dlerror(); return false; }
+        }
         // the soname first: a process that already holds RCCL (PyTorch brings its own copy) gets that one back
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!lib) { err = "librccl.so.1 not found"; return false; }
+        is_shim = dlsym(lib, "ls_rccl_shim_marker") != nullptr;
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
@@ -221,15 +233,29 @@ void ls_group_destroy(ls_group *g)
 }
 
 namespace {
-// a second communicator over the same ranks: ncclCommSplit with one colour where RCCL has it, else a fresh id that
-// rank 0 makes and the first communicator broadcasts.  Collective; nullptr when neither works.
-ncclComm_t duplicate_comm(ls_group *g, hipStream_t s)
+// One 32-bit word from every rank over the first communicator -> the AND over the ranks (negative: the gather failed).
+int gather_and(ls_group *g, uint32_t mine)
+{
+    uint32_t *d = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d), 4u * (g->world + 1u)) != hipSuccess) return LS_ERR_HIP;
+    std::vector<uint32_t> all(g->world, 0u);
+    bool ok = hipMemcpyAsync(d + g->world, &mine, 4, hipMemcpyHostToDevice, g->comm_stream) == hipSuccess &&
+              rccl().AllGather(d + g->world, d, 4, ncclUint8, g->comm, g->comm_stream) == ncclSuccess &&
+              hipMemcpyAsync(all.data(), d, 4u * g->world, hipMemcpyDeviceToHost, g->comm_stream) == hipSuccess &&
+              hipStreamSynchronize(g->comm_stream) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return LS_ERR_HIP;
+    uint32_t common = 0x7FFFFFFFu;
+    for (uint32_t v : all) common &= v;
+    return (int)common;
+}
+
+// a second communicator over the same ranks from a fresh id that rank 0 makes and the first communicator broadcasts
+// (libraries without ncclCommSplit).  Collective; nullptr when it did not work here.
+ncclComm_t duplicate_by_id(ls_group *g, hipStream_t s)
 {
     Rccl &R = rccl();
     ncclComm_t dup = nullptr;
-    if (R.CommSplit && R.CommSplit(g->comm, 0, (int)g->rank, &dup, nullptr) == ncclSuccess && dup) return dup;
-    dup = nullptr;
-    if (!R.Broadcast) return nullptr;
     ncclUniqueId u;
     std::memset(&u, 0, sizeof(u));
     if (g->rank == 0 && R.GetUniqueId(&u) != ncclSuccess) std::memset(&u, 0, sizeof(u));   // (the others then fail to join, all alike)
@@ -243,6 +269,39 @@ ncclComm_t duplicate_comm(ls_group *g, hipStream_t s)
     return ok ? dup : nullptr;
 }
 
+// The communicators of the buffer sets 1 .. kSets - 1.  Every rank issues the SAME collectives whatever happens to it
+// locally: HOW a duplicate is made -- ncclCommSplit with one colour, or a fresh id broadcast over the first
+// communicator -- is the group's choice, the AND of "my library has ncclCommSplit" gathered first, never a rank's; and a
+// rank whose duplicate i failed still attempts duplicate i + 1 with its peers.  (The old code chose per rank and per call: a
+// rank whose split failed locally went into a broadcast its peers were not in.)  A duplicate that failed HERE is nullptr
+// while the peers may hold their half of it: agree_on_arrangement's AND makes every rank drop all of them.
+// -> 1 every duplicate exists on this rank, 0 not, negative: the first communicator itself does not work.
+int make_duplicates(ls_group *g)
+{
+    Rccl &R = rccl();
+    const int by_split = gather_and(g, R.CommSplit ? 1u : 0u);
+    if (by_split < 0) return by_split;
+    if (!(by_split & 1) && !R.Broadcast) return 0;   // (the library's: the same answer on every rank that loaded it)
+    bool all = true;
+    for (int i = 0; i < kSets - 1; ++i) {
+        ncclComm_t dup = nullptr;
+        if (by_split & 1) {
+            if (R.CommSplit(g->comm, 0, (int)g->rank, &dup, nullptr) != ncclSuccess) dup = nullptr;
+        } else {
+            dup = duplicate_by_id(g, g->comm_stream);
+        }
+        g->comm_dup[i] = dup;
+        all = all && dup != nullptr;
+    }
+    return all ? 1 : 0;
+}
+
+void drop_duplicates(ls_group *g)
+{
+    for (ncclComm_t &c : g->comm_dup)
+        if (c) { (void)rccl().CommDestroy(c); c = nullptr; }
+}
+
 // What every rank decided for itself about the group's arrangement -- `mine`: bit 0 "I hold a communicator per buffer set",
 // bit 1 "my tracer runs three frames on three streams" -- gathered over the first communicator: -> the AND over the ranks, or
 // negative.  A rank alone in an arrangement would issue its collectives on another communicator than its peers and the group
@@ -250,19 +309,10 @@ ncclComm_t duplicate_comm(ls_group *g, hipStream_t s)
 // calibration), the other a library call that can fail on one rank only.
 int agree_on_arrangement(ls_group *g, uint32_t mine)
 {
-    uint32_t *d = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&d), 4u * (g->world + 1u)) != hipSuccess) return LS_ERR_HIP;
-    std::vector<uint32_t> all(g->world, 0u);
-    bool ok = hipMemcpyAsync(d + g->world, &mine, 4, hipMemcpyHostToDevice, g->comm_stream) == hipSuccess &&
-              rccl().AllGather(d + g->world, d, 4, ncclUint8, g->comm, g->comm_stream) == ncclSuccess &&
-              hipMemcpyAsync(all.data(), d, 4u * g->world, hipMemcpyDeviceToHost, g->comm_stream) == hipSuccess &&
-              hipStreamSynchronize(g->comm_stream) == hipSuccess;
-    (void)hipFree(d);
-    if (!ok) return LS_ERR_HIP;
-    uint32_t common = ~0u;
-    for (uint32_t v : all) common &= v;
-    if (g->flags & LS_GROUP_FLAG_DEBUG_PEER_REFUSES) common = 0u;
-    return (int)(common & 3u);
+    int common = gather_and(g, mine);
+    if (common < 0) return common;
+    if (g->flags & LS_GROUP_FLAG_DEBUG_PEER_REFUSES) common = 0;
+    return common & 3;
 }
 }  // namespace
 
@@ -315,12 +365,9 @@ int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, ui
         // per-set mode: a communicator per buffer set (collective: every rank takes this branch or none does -- the flags
         // are the caller's and equal on all ranks).  Without the duplicates the group runs round 3's path.
         if (!(flags & LS_GROUP_FLAG_ONE_COMMUNICATOR)) {
-            bool all = true;
-            for (int i = 0; i < kSets - 1 && all; ++i) all = (g->comm_dup[i] = duplicate_comm(g, g->comm_stream)) != nullptr;
-            if (!all)
-                for (ncclComm_t &c : g->comm_dup)
-                    if (c) { (void)rccl().CommDestroy(c); c = nullptr; }
-            g->per_set = all;
+            const int made = make_duplicates(g);
+            if (made < 0) { g->err = "the first communicator does not carry a 4-byte all-gather"; return bail(LS_ERR_HIP); }
+            g->per_set = made == 1;   // (a partial set is kept until the ranks have agreed: its other halves live on the peers)
         }
         // (the shard's own 32-byte points are never written: LS_OPT_EMIT_POINTS = 0 below, hit buffers alone are installed
         // per frame -- ls_tracer_set_hit_buffers -- and every rank rebuilds the whole frame's points from the gathered records)
@@ -363,9 +410,7 @@ int ls_group_create_opts(const uint8_t id[LS_GROUP_ID_BYTES], uint32_t world, ui
         if (common < 0) { g->err = "the ranks could not agree on the group's arrangement (all-gather over the first communicator failed)"; return bail(LS_ERR_HIP); }
         g->arrangement_mine = (g->per_set ? 1u : 0u) | (three_streams ? 2u : 0u);
         g->arrangement_common = (uint32_t)common;
-        if (!(common & 1) && g->per_set)
-            for (ncclComm_t &c : g->comm_dup)
-                if (c) { (void)rccl().CommDestroy(c); c = nullptr; }
+        if (!(common & 1)) drop_duplicates(g);
         g->per_set = (common & 1) != 0;
         three_streams = three_streams && (common & 2);   // (a rank with three streams among ranks without runs the one-communicator path like them)
     }
@@ -635,6 +680,7 @@ long ls_group_info(ls_group *g, int what)
     }
     case LS_GROUP_INFO_ARRANGEMENT_MINE: return (long)g->arrangement_mine;
     case LS_GROUP_INFO_ARRANGEMENT_COMMON: return (long)g->arrangement_common;
+    case LS_GROUP_INFO_COLLECTIVES_ARE_A_SHIM: return R.is_shim ? 1 : 0;
     default: return fail(g, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }

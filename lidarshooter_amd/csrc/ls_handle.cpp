@@ -101,6 +101,13 @@ extern "C" {
 
 int ls_abi_version(void) { return LS_ABI_VERSION; }
 
+// (ls_source_hash.inc is written by the Makefile from the sources this binary is made of; the marker lets a script read the
+// hash out of the file without loading it)
+static const char kSourceHash[] = "LS_SOURCE_HASH="
+#include "ls_source_hash.inc"
+    ;
+const char *ls_source_hash(void) { return kSourceHash + 15; }
+
 // the sensor's tables on the device and on the host, from tr's sensor fields (create, ls_tracer_set_sensor*)
 static int upload_tables(ls_tracer *tr)
 {

@@ -10,6 +10,7 @@
 #pragma once
 
 #include "../../include/lidarshooter_hip.h"
+#include "../../include/lidarshooter_hip_debug.h"   // (LS_OPT_DEBUG_FAULT)
 #include "ls_kernels.h"
 #include "ls_launch.h"
 #include "ls_tuning.h"

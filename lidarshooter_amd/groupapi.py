@@ -19,7 +19,7 @@ SYMBOLS = ("ls_group_shard_columns", "ls_group_slot_capacity", "ls_group_slot_by
            "ls_group_create_opts", "ls_group_info", "ls_group_frame_status")
 FLAG_ONE_COMMUNICATOR, FLAG_NO_GRAPH, FLAG_SIZED_GATHER, FLAG_DEBUG_PEER_REFUSES = 1, 2, 4, 0x100
 INFO_RCCL_VERSION, INFO_COMM_RANKS, INFO_COMM_DEVICE, INFO_COMMUNICATORS, INFO_PER_SET, INFO_FRAME_GRAPH = 1, 2, 3, 4, 5, 6
-INFO_GATHER_CAPACITY, INFO_TRUNCATED_FRAMES, INFO_ARRANGEMENT_MINE, INFO_ARRANGEMENT_COMMON = 7, 8, 9, 10
+INFO_GATHER_CAPACITY, INFO_TRUNCATED_FRAMES, INFO_ARRANGEMENT_MINE, INFO_ARRANGEMENT_COMMON, INFO_COLLECTIVES_ARE_A_SHIM = 7, 8, 9, 10, 11
 _lib = None
 
 
@@ -116,7 +116,7 @@ class Group:
         """what RCCL itself says about this rank's communicator (bench.py's "rccl" object)"""
         return {"version": self.info(INFO_RCCL_VERSION), "comm_ranks": self.info(INFO_COMM_RANKS), "device": self.info(INFO_COMM_DEVICE),
                 "communicators": self.info(INFO_COMMUNICATORS), "per_set_streams": bool(self.info(INFO_PER_SET)),
-                "frame_graph_state": self.info(INFO_FRAME_GRAPH)}
+                "frame_graph_state": self.info(INFO_FRAME_GRAPH), "shim": bool(self.info(INFO_COLLECTIVES_ARE_A_SHIM))}
 
     def owns(self, frame: int) -> bool:
         return bool(self.L.ls_group_owns_frame(self.g, frame))

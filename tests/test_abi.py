@@ -33,7 +33,7 @@ def test_debug_header_symbols_are_exported(capi):
 
 
 def test_abi_version(capi):
-    assert capi.load().ls_abi_version() == 3
+    assert capi.load().ls_abi_version() == 4 == capi.ABI_VERSION
 
 
 def test_shipped_library_reads_no_tuning_knobs_from_the_environment():
@@ -41,8 +41,30 @@ def test_shipped_library_reads_no_tuning_knobs_from_the_environment():
     src = os.path.join(ROOT, "lidarshooter_amd", "csrc")
     for fn in os.listdir(src):
         if fn.endswith((".cpp", ".hip", ".h")) and fn != "ls_tuning.h":
-            assert "getenv" not in open(os.path.join(src, fn)).read(), fn
+            txt = open(os.path.join(src, fn)).read()
+            if fn == "ls_group.cpp":   # WHICH collective library to load is deployment, not tuning: the one variable the header documents
+                assert re.findall(r'getenv\("([A-Z_]+)"\)', txt) == ["LS_GROUP_RCCL_LIBRARY"] and txt.count("getenv") == 1
+                continue
+            assert "getenv" not in txt, fn
     assert "LS_EXPERIMENTAL" in open(os.path.join(src, "ls_tuning.h")).read()
+
+
+def test_library_was_built_from_these_sources(capi):
+    """ls_source_hash(): the binary says which sources it was made of (a stale .so must not speak for newer
+    sources -- the library is built in-tree and travels to the GPU box as a binary).  After build() the two agree; the marker
+    can be read out of the file without loading it (bench.py does that before it loads anything)."""
+    import hashlib
+    src = os.path.join(ROOT, "lidarshooter_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(src, fn), "rb").read())
+    want = h.hexdigest()[:16]
+    assert capi.load().ls_source_hash().decode() == want
+    blob = open(capi.LIB_PATH, "rb").read()
+    at = blob.index(b"LS_SOURCE_HASH=")
+    assert blob[at + 15:at + 31].decode() == want
 
 
 def test_struct_sizes(capi):

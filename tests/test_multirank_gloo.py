@@ -153,7 +153,8 @@ def test_bench_never_reports_fewer_gpus_than_asked_for():
 def test_bench_watchdog_ends_a_hung_phase_and_still_reports():
     """bench.py's N > 1 watchdog (the multi-rank RCCL path has never run on hardware): a phase that does not finish in time
     ends the process from a second thread; rank 0 prints the measurements that did finish as ONE line with an "error"
-    field (exit code 0), or nothing and exit code 3 when there is nothing to report; another rank prints nothing."""
+    field and exit code 4 -- a job whose watchdog fired has NOT succeeded, its line is there to be read -- or
+    nothing and exit code 3 when there is nothing to report; another rank prints nothing (and leaves with 4 as well)."""
     import json
     import subprocess
     import sys
@@ -163,7 +164,7 @@ def test_bench_watchdog_ends_a_hung_phase_and_still_reports():
     def run(rank, with_fallback):
         return subprocess.run([sys.executable, "-c", prog, str(rank), "1" if with_fallback else "0"], capture_output=True, text=True, timeout=120)
     out = run(0, True)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 4, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
@@ -173,13 +174,13 @@ def test_bench_watchdog_ends_a_hung_phase_and_still_reports():
     out = run(0, False)
     assert out.returncode == 3 and out.stdout.strip() == "" and "did not finish within" in out.stderr
     out = run(1, True)
-    assert out.returncode == 0 and out.stdout.strip() == ""   # only rank 0 reports
+    assert out.returncode == 4 and out.stdout.strip() == ""   # only rank 0 reports
     # a phase that raises on this rank ends the same way, at once
     prog3 = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(1, 0); "
              "d.arm('azimuth shards + all-gather', 600.0, {'value': 7.0, 'config': {'workload': 'w', 'parallelism': 'frames interleaved'}})\n"
              "try:\n    raise RuntimeError('no communicator')\nexcept Exception as e:\n    d.failed(e)\n") % ROOT
     out = subprocess.run([sys.executable, "-c", prog3], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 4, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
     assert rec["value"] == 7.0 and "raised on rank 0" in rec["error"] and "no communicator" in rec["error"]
     # a phase that finishes: disarm, nothing happens
