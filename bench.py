@@ -1149,8 +1149,9 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
 
     if cgroup:   # the whole frame's cloud as this rank holds it after the gather + rebuild (the group keeps three frames)
         import hashlib
-        gathered_cloud = grp.download(group_last_frame[0])[0]
-        points_sha = hashlib.sha256(gathered_cloud.tobytes()).hexdigest()
+        gathered_cloud, gathered_hits = grp.download(group_last_frame[0])
+        # (sector-major as gathered: rank 0's records, then rank 1's ...; hashed in ray order, the order of the one-GPU cloud)
+        points_sha = hashlib.sha256(np.ascontiguousarray(gathered_cloud[np.argsort(gathered_hits[:, 0], kind="stable")]).tobytes()).hexdigest()
     out = {
         "metric": {"syn128x1m": "Mrays/s (LiDAR frame = updateGeometry + commitScene + traceScene incl. point packing, 128ch x 4096az over 1M tris; "
                                 "geometry resident in HBM, every mesh's pose restated per frame; cloud left in HBM -- the frame with vertices "

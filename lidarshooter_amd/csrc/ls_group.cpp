@@ -269,29 +269,42 @@ ncclComm_t duplicate_by_id(ls_group *g, hipStream_t s)
     return ok ? dup : nullptr;
 }
 
+void drop_duplicates(ls_group *g);
+
 // The communicators of the buffer sets 1 .. kSets - 1.  Every rank issues the SAME collectives whatever happens to it
 // locally: HOW a duplicate is made -- ncclCommSplit with one colour, or a fresh id broadcast over the first
-// communicator -- is the group's choice, the AND of "my library has ncclCommSplit" gathered first, never a rank's; and a
-// rank whose duplicate i failed still attempts duplicate i + 1 with its peers.  (The old code chose per rank and per call: a
-// rank whose split failed locally went into a broadcast its peers were not in.)  A duplicate that failed HERE is nullptr
-// while the peers may hold their half of it: agree_on_arrangement's AND makes every rank drop all of them.
+// communicator -- is the group's choice, never a rank's, and a rank whose duplicate i failed still attempts duplicate i + 1
+// with its peers.  (The old code chose per rank and per call: a rank whose split failed locally went into a broadcast its
+// peers were not in.)  Stage 1, if every rank's library has ncclCommSplit: all splits, then the AND of "all of mine exist"
+// over the ranks; unless everybody holds everything, everybody drops what it holds and the group goes on to stage 2: all
+// duplicates by broadcast ids.  A duplicate that failed HERE in stage 2 is nullptr while the peers may hold their half of
+// it: agree_on_arrangement's AND (later, once the tracer's half of the arrangement is known) makes every rank drop all of them.
 // -> 1 every duplicate exists on this rank, 0 not, negative: the first communicator itself does not work.
 int make_duplicates(ls_group *g)
 {
     Rccl &R = rccl();
     const int by_split = gather_and(g, R.CommSplit ? 1u : 0u);
     if (by_split < 0) return by_split;
-    if (!(by_split & 1) && !R.Broadcast) return 0;   // (the library's: the same answer on every rank that loaded it)
+    if (by_split & 1) {
+        bool all = true;
+        for (int i = 0; i < kSets - 1; ++i) {
+            ncclComm_t dup = nullptr;
+            if (R.CommSplit(g->comm, 0, (int)g->rank, &dup, nullptr) != ncclSuccess) dup = nullptr;
+            g->comm_dup[i] = dup;
+            all = all && dup != nullptr;
+        }
+        const int everybody = gather_and(g, all ? 1u : 0u);
+        if (everybody < 0) return everybody;
+        if (everybody & 1) return 1;
+        drop_duplicates(g);
+    }
+    const int can_broadcast = gather_and(g, R.Broadcast ? 1u : 0u);
+    if (can_broadcast < 0) return can_broadcast;
+    if (!(can_broadcast & 1)) return 0;
     bool all = true;
     for (int i = 0; i < kSets - 1; ++i) {
-        ncclComm_t dup = nullptr;
-        if (by_split & 1) {
-            if (R.CommSplit(g->comm, 0, (int)g->rank, &dup, nullptr) != ncclSuccess) dup = nullptr;
-        } else {
-            dup = duplicate_by_id(g, g->comm_stream);
-        }
-        g->comm_dup[i] = dup;
-        all = all && dup != nullptr;
+        g->comm_dup[i] = duplicate_by_id(g, g->comm_stream);
+        all = all && g->comm_dup[i] != nullptr;
     }
     return all ? 1 : 0;
 }

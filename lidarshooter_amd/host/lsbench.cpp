@@ -16,6 +16,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -311,9 +312,17 @@ int run(int rank, int world, const std::string& id_path, int result_fd)
         std::string sha = "-";
         if (owns_last) {
             std::vector<uint8_t> pts(static_cast<size_t>(whole_rays) * 32);
-            n = ls_group_download_cloud(g, last, pts.data(), nullptr, whole_rays);
+            std::vector<ls_hit> hits(whole_rays);
+            n = ls_group_download_cloud(g, last, pts.data(), hits.data(), whole_rays);
             if (n < 0) { std::fprintf(stderr, "download: %s\n", ls_group_last_error(g)); return 2; }
-            sha = lidarshooter::sha256Hex(pts.data(), static_cast<size_t>(n) * 32);
+            // a sharded group's cloud is sector-major (rank 0's records, then rank 1's ...): hashed in ray order, the order of
+            // the one-GPU cloud and of the oracle's
+            std::vector<uint32_t> order(static_cast<size_t>(n));
+            for (long i = 0; i < n; ++i) order[static_cast<size_t>(i)] = static_cast<uint32_t>(i);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hits[a].ray < hits[b].ray; });
+            std::vector<uint8_t> sorted(static_cast<size_t>(n) * 32);
+            for (long i = 0; i < n; ++i) std::memcpy(&sorted[static_cast<size_t>(i) * 32], &pts[static_cast<size_t>(order[static_cast<size_t>(i)]) * 32], 32);
+            sha = lidarshooter::sha256Hex(sorted.data(), sorted.size());
         }
         char line[384];
         const int len = std::snprintf(line, sizeof(line), "%.9f %.9f %u %llu %ld %d %s %ld %ld %ld %ld %ld %ld\n", elapsed, enqueue_s, whole_rays,

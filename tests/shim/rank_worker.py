@@ -55,6 +55,7 @@ def with_raster(base, vertical, h_begin, h_end, h_count):
 
 
 def tracer_for(s):
+    same_cloud.H = s.H
     tr = capi.Tracer(s.vertical, s.h_begin, s.h_end, s.h_count, s.Rinv, s.t, device=0)
     tr.setOption(capi.LS_OPT_ENGINE, capi.ENGINE_PROJECTION)
     return tr
@@ -68,9 +69,39 @@ def group_facts(g, tr):
             "frame_graph_state": tr.info(capi.LS_INFO_FRAME_GRAPH_STATE), "pipeline_mode": tr.info(capi.LS_INFO_PIPELINE_MODE)}
 
 
-def same_cloud(got, ref):
+CHECKS = []   # every comparison of a downloaded cloud with the oracle's, for the parent's failure message
+
+
+def ray_order(got, H, world):
+    """The gathered cloud is SECTOR-major -- rank 0's records (every channel, its columns), then rank 1's, ... (lidarshooter_group.h);
+    the oracle's is in ray-index order (the reference's own order is a thread interleaving, SURVEY.md appendix: compare per ray).
+    -> the same cloud in ray order, after checking that it really is sector-major with ascending rays inside every sector."""
     pts, hits = got
-    return bool(np.array_equal(pts, ref["points"]) and np.array_equal(hits, ref["hits"]))
+    if hits.shape[0] == 0:
+        return pts, hits
+    col = (hits[:, 0] % np.uint32(H)).astype(np.int64)
+    sector = np.zeros_like(col)
+    for r in range(world):
+        first, n = groupapi.shard_columns(H, world, r)
+        sector[(col >= first) & (col < first + n)] = r
+    assert np.all(np.diff(sector) >= 0), "the gathered cloud is not sector-major"
+    ray = hits[:, 0].astype(np.int64)
+    assert np.all((np.diff(ray) > 0) | (np.diff(sector) > 0)), "rays are not ascending inside a sector"
+    order = np.argsort(hits[:, 0], kind="stable")
+    return pts[order], hits[order]
+
+
+def same_cloud(got, ref, what=""):
+    pts, hits = ray_order(got, same_cloud.H, same_cloud.world)
+    ok = bool(np.array_equal(pts, ref["points"]) and np.array_equal(hits, ref["hits"]))
+    rec = {"what": what, "points": int(pts.shape[0]), "oracle": int(ref["points"].shape[0]), "equal": ok}
+    if not ok and pts.shape[0] and ref["hits"].shape[0]:
+        got_rays, ref_rays = set(hits[:, 0].tolist()), set(ref["hits"][:, 0].tolist())
+        rec["rays_missing"] = sorted(ref_rays - got_rays)[:8]
+        rec["rays_extra"] = sorted(got_rays - ref_rays)[:8]
+        rec["n_missing_extra"] = [len(ref_rays - got_rays), len(got_rays - ref_rays)]
+    CHECKS.append(rec)
+    return ok
 
 
 def xt32(args, out):
@@ -96,7 +127,7 @@ def xt32(args, out):
         assert g.trace(f) == 0
         if f >= 2 and f % 2 == 0:
             for k in (f - 2, f - 1, f):
-                ok = ok and same_cloud(g.download(k), refs[k])
+                ok = same_cloud(g.download(k), refs[k], f"trace {k} at {f}") and ok
     # ... and through the C++ frame loop (host_capi.cpp: lsh_group_stream_frames), poses restated from a list
     HL = hostapi.load()
     f32p = C.POINTER(C.c_float)
@@ -109,11 +140,11 @@ def xt32(args, out):
     first = 14   # (a multiple of len(poses): frame f takes pose f mod 7)
     assert HL.lsh_group_stream_frames(g.g, tr.h, names, aff, n_aff, 2, first, 9) == 0, g.L.ls_group_last_error(g.g)
     for k in (first + 6, first + 7, first + 8):
-        ok = ok and same_cloud(g.download(k), refs[k % len(poses)])
+        ok = same_cloud(g.download(k), refs[k % len(poses)], f"stream {k}") and ok
     out["identity_points"] = int(g.download(first + 7)[0].shape[0])   # frame 21: pose 0
     out["clouds_equal_oracle"] = ok
     g.close()
-    rc, pts, _ = tr.traceScene(99)   # the tracer is the caller's again: the whole raster, on its own
+    rc, pts, _ = tr.traceScene(99)   # the tracer is the caller's again: the whole raster, on its own, in ray order
     out["after_close_equal_oracle"] = bool(rc == 0 and np.array_equal(pts, refs[(first + 8) % len(poses)]["points"]))
     tr.close()
 
@@ -130,9 +161,9 @@ def syn(args, out):
     out["group"] = group_facts(g, tr)
     for f in range(5):
         assert tr.commitScene() == 0 and g.trace(f) == 0
-    pts, hits = g.download(4)
+    pts, hits = ray_order(g.download(4), s.H, args.world)   # (checks the sector-major layout on the way)
     out["points"] = int(pts.shape[0])
-    out["points_sha256"] = hashlib.sha256(pts.tobytes()).hexdigest()
+    out["points_sha256"] = hashlib.sha256(np.ascontiguousarray(pts).tobytes()).hexdigest()
     out["rays_ascending"] = bool(np.all(np.diff(hits[:, 0].astype(np.int64)) > 0))
     g.close()
     tr.close()
@@ -245,6 +276,7 @@ def main():
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     out = {"rank": args.rank, "scenario": args.scenario, "flags": args.flags, "ok": False}
+    same_cloud.world = args.world
     try:
         O.build()
         {"xt32": xt32, "syn": syn, "sized": sized, "empty": empty}[args.scenario](args, out)
@@ -252,6 +284,7 @@ def main():
     except BaseException as e:   # the parent reads the file whatever happened
         out["error"] = repr(e)
         out["traceback"] = traceback.format_exc()
+    out["checks"] = CHECKS
     with open(args.out + ".tmp", "w") as f:
         json.dump(out, f)
     os.rename(args.out + ".tmp", args.out)

@@ -17,7 +17,8 @@
 //
 // Fault injection (the tests' "one rank only" cases):
 //   LS_SHIM_FAIL_SPLIT_RANK=<r>   ncclCommSplit on rank r takes part in the collective (its peers succeed) and then fails locally
-//   LS_SHIM_NO_SPLIT=1            ncclCommSplit fails on every rank at once (the loader's unique-id + broadcast path is taken)
+//   LS_SHIM_NO_SPLIT=1            ncclCommSplit fails on every rank at once (the group's unique-id + broadcast path is taken)
+//   LS_SHIM_FAIL_INIT_RANK=<r>    every ncclCommInitRank AFTER THE FIRST of the process fails on rank r, after the rendezvous
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -213,7 +214,15 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     *comm = nullptr;
     if (std::memcmp(id.internal, kMagic, 8) != 0) return ncclInvalidArgument;   // (an all-zero id from a rank 0 that could not make one)
     id.internal[sizeof(id.internal) - 1] = 0;
-    return attach(comm, std::string(id.internal + 8), nranks, rank);
+    static std::atomic<int> inits{0};
+    const ncclResult_t rc = attach(comm, std::string(id.internal + 8), nranks, rank);
+    const char *fail = std::getenv("LS_SHIM_FAIL_INIT_RANK");
+    if (rc == ncclSuccess && inits.fetch_add(1) > 0 && fail && std::atoi(fail) == rank) {   // the peers hold a communicator this rank walked away from
+        (void)ncclCommDestroy(*comm);
+        *comm = nullptr;
+        return ncclInternalError;
+    }
+    return rc;
 }
 
 ncclResult_t ncclCommDestroy(ncclComm_t c)

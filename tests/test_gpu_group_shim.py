@@ -66,13 +66,16 @@ def run_ranks(tmp_path, scenario, flags, world=2, timeout=420, **extra_env):
         res.append(json.load(open(o)))
     for v in res:
         assert v["ok"], f"rank {v['rank']}: {v.get('error')}\n{v.get('traceback')}\n{logs}"
+        bad = [c for c in v.get("checks", []) if not c["equal"]]
+        assert not bad, f"rank {v['rank']}: clouds that differ from the oracle's: {bad}"
     return res
 
 
-def assert_two_ranks_on_the_shim(res):
+def assert_two_ranks_on_the_shim(res, world=2):
+    assert len(res) == world
     for v in res:
         g = v["group"]
-        assert g["comm_ranks"] == 2 and g["shim"] == 1 and g["version"] == 1 and g["device"] == 0
+        assert g["comm_ranks"] == world and g["shim"] == 1 and g["version"] == 1 and g["device"] == 0
         assert g["pipeline_mode"] == 2           # the group keeps three frames in flight per rank
 
 
@@ -97,6 +100,18 @@ def test_two_ranks_xt32_clouds_equal_the_oracle(tmp_path, flags):
     assert res[0]["group"]["per_set"] == res[1]["group"]["per_set"]
 
 
+@pytest.mark.parametrize("world,flags", [(3, 2), (4, 1)])
+def test_three_and_four_ranks_ragged_shards(tmp_path, world, flags):
+    """more than one peer, and shards of unequal width: XT-32's 150 azimuth columns over 4 ranks are 38 + 38 + 37 + 37 (the slot
+    capacity is the widest shard's); three ranks in the per-set arrangement, four on one communicator (parent + 4 children: the
+    box allows six processes on the card)"""
+    res = run_ranks(tmp_path, "xt32", flags, world=world)
+    assert_two_ranks_on_the_shim(res, world)
+    for v in res:
+        assert v["clouds_equal_oracle"] and v["after_close_equal_oracle"] and v["identity_points"] == 1781
+    assert len({(v["group"]["common"], v["group"]["per_set"], v["group"]["communicators"]) for v in res}) == 1
+
+
 @pytest.mark.parametrize("flags", [1, 2])
 def test_two_ranks_headline_cloud(tmp_path, flags):
     """BASELINE.json configs[3] -- SYN-128 x SYN-1M, azimuth halves, one all-gather of 4 MiB slots per frame: both ranks end up with the
@@ -109,11 +124,24 @@ def test_two_ranks_headline_cloud(tmp_path, flags):
 
 
 def test_a_rank_whose_comm_split_fails(tmp_path):
-    """ncclCommSplit fails on rank 1 ONLY (after the collective part, so its peer's call succeeds).  Before round 6
-    rank 1 went on into a broadcast its peer was not in and the group hung in ls_group_create; now every rank attempts every
-    duplicate the same way, the agreement collective finds that not everybody holds them, BOTH ranks drop theirs and run the
-    one-communicator arrangement -- clouds still the oracle's."""
+    """ncclCommSplit fails on rank 1 ONLY (after the collective part, so its peer's calls succeed).  Before round 6
+    rank 1 went on alone into a broadcast its peer was not in and the group hung in ls_group_create.  Now every rank attempts every
+    split, the ranks find out together that not everybody holds everything, BOTH drop what they hold and make the duplicates from
+    broadcast ids instead, together: the group still has its communicator per buffer set, clouds the oracle's."""
     res = run_ranks(tmp_path, "xt32", 2, LS_SHIM_FAIL_SPLIT_RANK=1)
+    assert_two_ranks_on_the_shim(res)
+    for v in res:
+        g = v["group"]
+        assert g["mine"] & 1 == 1 and g["common"] & 1 == 1
+        assert g["per_set"] == (1 if g["common"] == 3 else 0) and g["communicators"] == (3 if g["per_set"] else 1)
+        assert v["clouds_equal_oracle"] and v["identity_points"] == 1781
+    assert res[0]["group"]["per_set"] == res[1]["group"]["per_set"]
+
+
+def test_a_rank_that_cannot_hold_any_duplicate(tmp_path):
+    """... and when the broadcast ids fail on rank 1 as well (its ncclCommInitRank, after the rendezvous): rank 0 holds both of its
+    duplicates, rank 1 none; the agreement collective (the AND over the ranks) makes BOTH run the one-communicator arrangement."""
+    res = run_ranks(tmp_path, "xt32", 2, LS_SHIM_FAIL_SPLIT_RANK=1, LS_SHIM_FAIL_INIT_RANK=1)
     assert_two_ranks_on_the_shim(res)
     assert res[0]["group"]["mine"] & 1 == 1 and res[1]["group"]["mine"] & 1 == 0
     for v in res:
@@ -145,7 +173,7 @@ def test_sized_gather_truncated_by_one_rank_is_reported_by_both(tmp_path):
     assert res[0]["group"]["per_set"] == res[1]["group"]["per_set"]
     for v in res:
         assert v["clouds_equal_oracle"], v
-        assert v["points_without_and_with_wall"][1] > v["points_without_and_with_wall"][0] + 20000
+        assert v["points_without_and_with_wall"][1] > v["points_without_and_with_wall"][0] + 10000
         full, small = v["capacity_full_then_sized"]
         assert full == 64 * 512
         if v["group"]["per_set"]:
