@@ -70,8 +70,12 @@ typedef struct ls_sensor_desc {
  * API only: LidarDevice::nextRay1 and originToSensor, LidarDevice.hpp:180,252).  Ray (v, h) has the
  * direction (sin_theta[v]*cos_phi[h], sin_theta[v]*sin_phi[h], cos_theta[v]) -- the products the
  * reference forms (LidarDevice.cpp:310-316); the kernels multiply exactly these entries.
- * elevation_deg / h_begin_deg / h_step_deg only feed conservative footprint bounds (0.005 degrees of
- * slack), so values good to 1e-4 degrees are enough. */
+ * The footprint bounds of the projection engine need the ANGLES too.  Elevations: the library derives every
+ * channel's from the tables themselves, atan2(cos_theta, sin_theta) in double (the bounds' elevation slack is
+ * 2e-4 degrees: no description could be trusted to that); elevation_deg is a cross-check -- tables whose
+ * elevation_deg is more than 0.01 degrees off that are refused (LS_ERR_INVALID_ARGUMENT), never traced wrongly.
+ * Azimuths: h_begin_deg + h * h_step_deg feeds bounds with 0.005 degrees + 1/16 column of slack and must be within
+ * 0.002 degrees of atan2(sin_phi, cos_phi) for every column, or the tables are refused as well. */
 typedef struct ls_sensor_tables {
     const float *sin_theta;     /* [n_vertical]                                              */
     const float *cos_theta;     /* [n_vertical]                                              */

@@ -678,7 +678,17 @@ private:
     /// which is what BadGeometryException (Exceptions.hpp:143-157) is for; anything else stays a TraceException
     [[noreturn]] void throwCommitError(int rc)
     {
-        if (rc == LS_ERR_OUT_OF_RANGE) throw BadGeometryException(__FILE__, ls_last_error(_handle), rc, RTC_GEOMETRY_TYPE_TRIANGLE);
+        if (rc == LS_ERR_OUT_OF_RANGE) {
+            // the refused geometry's own type (the library's message names it: "geometry '<name>': ...")
+            const std::string msg = ls_last_error(_handle);
+            RTCGeometryType type = RTC_GEOMETRY_TYPE_TRIANGLE;
+            const std::size_t a = msg.find('\''), b = a == std::string::npos ? a : msg.find('\'', a + 1);
+            if (b != std::string::npos) {
+                const auto it = _meshes.find(msg.substr(a + 1, b - a - 1));
+                if (it != _meshes.end() && it->second.verticesPerElement == 4) type = RTC_GEOMETRY_TYPE_QUAD;
+            }
+            throw BadGeometryException(__FILE__, msg, rc, type);
+        }
         throw TraceException(__FILE__, ls_last_error(_handle), rc);
     }
 

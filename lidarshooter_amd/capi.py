@@ -207,6 +207,42 @@ class Tracer:
             raise LidarShooterHipError(f"ls_tracer_create failed with status {rc} (no HIP device / bad sensor)")
         self.h = h
 
+    @classmethod
+    def fromTables(cls, sin_theta, cos_theta, elevation_deg, sin_phi, cos_phi, h_begin_deg, h_step_deg, Rinv, t, device: int = 0):
+        """ls_tracer_create_tables: the sensor as ray-direction factor tables (what integration/HipTracer.hpp probes out of a live
+        LidarDevice); raises when the library refuses them (elevation_deg / h_begin_deg / h_step_deg off their own tables)"""
+        self = cls.__new__(cls)
+        self.L = load()
+        self._tabs = [np.ascontiguousarray(a, np.float32) for a in (sin_theta, cos_theta, elevation_deg, sin_phi, cos_phi)]
+        st = SensorTables()
+        st.sin_theta, st.cos_theta, st.elevation_deg, st.sin_phi, st.cos_phi = [_f32p(a) for a in self._tabs]
+        st.n_vertical, st.h_count = self._tabs[0].shape[0], self._tabs[3].shape[0]
+        st.h_begin_deg, st.h_step_deg = float(h_begin_deg), float(h_step_deg)
+        st.Rinv = (C.c_float * 9)(*[float(x) for x in np.asarray(Rinv, np.float32).reshape(9)])
+        st.t = (C.c_float * 3)(*[float(x) for x in np.asarray(t, np.float32).reshape(3)])
+        self.V, self.H = int(st.n_vertical), int(st.h_count)
+        self.az0, self.naz = 0, self.H
+        h = C.c_void_p()
+        rc = self.L.ls_tracer_create_tables(C.byref(st), device, C.byref(h))
+        if rc != 0:
+            raise LidarShooterHipError(f"ls_tracer_create_tables failed with status {rc} (no HIP device / tables refused)")
+        self.h = h
+        return self
+
+    def setSensorTables(self, sin_theta, cos_theta, elevation_deg, sin_phi, cos_phi, h_begin_deg, h_step_deg, Rinv, t):
+        """ls_tracer_set_sensor_tables: another sensor, given as factor tables, for this handle (its geometries stay)"""
+        tabs = [np.ascontiguousarray(a, np.float32) for a in (sin_theta, cos_theta, elevation_deg, sin_phi, cos_phi)]
+        st = SensorTables()
+        st.sin_theta, st.cos_theta, st.elevation_deg, st.sin_phi, st.cos_phi = [_f32p(a) for a in tabs]
+        st.n_vertical, st.h_count = tabs[0].shape[0], tabs[3].shape[0]
+        st.h_begin_deg, st.h_step_deg = float(h_begin_deg), float(h_step_deg)
+        st.Rinv = (C.c_float * 9)(*[float(x) for x in np.asarray(Rinv, np.float32).reshape(9)])
+        st.t = (C.c_float * 3)(*[float(x) for x in np.asarray(t, np.float32).reshape(3)])
+        self._check(self.L.ls_tracer_set_sensor_tables(self.h, C.byref(st)), "ls_tracer_set_sensor_tables")
+        self._tabs = tabs
+        self.V, self.H = int(st.n_vertical), int(st.h_count)
+        self.az0, self.naz = 0, self.H
+
     def setSensor(self, vertical_deg, h_begin, h_end, h_count, Rinv, t):
         """ITracer::setSensorConfig: another sensor for this handle, its geometries stay (ls_tracer_set_sensor)"""
         self._vert = np.ascontiguousarray(vertical_deg, np.float32)

@@ -151,7 +151,9 @@ static void take_sensor_desc(ls_tracer *tr, const ls_sensor_desc *sd)
 static void take_sensor_tables(ls_tracer *tr, const ls_sensor_tables *st)
 {
     const uint32_t V = tr->V = st->n_vertical, H = tr->H = st->h_count;
-    tr->vertical.assign(st->elevation_deg, st->elevation_deg + V);
+    // (the elevations the tables stand for -- check_tables -- not the caller's description of them; float keeps them to 4e-6 degrees)
+    tr->vertical.resize(V);
+    for (uint32_t v = 0; v < V; ++v) tr->vertical[v] = static_cast<float>(std::atan2((double)st->cos_theta[v], (double)st->sin_theta[v]) * 180.0 / M_PI);
     tr->h_begin = st->h_begin_deg;
     tr->h_step = st->h_step_deg;
     tr->h_end = st->h_begin_deg + st->h_step_deg * static_cast<float>(H - 1u);
@@ -164,9 +166,34 @@ static void take_sensor_tables(ls_tracer *tr, const ls_sensor_tables *st)
     std::memcpy(tr->t, st->t, sizeof(tr->t));
 }
 
-static bool valid_tables(const ls_sensor_tables *st)
+// The angles the caller's factor tables really stand for, in double: a channel's elevation above the horizon is
+// atan2(cos theta, sin theta), a column's azimuth atan2(sin phi, cos phi).  The footprint bounds of the projection engine are
+// built from THESE (with the elevation slack at 2e-4 degrees an elevation_deg that is off by more than that
+// would silently drop hits at ring boundaries -- a wrong cloud with no error); what the caller says in elevation_deg /
+// h_begin_deg / h_step_deg is a cross-check, and a description that is grossly off its own tables is refused.
+constexpr double kGivenElevationToleranceDeg = 0.01;   // caller's elevation_deg against the derived one
+constexpr double kGivenAzimuthToleranceDeg = 0.002;    // h_begin_deg + h * h_step_deg against the derived azimuth (the bounds carry 0.005 degrees + 1/16 column)
+
+static const char *check_tables(const ls_sensor_tables *st)
 {
-    return st && st->sin_theta && st->cos_theta && st->elevation_deg && st->sin_phi && st->cos_phi && st->n_vertical != 0 && st->h_count >= 2;
+    if (!(st && st->sin_theta && st->cos_theta && st->elevation_deg && st->sin_phi && st->cos_phi && st->n_vertical != 0 && st->h_count >= 2))
+        return "incomplete sensor tables";
+    for (uint32_t v = 0; v < st->n_vertical; ++v) {
+        const double s = st->sin_theta[v], c = st->cos_theta[v];
+        if (!std::isfinite(s) || !std::isfinite(c) || std::fabs(std::hypot(s, c) - 1.0) > 1e-3) return "sin_theta / cos_theta are not the sine and cosine of one angle";
+        const double derived = std::atan2(c, s) * 180.0 / M_PI;
+        if (!(std::fabs(derived - (double)st->elevation_deg[v]) <= kGivenElevationToleranceDeg))
+            return "elevation_deg does not describe sin_theta / cos_theta (more than 0.01 degrees off atan2(cos_theta, sin_theta))";
+    }
+    for (uint32_t h = 0; h < st->h_count; ++h) {
+        const double s = st->sin_phi[h], c = st->cos_phi[h];
+        if (!std::isfinite(s) || !std::isfinite(c) || std::fabs(std::hypot(s, c) - 1.0) > 1e-3) return "sin_phi / cos_phi are not the sine and cosine of one angle";
+        const double said = (double)st->h_begin_deg + (double)st->h_step_deg * (double)h;
+        if (!std::isfinite(said)) return "h_begin_deg / h_step_deg are not finite";
+        const double off = std::remainder(std::atan2(s, c) * 180.0 / M_PI - said, 360.0);
+        if (!(std::fabs(off) <= kGivenAzimuthToleranceDeg)) return "h_begin_deg / h_step_deg do not describe sin_phi / cos_phi (more than 0.002 degrees off)";
+    }
+    return nullptr;
 }
 
 // A handle takes another sensor -- raster, channel tables, pose -- and keeps its geometries (ITracer::setSensorConfig,
@@ -311,7 +338,7 @@ int ls_tracer_set_sensor(ls_tracer *tr, const ls_sensor_desc *sd)
 int ls_tracer_set_sensor_tables(ls_tracer *tr, const ls_sensor_tables *st)
 {
     LS_ENTER(tr);
-    if (!valid_tables(st)) return fail(tr, LS_ERR_INVALID_ARGUMENT, "incomplete sensor tables");
+    if (const char *why = check_tables(st)) return fail(tr, LS_ERR_INVALID_ARGUMENT, why);
     if ((unsigned long long)st->n_vertical * st->h_count > 0x7FFFFFFFull) return fail(tr, LS_ERR_OUT_OF_RANGE, "ray indices are 32-bit");
     if (tr->fg_open) return fail(tr, LS_ERR_INVALID_ARGUMENT, "a frame graph is open");
     // (another sensor puts the handle back on the full turn: whoever installed output buffers sized them for the old raster,
@@ -329,7 +356,7 @@ int ls_tracer_create_tables(const ls_sensor_tables *st, int hip_device, ls_trace
 {
     if (!out) return LS_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (!valid_tables(st)) return LS_ERR_INVALID_ARGUMENT;
+    if (check_tables(st)) return LS_ERR_INVALID_ARGUMENT;
     if ((unsigned long long)st->n_vertical * st->h_count > 0x7FFFFFFFull) return LS_ERR_OUT_OF_RANGE;
     ls_tracer *tr = new ls_tracer();
     take_sensor_tables(tr, st);

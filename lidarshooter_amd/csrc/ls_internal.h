@@ -217,6 +217,7 @@ struct ls_tracer {
     int opt_emit_points = 1;     // LS_OPT_EMIT_POINTS
     int opt_debug_fault = 0;     // LS_OPT_DEBUG_FAULT (one frame)
     uint32_t *h_status = nullptr;   // sticky device status word in pinned host memory (bit 0: chained prefix gave up)
+    uint32_t cull_hint_in_use = 0;  // the survivor hint the culled grid is sized from (h_status[1] with hysteresis: trace_once)
     // ls_trace_scene_begin / ls_trace_scene_expand: the device tells the host how far the frame is (ls::HostProgress)
     ls::HostProgress *h_progress = nullptr;   // pinned host memory
     uint32_t progress_epoch = 0;

@@ -20,14 +20,33 @@
 
 namespace ls {
 
+constexpr uint32_t kMaxLaunchArgs = 20;   // arg_off holds n_args + 1 offsets: a kernel takes at most kMaxLaunchArgs - 1 arguments
+
 struct LaunchRecord {
     const void *func = nullptr;
     dim3 grid, block;
     uint32_t shmem = 0;
     uint32_t n_args = 0;
-    uint32_t arg_off[20] = {};        // byte offset of argument i in blob; arg_off[n_args] = blob size
+    uint32_t arg_off[kMaxLaunchArgs] = {};   // byte offset of argument i in blob; arg_off[n_args] = blob size
     std::vector<uint8_t> blob;
 };
+
+// two records describe the same launch: same grid, block, LDS bytes and argument bytes (padding between arguments included: it
+// is zero-filled by pack_args, so two packings of the same values compare equal).  The function is compared by the caller.
+inline bool same_launch(const LaunchRecord &a, const LaunchRecord &b)
+{
+    return a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.grid.z == b.grid.z && a.block.x == b.block.x && a.block.y == b.block.y &&
+           a.block.z == b.block.z && a.shmem == b.shmem && a.n_args == b.n_args && a.blob.size() == b.blob.size() &&
+           std::memcmp(a.arg_off, b.arg_off, sizeof(uint32_t) * (a.n_args + 1)) == 0 &&
+           (a.blob.empty() || std::memcmp(a.blob.data(), b.blob.data(), a.blob.size()) == 0);
+}
+
+// hipKernelNodeParams::kernelParams for a record: one pointer per argument, into the record's own blob (valid until the
+// record is packed again or destroyed -- hipGraphExecKernelNodeSetParams copies the values out before it returns)
+inline void argument_pointers(LaunchRecord &r, void *argv[kMaxLaunchArgs])
+{
+    for (uint32_t a = 0; a < r.n_args; ++a) argv[a] = r.blob.data() + r.arg_off[a];
+}
 
 struct LaunchSink {
     enum Mode { kOff = 0, kCapture = 1, kDescribe = 2 };
@@ -51,9 +70,9 @@ template <typename A, typename... Rest>
 inline void pack_args(LaunchRecord &r, const A &a, const Rest &...rest)
 {
     static_assert(std::is_trivially_copyable<A>::value, "kernel arguments are plain data");
-    const size_t align = alignof(A) > 16 ? 16 : alignof(A);
+    const size_t align = alignof(A) > 16 ? 16 : alignof(A);   // (offsets only order the arguments inside the blob: nothing reads them at their natural alignment)
     size_t at = (r.blob.size() + align - 1) / align * align;
-    r.blob.resize(at + sizeof(A));
+    r.blob.resize(at + sizeof(A));   // (value-initialises the padding: zero)
     std::memcpy(r.blob.data() + at, &a, sizeof(A));
     r.arg_off[r.n_args++] = (uint32_t)at;
     pack_args(r, rest...);
@@ -64,7 +83,7 @@ template <typename... KArgs, typename... Args>
 inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, uint32_t shmem, hipStream_t s, Args &&...args)
 {
     static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
-    static_assert(sizeof...(KArgs) < 20, "LaunchRecord::arg_off");
+    static_assert(sizeof...(KArgs) < kMaxLaunchArgs, "LaunchRecord::arg_off holds one offset more than there are arguments");
     LaunchSink *sink = thread_sink();
     if (!sink || sink->mode == LaunchSink::kOff || sink->stream != s) {
         hipLaunchKernelGGL(kernel, grid, block, shmem, s, static_cast<KArgs>(args)...);

@@ -451,14 +451,6 @@ int kernel_nodes_in_order(ls_tracer *tr, hipGraph_t graph, std::vector<hipGraphN
     return LS_OK;
 }
 
-bool same_launch(const ls::LaunchRecord &a, const ls::LaunchRecord &b)
-{
-    return a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.grid.z == b.grid.z && a.block.x == b.block.x && a.block.y == b.block.y &&
-           a.block.z == b.block.z && a.shmem == b.shmem && a.n_args == b.n_args && a.blob.size() == b.blob.size() &&
-           std::memcmp(a.arg_off, b.arg_off, sizeof(uint32_t) * (a.n_args + 1)) == 0 &&
-           (a.blob.empty() || std::memcmp(a.blob.data(), b.blob.data(), a.blob.size()) == 0);
-}
-
 // the frame graph is given up for this frame (and, when `broken`, for good): nothing was launched, the rotation steps back
 int frame_graph_discard(ls_tracer *tr, FrameGraph &fg, bool broken)
 {
@@ -521,7 +513,7 @@ int frame_graph_close(ls_tracer *tr)
         bool idle = false;
         for (size_t i = 0; i < sk.n; ++i) {
             ls::LaunchRecord &now = sk.recs[i];
-            if (same_launch(now, fg.recs[i])) continue;
+            if (ls::same_launch(now, fg.recs[i])) continue;
             // A node's arguments are about to change while this exec's previous launch -- three frames back on this very
             // stream -- may still be queued or running: nothing bounds how far the host runs ahead of the device, and whether
             // a launched graph keeps a snapshot of its kernel arguments or reads the exec's (ROCm keeps a graph's kernel
@@ -531,14 +523,19 @@ int frame_graph_close(ls_tracer *tr)
             if (!idle) {
                 if (hipStreamQuery(s) != hipSuccess) {
                     (void)hipGetLastError();
-                    LS_HIP(hipStreamSynchronize(s));
+                    const hipError_t e = hipStreamSynchronize(s);
+                    if (e != hipSuccess) {   // (nothing of this frame was launched: the rotation steps back like on any other discard)
+                        (void)frame_graph_discard(tr, fg, true);
+                        tr->err = std::string("frame graph: waiting for the graph's previous launch: ") + hipGetErrorString(e);
+                        return LS_ERR_HIP;
+                    }
                     ++tr->fg_patch_waits;
                 }
                 idle = true;
             }
             tr->fg_last_patched |= 1u << (i < 31 ? i : 31);
-            void *argv[20];
-            for (uint32_t a = 0; a < now.n_args; ++a) argv[a] = now.blob.data() + now.arg_off[a];
+            void *argv[ls::kMaxLaunchArgs];
+            ls::argument_pointers(now, argv);
             hipKernelNodeParams p;
             std::memset(&p, 0, sizeof(p));
             p.func = const_cast<void *>(now.func);
@@ -733,7 +730,17 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
         // or three of waves walking their segment in rounds, never a wrong cloud.  The geometry set it speaks for is the
         // handle's: a new layout forgets it.
         uint32_t *hint_word = tr->h_status + 1;
-        const uint32_t survivors_hint = any_culled ? __atomic_load_n(hint_word, __ATOMIC_RELAXED) : 0u;
+        // With hysteresis: under a pose that changes every frame the raw number wanders, every change of it that
+        // crosses a quantum of the grid is a changed node parameter of a captured frame graph, and a patch may have to wait for
+        // the graph's previous launch.  The number in use grows at once (with an eighth on top, so that a scene that keeps growing
+        // does not patch every frame) and shrinks only when the fresh one has fallen below half of it.
+        uint32_t survivors_hint = 0u;
+        if (any_culled) {
+            const uint32_t fresh = __atomic_load_n(hint_word, __ATOMIC_RELAXED);
+            if (fresh && (fresh > tr->cull_hint_in_use || fresh < tr->cull_hint_in_use / 2u)) tr->cull_hint_in_use = fresh + fresh / 8u;
+            if (!fresh) tr->cull_hint_in_use = 0u;   // (a new layout forgot it)
+            survivors_hint = tr->cull_hint_in_use;
+        }
         if (pipelined) {
             // one launch: this frame's k_project workgroups + the previous frame's finish + pack workgroups
             ls::launch_project(s, pp, srcs.data(), (uint32_t)srcs.size(), keys, bigq, tr->big_capacity, big_count, nullptr,

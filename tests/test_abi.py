@@ -161,3 +161,35 @@ def test_host_rebuild_of_points_from_ray_and_t(capi, oracle, sensors):
             got = buf[off:off + rays.size * 32].view(np.uint32).reshape(-1, 8)
             assert np.array_equal(got, want.view(np.uint32)), (n, shift)
     assert L.ls_debug_expand_hits(None, None, 0, None, None, None, V, H) == 0
+
+
+def test_given_sensor_tables_are_checked_before_anything_touches_a_device(capi, oracle, sensors):
+    """ls_tracer_create_tables without a GPU: tables whose own description is grossly off them are refused (LS_ERR_INVALID_ARGUMENT,
+    -2) BEFORE the device is looked for; consistent ones get as far as "no device" (-7) here.  ADVICE round 5: elevation_deg used to
+    feed the footprint bounds unchecked."""
+    import numpy as np
+    L = capi.load()
+    s = sensors["0001"]
+    st, ct, sp, cp = oracle.ray_tables(s)
+
+    def create(elev, begin, step, sin_theta=st):
+        tabs = [np.ascontiguousarray(a, np.float32) for a in (sin_theta, ct, elev, sp, cp)]
+        t = capi.SensorTables()
+        t.sin_theta, t.cos_theta, t.elevation_deg, t.sin_phi, t.cos_phi = [a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) for a in tabs]
+        t.n_vertical, t.h_count = s.V, s.H
+        t.h_begin_deg, t.h_step_deg = float(begin), float(step)
+        t.Rinv = (ctypes.c_float * 9)(*[float(x) for x in s.Rinv])
+        t.t = (ctypes.c_float * 3)(*[float(x) for x in s.t])
+        h = ctypes.c_void_p()
+        rc = L.ls_tracer_create_tables(ctypes.byref(t), 0, ctypes.byref(h))
+        if rc == 0:
+            L.ls_tracer_destroy(h)
+        return rc
+    ok = create(s.vertical, s.h_begin, s.step())
+    assert ok in (0, -7)                                                          # accepted (0 on a GPU box, "no device" here)
+    assert create(s.vertical + np.float32(0.004), s.h_begin, s.step()) == ok      # a loose description is fine: the library derives its own
+    assert create(s.vertical + np.float32(0.02), s.h_begin, s.step()) == -2
+    assert create(s.vertical, s.h_begin, s.step() * np.float32(1.01)) == -2
+    assert create(s.vertical, s.h_begin + np.float32(0.01), s.step()) == -2
+    assert create(s.vertical, s.h_begin, s.step(), sin_theta=st * np.float32(1.01)) == -2   # not a sine and a cosine of one angle
+    assert create(s.vertical, s.h_begin + np.float32(360.0), s.step()) == ok      # azimuths compare modulo a turn

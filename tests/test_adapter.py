@@ -177,8 +177,16 @@ def test_adapter_refuses_a_mesh_with_a_wild_index(adapterapi, oracle, sensors, m
     tr.updateGeometry("mesh")
     assert tr.commitScene() == -200
     assert "BadGeometry" in tr.L.lsa_last_error().decode() and "vertex index %d" % (gv.shape[0] + 100) in tr.L.lsa_last_error().decode()
+    assert "(type 0)" in tr.L.lsa_last_error().decode()          # RTC_GEOMETRY_TYPE_TRIANGLE: the refused geometry's own type
     assert tr.commitScene() == -200                              # it stays refused
     assert tr.removeGeometry("mesh") == 0
+    # ... a QUAD geometry with a wild index is reported as a quad geometry (EmbreeTracer.cpp:179-198 accepts RTC_GEOMETRY_TYPE_QUAD)
+    qv = np.array([(-30, -30, 0), (30, -30, 0), (30, 30, 0), (-30, 30, 0)], np.float32)
+    tr.meshFromArrays("plate", qv, np.array([(0, 1, 2, 9)], np.uint32), point_step=16)
+    tr.addGeometry("plate", geometry_type=1)
+    tr.updateGeometry("plate")
+    assert tr.commitScene() == -200 and "(type 1)" in tr.L.lsa_last_error().decode() and "'plate'" in tr.L.lsa_last_error().decode()
+    assert tr.removeGeometry("plate") == 0
     tr.meshFromArrays("mesh", gv, gt, point_step=16)
     tr.addGeometry("mesh")
     tr.updateGeometry("mesh")
@@ -359,3 +367,26 @@ def test_adapter_follows_the_sensor(adapterapi, oracle, sensors, meshes, tmp_pat
     c = frame(5)
     assert tr.sensorProbeCount() == 5 and np.array_equal(_points(c), want)
     tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_grazing_corners_through_probed_tables(adapterapi, oracle, tmp_path):
+    """the adapter hands the library factor tables it PROBED out of a live LidarDevice (nextRay1 walks), with an
+    elevation estimate good to 1e-4 degrees -- half the elevation slack of the footprint bounds.  The library now derives the
+    elevations from the tables itself; triangles whose corner lies ON a ray of the raster (conftest.grazing_mesh), rings on and
+    around the horizon included, come out as the oracle's cloud through ITracer::Ptr."""
+    from conftest import grazing_mesh
+    from lidarshooter_amd import synth
+    for name, vertical in (("syn", synth.syn_vertical(128)), ("horizon", np.linspace(-0.5, 0.5, 65, dtype=np.float32))):
+        path = synth.write_sensor_json(CFG["0000"], str(tmp_path / f"{name}.json"), vertical, 0.0, 360.0, 1024)
+        s = oracle.load_sensor(path)
+        verts, idx = grazing_mesh(oracle, s)
+        tr = adapterapi.AdapterTracer(path)
+        tr.meshFromArrays("graze", verts, idx, point_step=16)
+        assert tr.addGeometry("graze") == 0
+        for k, A in enumerate((oracle.IDENTITY_AFFINE, oracle.affine_from_components(np.array((0.3, -0.2, 0.05), np.float32), np.array((0.0, 0.0, 0.7), np.float32)))):
+            assert tr.updateGeometry("graze", A) == 0 and tr.commitScene() == 0 and tr.traceScene(k) == 0
+            ref = oracle.trace_frame(s, [(0, verts, idx, A)])
+            assert ref["points"].shape[0] > 300
+            assert np.array_equal(_points(tr.cloud()), ref["points"])
+        tr.close()

@@ -164,7 +164,7 @@ def test_duplicates_by_a_broadcast_id_when_the_library_cannot_split(tmp_path):
 
 def test_sized_gather_truncated_by_one_rank_is_reported_by_both(tmp_path):
     """LS_GROUP_FLAG_SIZED_GATHER: the gather shrinks to what the scene needs; then a wall that only rank 1's half of the turn sees
-    makes rank 1's hits outgrow it.  BOTH ranks report that frame as truncated (LS_ERR_OUT_OF_RANGE = -10 from ls_group_frame_status
+    makes rank 1's hits outgrow it.  BOTH ranks report that frame as truncated (LS_ERR_OUT_OF_RANGE = -9 from ls_group_frame_status
     and from the download) and neither delivers it; a few frames later the gather has grown back and both hold the oracle's cloud
     with the wall.  (Per-set mode is a precondition of the flag: where the two ranks did not both find three concurrent streams the
     fixed-capacity gather runs and nothing is ever truncated -- asserted as that.)"""

@@ -1310,34 +1310,20 @@ def test_triangles_whose_corner_lies_on_a_ray(oracle, capi, sensors, engine):
         _corner_on_ray_case(oracle, capi, engine, base, V, H, np.asarray(vertical, np.float32))
 
 
-def _corner_on_ray_case(oracle, capi, engine, base, V, H, vertical):
-    if True:
-        s = oracle.Sensor(uid="graze", vertical=vertical, h_begin=np.float32(0.0), h_end=np.float32(360.0), h_count=H,
-                          R=base.R, Rinv=base.Rinv, t=base.t)
-    dirs = oracle.ray_dirs(s).astype(np.float64)
-    R = s.R.reshape(3, 3).astype(np.float64)
-    rng = np.random.default_rng(77)
-    tris_sensor = []
-    for k in range(640):
-        v, h = k % V, int(rng.integers(1, H - 2))
-        d = dirs[v * H + h]
-        r = float(rng.uniform(4.0, 70.0))
-        apex = (np.float32(r) * d.astype(np.float32)).astype(np.float64)        # on the ray, as the kernels form t * direction
-        side = np.cross(d, [0.0, 0.0, 1.0]); side /= np.linalg.norm(side)
-        down = np.cross(side, d); down /= np.linalg.norm(down)                   # towards lower elevation, across the ray
-        if down[2] > 0: down = -down
-        w = r * float(rng.uniform(2e-4, 2e-2))
-        sign = 1.0 if k % 3 else -1.0                                            # the corner on the ray is the highest / the lowest
-        if k % 5 == 4:   # a sliver between this column's ray and the next one's, both corners on rays of the same ring
-            other = (np.float32(r * float(rng.uniform(0.98, 1.02))) * dirs[v * H + h + 1].astype(np.float32)).astype(np.float64)
-            third = 0.5 * (apex + other) + sign * down * w
-            tris_sensor.append([apex, other, third])
-        else:
-            tris_sensor.append([apex, apex + sign * down * w + side * w * float(rng.uniform(0.2, 1.0)), apex + sign * down * w - side * w * float(rng.uniform(0.2, 1.0))])
-    tri = np.array(tris_sensor, np.float64).reshape(-1, 3)
-    verts = (tri @ R.T + s.t.astype(np.float64)).astype(np.float32)              # v_world = R v_sensor + t
-    idx = np.arange(verts.shape[0], dtype=np.uint32).reshape(-1, 3)
-    tr = make_tracer(capi, s, engine)
+def _corner_on_ray_case(oracle, capi, engine, base, V, H, vertical, through_tables=False):
+    from conftest import grazing_mesh
+    s = oracle.Sensor(uid="graze", vertical=vertical, h_begin=np.float32(0.0), h_end=np.float32(360.0), h_count=H,
+                      R=base.R, Rinv=base.Rinv, t=base.t)
+    verts, idx = grazing_mesh(oracle, s)
+    if through_tables:
+        # ls_tracer_create_tables with a SLOPPY elevation_deg: 0.004 degrees off, twenty times the elevation slack of the footprint
+        # bounds.  The library derives the elevations from sin_theta / cos_theta itself, so nothing is lost.
+        st, ct, sp, cp = oracle.ray_tables(s)
+        sloppy = (vertical.astype(np.float64) + 0.004 * np.where(np.arange(V) % 2, 1.0, -1.0)).astype(np.float32)
+        tr = capi.Tracer.fromTables(st, ct, sloppy, sp, cp, s.h_begin, s.step(), s.Rinv, s.t)
+        tr.setOption(capi.LS_OPT_ENGINE, {"bvh": 1, "projection": 2}[engine])
+    else:
+        tr = make_tracer(capi, s, engine)
     assert tr.addGeometry("graze", verts.shape[0], idx.shape[0]) == 0
     for A in (oracle.IDENTITY_AFFINE, oracle.affine_from_components(np.array((0.3, -0.2, 0.05), np.float32), np.array((0.0, 0.0, 0.7), np.float32))):
         tr.updateGeometry("graze", A, verts, idx)
@@ -1346,6 +1332,30 @@ def _corner_on_ray_case(oracle, capi, engine, base, V, H, vertical):
         assert rc == 0
         ref = _assert_parity(oracle, s, tr, [(0, verts, idx, A)], pts, hits)
         assert ref["points"].shape[0] > 300
+    tr.close()
+
+
+def test_triangles_whose_corner_lies_on_a_ray_through_given_tables(oracle, capi, sensors, engine):
+    """The same grazing triangles through ls_tracer_create_tables -- the path the ROS-typed adapter takes -- with an elevation_deg
+    that is 0.004 degrees off: since round 6 the library takes each channel's elevation from atan2(cos_theta, sin_theta) (the
+    tables the kernels multiply), so a description that loose costs nothing; tables whose description is GROSSLY off (0.02 degrees,
+    or an azimuth step that does not fit sin_phi / cos_phi) are refused instead of traced wrongly."""
+    base = sensors["0000"]
+    from lidarshooter_amd import synth
+    for V, H, vertical in ((128, 1024, synth.syn_vertical(128)), (65, 1024, np.linspace(-0.5, 0.5, 65, dtype=np.float32))):
+        _corner_on_ray_case(oracle, capi, engine, base, V, H, np.asarray(vertical, np.float32), through_tables=True)
+    s = oracle.Sensor(uid="graze", vertical=synth.syn_vertical(16), h_begin=np.float32(0.0), h_end=np.float32(360.0), h_count=64,
+                      R=base.R, Rinv=base.Rinv, t=base.t)
+    st, ct, sp, cp = oracle.ray_tables(s)
+    off = s.vertical.copy()
+    off[5] += np.float32(0.02)
+    with pytest.raises(capi.LidarShooterHipError):
+        capi.Tracer.fromTables(st, ct, off, sp, cp, s.h_begin, s.step(), s.Rinv, s.t)
+    with pytest.raises(capi.LidarShooterHipError):
+        capi.Tracer.fromTables(st, ct, s.vertical, sp, cp, s.h_begin, np.float32(s.step() * 1.01), s.Rinv, s.t)
+    tr = capi.Tracer.fromTables(st, ct, s.vertical, sp, cp, s.h_begin, s.step(), s.Rinv, s.t)
+    with pytest.raises(capi.LidarShooterHipError, match="elevation_deg"):        # ... and by ls_tracer_set_sensor_tables, with the reason
+        tr.setSensorTables(st, ct, off, sp, cp, s.h_begin, s.step(), s.Rinv, s.t)
     tr.close()
 
 

@@ -1,7 +1,7 @@
 """The host-side code that needs no GPU under ThreadSanitizer and AddressSanitizer + UBSan (tests/san/: the hand-rolled worker
 pool with two callers at once, the host mirror's JSON / STL / trajectory parsers over the shipped files and over truncations
 and mutations of them, the oracle's threaded tracers).  CPU build only: GPU sanitizers do not exist on this pool.  The logs of
-a run are kept under profiles/r05_san_*.log (make -C tests/san logs).  Reference: the reference has no sanitizer set-up at all
+a run are kept under profiles/r06_san_*.log (make -C tests/san logs).  Reference: the reference has no sanitizer set-up at all
 (SURVEY.md section 5); the threading it has to survive is mainwindow.cpp:150-154,315-323 against :335-339."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ SAN = os.path.join(ROOT, "tests", "san")
 def test_host_code_is_clean_under_sanitizers():
     r = subprocess.run(["make", "-C", SAN, "run"], capture_output=True, text=True, timeout=900)
     logs = {}
-    for name in ("host_pool_tsan", "host_pool_asan", "host_parsers_asan", "oracle_asan", "oracle_tsan"):
+    for name in ("host_pool_tsan", "host_pool_asan", "host_parsers_asan", "oracle_asan", "oracle_tsan", "launch_record_asan"):
         p = os.path.join(SAN, "build", name + ".log")
         logs[name] = open(p).read() if os.path.exists(p) else ""
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:] + "".join("\n== %s\n%s" % (k, v[-1500:]) for k, v in logs.items())
@@ -23,3 +23,5 @@ def test_host_code_is_clean_under_sanitizers():
     assert "failures: 0" in logs["host_pool_tsan"] and "failures: 0" in logs["host_pool_asan"]
     assert logs["host_parsers_asan"].rstrip().endswith("ok")
     assert " 0 rays differ" in logs["oracle_asan"] and " 0 rays differ" in logs["oracle_tsan"]
+    # csrc/ls_launch.h's records as frame_graph_close uses them (19 arguments, alignment above 16, swap + reuse): VERDICT round 5, item 2
+    assert "failures: 0" in logs["launch_record_asan"] and "FAILED" not in logs["launch_record_asan"]
