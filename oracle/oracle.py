@@ -459,6 +459,34 @@ def fat_traverse_stats(nodes: np.ndarray, tris: np.ndarray, leaf_size: int, dirs
     return t, gid, stats
 
 
+def reference_packet_walk(total_rays: int):
+    """The ray indices EmbreeTracer::traceScene actually traces, packet by packet (EmbreeTracer.cpp:304-307, :315-318):
+    iterations = ceil(rays / 16), chunks = ceil(iterations / 4), and FOUR threads run `chunks` iterations each -- 4 * chunks
+    calls of nextRay16 on the one shared iterator, which stops a packet at the last ray and starts again at ray 0 on the next
+    call (LidarDevice.cpp:294-342, advanceRayIndex :824-845).  When ceil(rays / 16) is not a multiple of 4 the surplus
+    calls re-trace rays from index 0: -> list of (first ray, count) for every executed packet."""
+    N = int(total_rays)
+    iterations = N // 16 + (1 if N % 16 else 0)
+    chunks = iterations // 4 + (1 if iterations % 4 else 0)
+    out, pos = [], 0
+    for _ in range(4 * chunks):
+        n = min(16, N - pos)
+        out.append((pos, n))
+        pos = (pos + n) % N
+    return out
+
+
+def reference_width(sensor: Sensor, hit_mask) -> int:
+    """`cloud.width` the reference's Embree backend reports for a frame whose per-ray hit mask (ray-index order) is
+    `hit_mask`: every hit of every executed packet is appended (EmbreeTracer.cpp:338-352), duplicates included, and
+    width = the number appended (:364).  Equal to the number of hits whenever ceil(rays / 16) is a multiple of 4 -- every
+    shipped config (4800 rays: 300 iterations) and SYN-128 (32 768) -- and larger by the hits among the re-traced leading
+    rays otherwise.  The HIP backend (and the OptiX one, OptixTracer.cpp:895-942) reports every hit once."""
+    hit = np.asarray(hit_mask, bool).reshape(-1)
+    assert hit.shape[0] == sensor.total_rays
+    return int(sum(int(hit[a:a + n].sum()) for a, n in reference_packet_walk(sensor.total_rays)))
+
+
 def trace_frame(sensor: Sensor, meshes, use_bvh: bool = False, nthreads: int = 8):
     """The reference's per-frame sequence on the CPU: update every mesh, commit, trace, pack.
     -> dict(t, gid, points, hits, scene, dirs)."""

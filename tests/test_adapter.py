@@ -390,3 +390,27 @@ def test_adapter_grazing_corners_through_probed_tables(adapterapi, oracle, tmp_p
             assert ref["points"].shape[0] > 300
             assert np.array_equal(_points(tr.cloud()), ref["points"])
         tr.close()
+
+
+@pytest.mark.gpu
+def test_adapter_width_is_unique_hits_where_the_embree_backend_would_duplicate(adapterapi, oracle, sensors, meshes, tmp_path):
+    """A raster whose ceil(rays / 16) is not a multiple of 4 -- 32 x 151 = 4832 rays, channel 0 looking down: the reference's Embree
+    backend re-traces rays 0 .. 31 from the wrapped iterator and appends their hits again (EmbreeTracer.cpp:304-307,
+    LidarDevice.cpp:829-835; oracle.reference_width predicts its `width`).  HipTracer traces every ray once: its cloud is the
+    oracle's, its width the number of UNIQUE hits -- the OptiX backend's behaviour (OptixTracer.cpp:895-942) -- and the difference
+    is exactly the predicted 32.  INTEGRATION.md, "Differences a user can see"."""
+    from lidarshooter_amd import synth
+    base = sensors["0000"]
+    path = synth.write_sensor_json(CFG["0000"], str(tmp_path / "odd.json"), base.vertical[::-1].copy(), float(base.h_begin), float(base.h_end), 151)
+    s = oracle.load_sensor(path)
+    assert s.total_rays == 4832 and len(oracle.reference_packet_walk(s.total_rays)) == 304
+    tr = adapterapi.AdapterTracer(path)
+    tr.meshFromSTL("mesh", STL["ground"])
+    assert tr.addGeometry("mesh") == 0 and tr.updateGeometry("mesh", oracle.IDENTITY_AFFINE) == 0 and tr.commitScene() == 0
+    assert tr.traceScene(0) == 0
+    c = tr.cloud()
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    assert np.array_equal(_points(c), ref["points"])
+    unique = int((ref["gid"] != oracle.INVALID).sum())
+    assert c["width"] == unique and oracle.reference_width(s, ref["gid"] != oracle.INVALID) == unique + 32
+    tr.close()

@@ -457,3 +457,33 @@ def test_edge_rule_syn_10m_sector(oracle, sensors):
     st = _rule_diff(oracle, t0, g0, t1, g1)
     assert st["hits"] > 25000, st
     assert st["set_diff"] == 0 and st["id_diff"] == 0 and st["t_diff"] == 0, st
+
+
+def test_reference_width_and_the_wrap_around_duplicates(oracle, sensors, meshes):
+    """EmbreeTracer::traceScene runs 4 * ceil(ceil(rays / 16) / 4) packets on one shared ray iterator that wraps to ray 0
+    (EmbreeTracer.cpp:304-307, LidarDevice.cpp:829-835): when ceil(rays / 16) is not a multiple of 4 the leading rays are traced
+    again and their hits appended again.  oracle.reference_width predicts that `width`; on every shipped raster it is the hit
+    count (the reference's own 1668 / 1781), on others it is larger by exactly the hits among the re-traced rays."""
+    s = sensors["0000"]
+    walk = oracle.reference_packet_walk(s.total_rays)
+    assert len(walk) == 300 and sum(n for _, n in walk) == 4800 and walk[-1] == (4784, 16)      # 4800 rays: no surplus packet
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    assert oracle.reference_width(s, ref["gid"] != oracle.INVALID) == 1668                       # EmbreeTracer_test.cpp:122-135
+    ref = oracle.trace_frame(s, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, *meshes["ben"], oracle.IDENTITY_AFFINE)])
+    assert oracle.reference_width(s, ref["gid"] != oracle.INVALID) == 1781
+    from lidarshooter_amd import synth
+    assert len(oracle.reference_packet_walk(128 * 4096)) == 32768                                 # SYN-128: none either
+    # 32 channels x 151 columns = 4832 rays: 302 iterations -> 76 chunks -> 304 packets: rays 0 .. 31 are traced twice.
+    # Channel 0 looks DOWN here (the shipped order starts with the upward rings, whose rays hit nothing), so the duplicates show
+    odd = oracle.Sensor(uid="odd", vertical=s.vertical[::-1].copy(), h_begin=s.h_begin, h_end=s.h_end, h_count=151, R=s.R, Rinv=s.Rinv, t=s.t)
+    walk = oracle.reference_packet_walk(odd.total_rays)
+    assert len(walk) == 304 and walk[301] == (4816, 16) and walk[302] == (0, 16) and walk[303] == (16, 16)
+    ref = oracle.trace_frame(odd, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    hit = ref["gid"] != oracle.INVALID
+    assert int(hit[:32].sum()) == 32                                                              # the lowest ring hits the ground everywhere
+    assert oracle.reference_width(odd, hit) == int(hit.sum()) + 32 == ref["points"].shape[0] + 32
+    # a raster smaller than a packet: every surplus packet re-traces ALL of it (ceil(5 / 16) = 1 iteration -> 4 packets)
+    tiny = oracle.Sensor(uid="tiny", vertical=s.vertical[-1:].copy(), h_begin=s.h_begin, h_end=s.h_end, h_count=5, R=s.R, Rinv=s.Rinv, t=s.t)
+    assert oracle.reference_packet_walk(5) == [(0, 5)] * 4
+    ref = oracle.trace_frame(tiny, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE)])
+    assert oracle.reference_width(tiny, ref["gid"] != oracle.INVALID) == 4 * ref["points"].shape[0]
