@@ -400,9 +400,12 @@ class Watchdog:
     line is there to be read), 3 when there is nothing to report."""
     EXIT_WITH_LINE, EXIT_WITHOUT = 4, 3
 
-    def __init__(self, result_fd: int, rank: int):
+    def __init__(self, result_fd: int, rank: int, store=None):
         import threading
-        self.result_fd, self.rank = result_fd, rank
+        # store: torch.distributed's key-value store.  A rank other than 0 that ends the job says so THERE first, and rank 0's
+        # watchdog thread, which polls it, writes the line and leaves within a quarter of a second -- before the launcher, seeing
+        # a rank leave with a non-zero code, terminates the others (it would otherwise end rank 0 before its line is out).
+        self.result_fd, self.rank, self.store = result_fd, rank, store
         self.lock = threading.Lock()
         self.deadline, self.what, self.seconds, self.fallback = None, None, 0.0, None
         t = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
@@ -425,6 +428,12 @@ class Watchdog:
                 what, seconds, fallback = self.what, self.seconds, self.fallback
             if late:
                 self._expire(what, seconds, fallback)
+            if self.rank == 0 and self.store is not None and what is not None:
+                try:
+                    if self.store.check(["ls_bench_watchdog"]):
+                        self._end("a peer ended the job: " + self.store.get("ls_bench_watchdog").decode(), fallback)
+                except Exception:
+                    pass
 
     def _expire(self, what, seconds, fallback):
         self._end(f"'{what}' did not finish within {seconds:.0f} s on rank {self.rank}: taken to be hung (a collective that never "
@@ -448,6 +457,11 @@ class Watchdog:
                 line["error"] = msg + f"; `value` is the measurement that did finish ({fallback['config']['parallelism']})"
                 os.write(self.result_fd, (json.dumps(front_loaded(line)) + "\n").encode())
         else:
+            try:
+                if self.store is not None:
+                    self.store.set("ls_bench_watchdog", msg)
+            except Exception:
+                pass
             time.sleep(3.0)   # rank 0 writes its line before a launcher that sees a rank leave ends the others
         os._exit(self.EXIT_WITH_LINE if fallback is not None else self.EXIT_WITHOUT)
 
@@ -593,7 +607,13 @@ def main():
             b["workload"] = m["config"]["workload"]
             b["parallelism"] = m["config"]["parallelism"]
             return b
-        dog = Watchdog(result_fd, rank)
+        store = None
+        if world > 1:
+            try:
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:
+                store = None
+        dog = Watchdog(result_fd, rank, store)
         limit = float(os.environ.get("LS_BENCH_WATCHDOG_S", "240"))
         dog.arm("frames interleaved over the ranks", limit)
         inter = measure(args, rank, world, device, dev_index, rehearsal, "interleaved", force_group=force_group)
