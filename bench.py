@@ -62,7 +62,7 @@ def parse_args():
                     help="single GPU: LS_OPT_PIPELINE mode, 1 = two frames in flight on one stream (finish + pack ride in "
                          "the next frame's launch: one launch per frame), 2 = three frames in flight on three streams; "
                          "0 (default) = 2 for scenes of 200 000 triangles or more, 1 for small scenes (host-bound)")
-    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5"],
+    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5", "syn128x2m", "syn128x3m", "syn128x5m"],
                     help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size; "
                          "cfg5 = configs[4] itself: one SYN-128 sensor per GPU on a 20 m circle over SYN-10M + ben "
                          "animated by config/trajectory.json, replicas only (weak scaling, no collective)")
@@ -115,7 +115,10 @@ def build_workload(name, rank=0):
     d = dict(d)
     d["vertical"] = synth.syn_vertical(128)      # +15 .. -25 deg
     d["h_begin"], d["h_end"], d["h_count"] = np.float32(0.0), np.float32(360.0), 4096
-    v, t = synth.syn_10m() if name in ("syn128x10m", "cfg5") else synth.syn_1m()
+    if os.environ.get("LS_BENCH_SYN_CHANNELS"):   # (tools/cull_crossover.sh: the same span with fewer, wider-spaced rings)
+        d["vertical"] = synth.syn_vertical(int(os.environ["LS_BENCH_SYN_CHANNELS"]))
+    between = {"syn128x2m": (1414, 707), "syn128x3m": (1732, 866), "syn128x5m": (2236, 1118)}   # BASELINE.md section 4's formula, 2 : 1 cells, other sizes
+    v, t = synth.grid_mesh(*between[name]) if name in between else (synth.syn_10m() if name in ("syn128x10m", "cfg5") else synth.syn_1m())
     if name == "cfg5":
         ang = 2.0 * np.pi * rank / 8.0            # 8 sensor poses on a 20 m circle around lidar_0000's
         d["t"] = (d["t"] + np.array([20.0 * np.cos(ang), 20.0 * np.sin(ang), 0.0], np.float32)).astype(np.float32)
@@ -1263,6 +1266,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                                 "geometry resident in HBM, every mesh's pose restated per frame; cloud left in HBM -- the frame with vertices "
                                 "re-sent from host memory and the cloud delivered to PointCloud2::data is dropin_ms_per_step)",
                    "syn128x10m": "Mrays/s (LiDAR frame as above; 128ch x 4096az over 10M tris; geometry resident in HBM, cloud left in HBM)",
+                   "syn128x2m": "Mrays/s (LiDAR frame as above; 2M tris)", "syn128x3m": "Mrays/s (LiDAR frame as above; 3M tris)", "syn128x5m": "Mrays/s (LiDAR frame as above; 5M tris)",
                    "cfg5": "Mrays/s (one 128ch x 4096az sensor per GPU over a shared 10M-tri scene + animated instance)",
                    "xt32": "Mrays/s (XT-32 over ground+ben)"}[args.workload],
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1270,6 +1274,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         "dtype": "f32", "data": "synthetic" + (" (LS_BENCH_SHIM: %d ranks on ONE device, collectives through tests/shim -- a test of semantics, not a measurement)" % world if SHIM else ""),
         "config": {"workload": {"syn128x1m": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)",
                                 "syn128x10m": "SYN-128 x SYN-10M (9,998,244 tris)",
+                                "syn128x2m": "SYN-128 x 1414 x 707-cell grid (1,999,396 tris)", "syn128x3m": "SYN-128 x 1732 x 866-cell grid (2,999,824 tris)",
+                                "syn128x5m": "SYN-128 x 2236 x 1118-cell grid (4,999,696 tris)",
                                 "cfg5": "8-pose SYN-128 ring x (SYN-10M + ben.stl animated by trajectory.json), replicas only",
                                 "xt32": "XT-32 lidar_0000 x ground.stl+ben.stl"}[args.workload],
                    "rays_per_frame": total_rays, "triangles": info["n_tris"], "engine": engine,

@@ -352,6 +352,10 @@ int ls_tracer_set_hit_buffers(ls_tracer *tr, void *d_hits, uint32_t *d_n_points,
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */
+#define LS_OPT_BVH_WIDE 16      /* BVH engine, instanced mode: 1 (default) the trace walks FOUR-wide nodes made of the binary hierarchy
+                                 *    after every build / refit (a node's slots are its grandchildren: half the trips per ray, four
+                                 *    slab tests in flight per trip; + 128 bytes per node); 0: the binary nodes.  Identical results.
+                                 *    Takes effect at the next commit.                                                              */
 #define LS_OPT_EMIT_POINTS 15   /* ls_trace_scene_async: 1 (default) the pack pass writes the 32-byte points and the 16-byte hit
                                  *    records; 0: the hit records only (d_points32 stays untouched) -- for a consumer that
                                  *    rebuilds points from (ray, t) anyway: a sharded group gathers hit records and

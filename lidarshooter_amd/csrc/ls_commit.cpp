@@ -140,7 +140,8 @@ bool inst_possible(const ls_tracer *tr, const std::vector<Geometry *> &order)
 int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool relayout)
 {
     const uint32_t g = tr->leaf_size;
-    const bool fresh = relayout || !tr->inst_valid || tr->inst_leaf_size != g || tr->inst_layout.size() != order.size();
+    const bool fresh = relayout || !tr->inst_valid || tr->inst_leaf_size != g || tr->inst_layout.size() != order.size() ||
+                       (tr->opt_bvh_wide != 0) != tr->wide_valid;   // (the option changed: the twins are made with the hierarchies)
     int rc;
     if (fresh) {
         tr->inst_layout.assign(order.size(), ls_tracer::InstSlot());
@@ -162,6 +163,7 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
         }
         if ((rc = ensure(tr, tr->records, (size_t)recs))) return rc;
         if ((rc = ensure(tr, tr->nodes, (size_t)nodes + 1))) return rc;
+        if (tr->opt_bvh_wide && (rc = ensure(tr, tr->wide_nodes, (size_t)nodes + 1))) return rc;
         if ((rc = ensure(tr, tr->range_boxes, (size_t)range + 2))) return rc;
         tr->n_leaves = nodes;
         tr->inst_leaf_size = g;
@@ -213,7 +215,10 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             // (a refit finds the topology of these very keys in the nodes: fresh layouts and classic builds in between clear the condition)
             if (refit) ls::launch_refit_nodes(s, sl.n_leaves, sl.rt, rb, tr->nodes.p + sl.node_first);
             else ls::launch_hierarchy(s, kb, sl.n_leaves, g, sl.rt, rb, tr->nodes.p + sl.node_first);
+            // the four-wide twins the trace walks (LS_OPT_BVH_WIDE): after every build and every refit of this geometry
+            if (tr->opt_bvh_wide) ls::launch_widen(s, tr->nodes.p + sl.node_first, sl.n_leaves, tr->wide_nodes.p + sl.node_first);
         }
+        tr->wide_valid = tr->opt_bvh_wide != 0;
         // a scene of one geometry: the top of its hierarchy for the trace grid's LDS (static with the hierarchy)
         tr->treelet_valid = false;
         static const bool no_treelet = tune_int("LS_TRACE_NO_TREELET", 0) != 0;

@@ -386,7 +386,7 @@ void ls_tracer_destroy(ls_tracer *tr)
     }
     release(tr->verts); release(tr->tris); release(tr->keys_a); release(tr->keys_b); release(tr->vals_a);
     release(tr->vals_b); release(tr->geom_table); release(tr->sort_temp); release(tr->records);
-    release(tr->inst_verts); release(tr->treelet);
+    release(tr->inst_verts); release(tr->treelet); release(tr->wide_nodes);
     if (tr->d_inst_maxabs) (void)hipFree(tr->d_inst_maxabs);
     release(tr->nodes); release(tr->range_boxes); release(tr->hit_t); release(tr->hit_gid);
     release(tr->row_counts); release(tr->points); release(tr->hits);
@@ -559,6 +559,7 @@ int ls_tracer_set_option(ls_tracer *tr, int option, int value)
     case LS_OPT_DEBUG_FAULT: tr->opt_debug_fault = value != 0; return LS_OK;
     case LS_OPT_BVH_REFIT: tr->opt_bvh_refit = value != 0; return LS_OK;
     case LS_OPT_BVH_INSTANCED: tr->opt_bvh_instanced = value != 0; tr->committed = false; return LS_OK;   // takes effect at the next commit
+    case LS_OPT_BVH_WIDE: tr->opt_bvh_wide = value != 0; tr->committed = false; return LS_OK;             // the same
     case LS_OPT_BLOCK_CULL:
         if (value < 0 || value > 2) return fail(tr, LS_ERR_INVALID_ARGUMENT, "LS_OPT_BLOCK_CULL: 0 off, 1 on, 2 auto");
         tr->opt_block_cull = value;

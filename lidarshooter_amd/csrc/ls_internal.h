@@ -202,6 +202,9 @@ struct ls_tracer {
     uint32_t *d_inst_maxabs = nullptr;   // kGeomsPerLaunch words
     lsi::DevBuf<ls::FatNode> treelet; // one-geometry scenes: the top of that hierarchy, breadth-first (k_trace_inst stages it in LDS)
     bool treelet_valid = false;
+    lsi::DevBuf<ls::WideNode> wide_nodes;   // instanced mode, LS_OPT_BVH_WIDE: the four-wide twins of `nodes` (k_widen), same indexing
+    bool wide_valid = false;
+    int opt_bvh_wide = 1;
     bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
     bool tris_rebased = false;          // tr->tris holds the rebased indices of the current layout and index uploads
     bool classic_nodes_valid = false;   // tr->nodes holds the classic hierarchy of the keys bvh_order_valid speaks of (k_refit_nodes may reuse its topology)

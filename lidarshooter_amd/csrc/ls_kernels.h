@@ -15,7 +15,8 @@ constexpr int kMaxRangeLevels = 32;
 constexpr int kMaxGeoms = 1024;
 constexpr int kQueues = 8;           // one ray queue per XCD
 constexpr int kStackLds = 32;        // per-lane traversal stack entries kept in LDS
-constexpr int kStackSpill = 32;      // further entries in global memory (tree depth <= 62 by construction)
+constexpr int kStackSpill = 64;      // further entries in global memory (tree depth <= 62 by construction: the binary walk holds at most 62
+                                     // pending references, the four-wide walk at most 3 per two levels: 93)
 
 // 64-byte BVH2 node: both child boxes + both child references (DESIGN.md "BVH layout").
 //   q[0] = (L.lo.x, L.lo.y, L.lo.z, bits(left ref))    q[1] = (L.hi.x, L.hi.y, L.hi.z, bits(right ref))
@@ -26,6 +27,14 @@ struct alignas(64) FatNode {
     float4 q[4];
 };
 static_assert(sizeof(FatNode) == 64, "node must be 64 bytes");
+
+// 128-byte four-wide node (k_widen, k_trace_inst<WIDE>): slot c = 0 .. 3 is a grandchild of the binary node of the same index (or a
+// child that is a leaf): q[c] = (lo.x, lo.y, lo.z, bits(reference)), q[4 + c] = (hi.x, hi.y, hi.z, 0); an empty slot's reference is
+// kInvalid.  References are those of the binary nodes (leaf bit, node index), so that both walks share leaves and records.
+struct alignas(128) WideNode {
+    float4 q[8];
+};
+static_assert(sizeof(WideNode) == 128, "wide node must be 128 bytes");
 
 // 48-byte triangle record, in Morton-sorted order (leaf k owns records [k*g, k*g+count)).
 struct alignas(16) TriRecord {
@@ -219,9 +228,12 @@ struct InstBatch {
 // breadth-first order with the references among them rewritten to kTreeletBit | slot (launch_treelet); every block of
 // the trace grid stages it in LDS once and walks the first levels of every ray there
 void launch_treelet(hipStream_t s, const FatNode *nodes, uint32_t n_leaves, FatNode *treelet);
+// wide: the four-wide nodes of the same hierarchies (launch_widen; same indexing as `nodes`), or nullptr for the binary walk
 void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq, const InstBatch &batch,
-                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
+                            const FatNode *nodes, const WideNode *wide, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
                             uint32_t *gid_out, uint32_t *spill, unsigned long long *visit_counts /* nullptr = do not count */);
+// the four-wide twins of a hierarchy's n_leaves - 1 binary nodes (after every build or refit of it)
+void launch_widen(hipStream_t s, const FatNode *nodes, uint32_t n_leaves, WideNode *wide);
 void launch_rowcount(hipStream_t s, const uint32_t *gid, uint32_t nrays, uint32_t *row_counts, uint32_t *queue_heads = nullptr);   // queue_heads: zeroed for the next k_trace
 // Progress of a synchronous frame whose compact points go straight to pinned host memory (ls_trace_scene_begin /
 // ls_trace_scene_expand): the device publishes, with system-scope release, (1) the frame's hit count as the pack pass

@@ -806,6 +806,47 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
     }
 }
 
+// Four-wide nodes of a binary hierarchy (round 6): wide node i stands for binary node i with its CHILDREN skipped -- its slots are
+// node i's grandchildren, a child that is a leaf keeps a slot of its own -- two to four slots, the rest empty (reference kInvalid).
+// One lane per binary node, no order among them: every node gets a wide twin at its own index (a walk from the root uses every
+// other level's; which ones is not known here, and a second, compacting pass would cost more than the unused half's stores).
+// The two children of a node are neighbours in the node array (Karras: split and split + 1), and most nodes are close to their
+// children: the gathers mostly land in lines a neighbouring lane reads as its own node.
+__global__ __launch_bounds__(kBlock) void k_widen(const FatNode *__restrict__ nodes, uint32_t n_nodes, WideNode *__restrict__ wide)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float4 *nd = nodes[i].q;
+    const float4 A = nd[0], B = nd[1], C = nd[2], D = nd[3];
+    const uint32_t left = __float_as_uint(A.w), right = __float_as_uint(B.w);
+    float4 lo[4], hi[4];
+    const float4 none_lo = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(kInvalid)), none_hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { lo[c] = none_lo; hi[c] = none_hi; }
+    // slots 0, 1: the left child's side; 2, 3: the right child's
+    if (left & kLeafBit) {
+        lo[0] = make_float4(A.x, A.y, A.z, __uint_as_float(left));
+        hi[0] = make_float4(B.x, B.y, B.z, 0.0f);
+    } else {
+        const float4 *c = nodes[left].q;
+        const float4 a = c[0], b = c[1], cc = c[2], d = c[3];
+        lo[0] = make_float4(a.x, a.y, a.z, a.w); hi[0] = make_float4(b.x, b.y, b.z, 0.0f);
+        lo[1] = make_float4(cc.x, cc.y, cc.z, b.w); hi[1] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+    if (right & kLeafBit) {
+        lo[2] = make_float4(C.x, C.y, C.z, __uint_as_float(right));
+        hi[2] = make_float4(D.x, D.y, D.z, 0.0f);
+    } else {
+        const float4 *c = nodes[right].q;
+        const float4 a = c[0], b = c[1], cc = c[2], d = c[3];
+        lo[2] = make_float4(a.x, a.y, a.z, a.w); hi[2] = make_float4(b.x, b.y, b.z, 0.0f);
+        lo[3] = make_float4(cc.x, cc.y, cc.z, b.w); hi[3] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+    float4 *o = wide[i].q;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { o[c] = lo[c]; o[4 + c] = hi[c]; }
+}
+
 // Top of a hierarchy in breadth-first order, for the LDS of k_trace_inst: slot 0 = the root; a node's child that is an
 // internal node gets the next free slot while there are any (its reference becomes kTreeletBit | slot), leaves and
 // the nodes below the last slot keep their references.  One workgroup; a level at a time.
@@ -854,8 +895,17 @@ __global__ __launch_bounds__(kBlock) void k_treelet(const FatNode *__restrict__ 
 // construction), and at a leaf the exact test of every other path: the three corners through this frame's transform
 // (xform_vertex: the bits of k_transform / k_project), e1, e2, NgC, Embree's test against the table direction.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, bool SINGLE /* one geometry (the usual scene): its descriptor is wave-uniform, scalar registers */>
+//
+// WIDE (round 6, the default): the nodes are the FOUR-wide ones k_widen makes of the same hierarchy -- a node's slots are its
+// grandchildren (a child that is a leaf keeps its slot), 128 bytes: one fetch resolves four boxes and a trip goes down two
+// levels of the binary tree.  The kernel is bound by what a trip costs a wave in latency (EXPERIMENTS.md E4): half the trips,
+// each with four independent slab tests in flight instead of two.  The hit children are ordered nearest first (a five-
+// comparator network on (t_near, reference) pairs), the nearest is walked on, the others are pushed far to near.  The same
+// boxes, leaves and exact test as the binary walk: a grandchild is visited when ITS box is hit (the binary walk also asks
+// its parent's, which contains it: the wide walk visits a superset), so the closest hit and its tie-break are the same bits.
+template <bool COUNT, bool SINGLE /* one geometry (the usual scene): its descriptor is wave-uniform, scalar registers */, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueues rq, InstBatch batch, const FatNode *__restrict__ nodes,
+                                                       const WideNode *__restrict__ wide,
                                                        const TriRecord *__restrict__ records, uint32_t g,
                                                        const FatNode *__restrict__ treelet, float *__restrict__ t_out,
                                                        uint32_t *__restrict__ gid_out, uint32_t *__restrict__ spill,
@@ -864,10 +914,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
     __shared__ uint32_t s_stack[kStackLds][kBlock];
     // one geometry: the top of its hierarchy (launch_treelet: breadth-first, kTreeletNodes nodes) sits in LDS; the first
     // levels of every ray -- the fetches every lane of every wave makes -- are LDS reads instead of cache round trips
-    __shared__ float4 s_tree[SINGLE ? 4 * kTreeletNodes : 1];
+    // (binary nodes only: it was worth 0.6 % there, E4, and the wide walk spends the LDS on nothing)
+    __shared__ float4 s_tree[(SINGLE && !WIDE) ? 4 * kTreeletNodes : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const bool use_tree = SINGLE && treelet != nullptr && batch.g[0].n_leaves > 1u;
-    if (SINGLE && use_tree) {
+    const bool use_tree = SINGLE && !WIDE && treelet != nullptr && batch.g[0].n_leaves > 1u;
+    if (SINGLE && !WIDE && use_tree) {
         const float4 *src = reinterpret_cast<const float4 *>(treelet);
         for (uint32_t i = tid; i < 4u * kTreeletNodes; i += kBlock) s_tree[i] = src[i];
         __syncthreads();
@@ -956,7 +1007,45 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
             // `ig` is geometry `gi` as this trip started; advance() may move the lane on to another geometry, whose
             // leaves must not be tested with `ig`'s records and transform: they wait for the next trip
             const uint32_t at_entry = gi;
-            if (cur != kInvalid && !(cur & kLeafBit)) {
+            if (WIDE && cur != kInvalid && !(cur & kLeafBit)) {
+                const float4 *nd = wide[ig.node_first + cur].q;
+                const float4 l0 = nd[0], l1 = nd[1], l2 = nd[2], l3 = nd[3], h0 = nd[4], h1 = nd[5], h2 = nd[6], h3 = nd[7];
+                if (COUNT) ++cn;
+                auto slab = [&](const float4 &lo, const float4 &hi, float &tn) {
+                    const float x1 = fmaf(lo.x, ix, cxl), x2 = fmaf(hi.x, ix, cxh), y1 = fmaf(lo.y, iy, cyl), y2 = fmaf(hi.y, iy, cyh),
+                                z1 = fmaf(lo.z, iz, czl), z2 = fmaf(hi.z, iz, czh);
+                    tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
+                    const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), best));
+                    // (the far bound gets two ulps: the products above round once each; an empty slot's reference is kInvalid)
+                    return tn <= tf * 1.0000003f && __float_as_uint(lo.w) != kInvalid;
+                };
+                float k0, k1, k2, k3;
+                const bool b0 = slab(l0, h0, k0), b1 = slab(l1, h1, k1), b2 = slab(l2, h2, k2), b3 = slab(l3, h3, k3);
+                uint32_t r0 = __float_as_uint(l0.w), r1 = __float_as_uint(l1.w), r2 = __float_as_uint(l2.w), r3 = __float_as_uint(l3.w);
+                k0 = b0 ? k0 : INFINITY; k1 = b1 ? k1 : INFINITY; k2 = b2 ? k2 : INFINITY; k3 = b3 ? k3 : INFINITY;
+                r0 = b0 ? r0 : kInvalid; r1 = b1 ? r1 : kInvalid; r2 = b2 ? r2 : kInvalid; r3 = b3 ? r3 : kInvalid;
+                // ascending t_near, missed slots last (t_near of a hit is finite: best caps the far bound it is compared with)
+                auto cswap = [](float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
+                    const bool sw = kb < ka || (ra == kInvalid && rb != kInvalid);
+                    const float kt = sw ? kb : ka; kb = sw ? ka : kb; ka = kt;
+                    const uint32_t rt = sw ? rb : ra; rb = sw ? ra : rb; ra = rt;
+                };
+                cswap(k0, r0, k1, r1); cswap(k2, r2, k3, r3); cswap(k0, r0, k2, r2); cswap(k1, r1, k3, r3); cswap(k1, r1, k2, r2);
+                auto push = [&](uint32_t ref) {
+                    if (sp < (uint32_t)kStackLds) s_stack[sp][tid] = ref;
+                    else if (sp < (uint32_t)(kStackLds + kStackSpill)) my_spill[sp - kStackLds] = ref;
+                    ++sp;
+                };
+                if (r0 == kInvalid) {
+                    advance();
+                } else {
+                    if (r3 != kInvalid) push(r3);
+                    if (r2 != kInvalid) push(r2);
+                    if (r1 != kInvalid) push(r1);
+                    cur = r0;
+                }
+            }
+            if (!WIDE && cur != kInvalid && !(cur & kLeafBit)) {
                 float4 A, B, C, D;
                 if (SINGLE && (cur & kTreeletBit)) {
                     const float4 *nd = s_tree + 4u * (cur & (kTreeletBit - 1u));
@@ -1628,17 +1717,28 @@ void launch_treelet(hipStream_t s, const FatNode *nodes, uint32_t n_leaves, FatN
 }
 
 void launch_trace_instanced(hipStream_t s, uint32_t grid_blocks, const SensorTables &tb, const RayQueues &rq, const InstBatch &batch,
-                            const FatNode *nodes, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
+                            const FatNode *nodes, const WideNode *wide, const TriRecord *records, uint32_t leaf_size, const FatNode *treelet, float *t_out,
                             uint32_t *gid_out, uint32_t *spill, unsigned long long *visit_counts)
 {
     const uint32_t nq = tb.V * tb.naz;
     if (!nq || !batch.n) return;
     const uint32_t grid = min(grid_blocks, (nq + kBlock - 1) / kBlock);
-#define LS_TRACE_INST(C, S) hipLaunchKernelGGL((k_trace_inst<C, S>), dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, records, leaf_size, \
-                                                treelet, t_out, gid_out, spill, visit_counts)
-    if (visit_counts) { if (batch.n == 1u) LS_TRACE_INST(true, true); else LS_TRACE_INST(true, false); }
-    else { if (batch.n == 1u) LS_TRACE_INST(false, true); else LS_TRACE_INST(false, false); }
+#define LS_TRACE_INST(C, S, W) hipLaunchKernelGGL((k_trace_inst<C, S, W>), dim3(grid), dim3(kBlock), 0, s, tb, rq, batch, nodes, wide, records, leaf_size, \
+                                                   treelet, t_out, gid_out, spill, visit_counts)
+    if (wide) {
+        if (visit_counts) { if (batch.n == 1u) LS_TRACE_INST(true, true, true); else LS_TRACE_INST(true, false, true); }
+        else { if (batch.n == 1u) LS_TRACE_INST(false, true, true); else LS_TRACE_INST(false, false, true); }
+    } else {
+        if (visit_counts) { if (batch.n == 1u) LS_TRACE_INST(true, true, false); else LS_TRACE_INST(true, false, false); }
+        else { if (batch.n == 1u) LS_TRACE_INST(false, true, false); else LS_TRACE_INST(false, false, false); }
+    }
 #undef LS_TRACE_INST
+}
+
+void launch_widen(hipStream_t s, const FatNode *nodes, uint32_t n_leaves, WideNode *wide)
+{
+    if (n_leaves < 2u) return;
+    hipLaunchKernelGGL(k_widen, dim3(blocks_for(n_leaves - 1u)), dim3(kBlock), 0, s, nodes, n_leaves - 1u, wide);
 }
 
 void launch_quads_to_triangles(hipStream_t s, const uint32_t *quad_idx, uint32_t n_quads, uint32_t *tri_idx)

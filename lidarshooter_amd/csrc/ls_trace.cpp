@@ -896,7 +896,7 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                 std::memcpy(ig.m.rinv, tr->rinv, sizeof(ig.m.rinv));
                 std::memcpy(ig.m.t, tr->t, sizeof(ig.m.t));
             }
-            ls::launch_trace_instanced(s, tr->trace_blocks, tb, rq, batch, tr->nodes.p, tr->records.p, tr->inst_leaf_size,
+            ls::launch_trace_instanced(s, tr->trace_blocks, tb, rq, batch, tr->nodes.p, tr->wide_valid ? tr->wide_nodes.p : nullptr, tr->records.p, tr->inst_leaf_size,
                                        (batch.n == 1u && tr->treelet_valid) ? tr->treelet.p : nullptr, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
         } else {
             ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,

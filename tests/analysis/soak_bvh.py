@@ -44,6 +44,7 @@ while time.time() - t0 < budget:
         bvh.setOption(capi.LS_OPT_LEAF_SIZE, int(rng.choice([1, 2, 4, 8])))
     elif what == "instanced":
         bvh.setOption(capi.LS_OPT_BVH_INSTANCED, int(rng.integers(0, 2)))
+        bvh.setOption(capi.LS_OPT_BVH_WIDE, int(rng.integers(0, 2)))
     elif what == "refit":
         bvh.setOption(capi.LS_OPT_BVH_REFIT, int(rng.integers(0, 2)))
     else:   # the BVH handle runs a frame under the projection engine with an upload in between, then comes back

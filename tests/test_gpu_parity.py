@@ -488,8 +488,9 @@ def test_many_geometries_one_frame(oracle, capi, sensors, engine):
     tr.close()
 
 
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("leaf", [1, 8])
-def test_bvh_instanced_single_leaf_geometries(oracle, capi, sensors, leaf):
+def test_bvh_instanced_single_leaf_geometries(oracle, capi, sensors, leaf, wide):
     """Instanced BVH path (16 geometries or fewer) where geometries that are ONE leaf -- a lone triangle; with leaf
     size 8 also a two-triangle quad and a 7-triangle soup -- do not come first in geomID order: a lane that leaves a
     bigger hierarchy with an empty stack enters them as `cur = leaf`, and must test that leaf with ITS records and
@@ -498,6 +499,7 @@ def test_bvh_instanced_single_leaf_geometries(oracle, capi, sensors, leaf):
     s = _syn_sensor(oracle, sensors, V=32, H=256)
     tr = make_tracer(capi, s, "bvh")
     tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
+    tr.setOption(capi.LS_OPT_BVH_WIDE, wide)       # the four-wide walk (round 6, default) and the binary one
     ml = []
     big_v, big_t = _random_soup(rng, 400, 9.0)
     # a wall of single triangles / small patches right around the sensor, so that most rays hit one of them
@@ -1410,3 +1412,47 @@ def test_set_sensor_keeps_the_geometries(oracle, capi, sensors, meshes, engine, 
         assert rc == 0
         _assert_parity(oracle, s, tr, ml, pts, hits)
     tr.close()
+
+
+@pytest.mark.parametrize("leaf", [1, 2, 4])
+def test_bvh_wide_and_binary_walks_give_the_oracles_answer(oracle, capi, sensors, meshes, leaf):
+    """LS_OPT_BVH_WIDE (round 6): the instanced BVH engine walks four-wide nodes made of the binary hierarchy (k_widen: a node's
+    slots are its grandchildren) -- half the trips per ray.  Same boxes, same leaves, same exact test: ids, t and points equal the
+    oracle's with the option on and off, switching back and forth on one handle (the twins are made at the commit after the
+    option changes), over the shipped scene with ben moving, after a vertex upload (a refit re-makes the twins) and over a
+    grid whose hierarchy is deep enough for the stack to matter."""
+    from lidarshooter_amd import synth
+    s = sensors["0001"]
+    tr = make_tracer(capi, s, "bvh")
+    tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
+    _add(tr, "ground", meshes["ground"])
+    _add(tr, "face", meshes["ben"])
+    tr.updateGeometry("ground", oracle.IDENTITY_AFFINE, *meshes["ground"])
+    bv, bt = meshes["ben"]
+    for k, wide in enumerate((1, 0, 1, 1, 0)):
+        tr.setOption(capi.LS_OPT_BVH_WIDE, wide)
+        A = oracle.affine_from_components(np.array((0.5 * k, -0.2 * k, 0.03 * k), np.float32), np.array((0.0, 0.1 * k, 0.3 * k), np.float32))
+        v = bv if k < 3 else (bv * np.float32(1.0 + 0.02 * k)).astype(np.float32)      # k >= 3: new vertices, same topology: a refit
+        tr.updateGeometry("face", A, v, bt)
+        assert tr.commitScene() == 0 and tr.info(capi.LS_INFO_BVH_INSTANCED) == 2
+        rc, pts, hits = tr.traceScene(k)
+        assert rc == 0
+        _assert_parity(oracle, s, tr, [(0, *meshes["ground"], oracle.IDENTITY_AFFINE), (1, v, bt, A)], pts, hits)
+    tr.close()
+    s2 = _syn_sensor(oracle, sensors, V=64, H=512)
+    gv, gt = synth.grid_mesh(300, 150)                       # 90 000 triangles
+    res = {}
+    for wide in (1, 0):
+        tr = make_tracer(capi, s2, "bvh")
+        tr.setOption(capi.LS_OPT_LEAF_SIZE, leaf)
+        tr.setOption(capi.LS_OPT_BVH_WIDE, wide)
+        tr.setOption(capi.LS_OPT_COUNT_VISITS, 1)
+        tr.addGeometry("grid", gv.shape[0], gt.shape[0])
+        tr.updateGeometry("grid", oracle.IDENTITY_AFFINE, gv, gt)
+        assert tr.commitScene() == 0
+        rc, pts, hits = tr.traceScene(0)
+        _assert_parity(oracle, s2, tr, [(0, gv, gt, oracle.IDENTITY_AFFINE)], pts, hits)
+        res[wide] = tr.visitStats()
+        tr.close()
+    # (node fetches per frame: the wide walk makes fewer of them, and not more triangle tests than twice the binary walk's)
+    assert res[1][0] < res[0][0] and res[1][1] <= 2 * res[0][1], res
