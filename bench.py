@@ -62,7 +62,7 @@ def parse_args():
                     help="single GPU: LS_OPT_PIPELINE mode, 1 = two frames in flight on one stream (finish + pack ride in "
                          "the next frame's launch: one launch per frame), 2 = three frames in flight on three streams; "
                          "0 (default) = 2 for scenes of 200 000 triangles or more, 1 for small scenes (host-bound)")
-    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5", "syn128x2m", "syn128x3m", "syn128x5m"],
+    ap.add_argument("--workload", default="syn128x1m", choices=["syn128x1m", "syn128x10m", "xt32", "cfg5", "syn128x2m", "syn128x3m", "syn128x5m", "syn128x1500k"],
                     help="syn128x1m = the headline config; syn128x10m = BASELINE.json configs[4]'s scene size; "
                          "cfg5 = configs[4] itself: one SYN-128 sensor per GPU on a 20 m circle over SYN-10M + ben "
                          "animated by config/trajectory.json, replicas only (weak scaling, no collective)")
@@ -117,7 +117,7 @@ def build_workload(name, rank=0):
     d["h_begin"], d["h_end"], d["h_count"] = np.float32(0.0), np.float32(360.0), 4096
     if os.environ.get("LS_BENCH_SYN_CHANNELS"):   # (tools/cull_crossover.sh: the same span with fewer, wider-spaced rings)
         d["vertical"] = synth.syn_vertical(int(os.environ["LS_BENCH_SYN_CHANNELS"]))
-    between = {"syn128x2m": (1414, 707), "syn128x3m": (1732, 866), "syn128x5m": (2236, 1118)}   # BASELINE.md section 4's formula, 2 : 1 cells, other sizes
+    between = {"syn128x1500k": (1224, 612), "syn128x2m": (1414, 707), "syn128x3m": (1732, 866), "syn128x5m": (2236, 1118)}   # BASELINE.md section 4's formula, 2 : 1 cells, other sizes
     v, t = synth.grid_mesh(*between[name]) if name in between else (synth.syn_10m() if name in ("syn128x10m", "cfg5") else synth.syn_1m())
     if name == "cfg5":
         ang = 2.0 * np.pi * rank / 8.0            # 8 sensor poses on a 20 m circle around lidar_0000's
@@ -696,6 +696,8 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         tr.setOption(capi.LS_OPT_BVH_INSTANCED, 0)
     if args.bvh_rebuild:
         tr.setOption(capi.LS_OPT_BVH_REFIT, 0)
+    if os.environ.get("LS_BENCH_BVH_WIDE") is not None:   # (tools/bvh_wide_ab.sh: the binary walk for comparison)
+        tr.setOption(capi.LS_OPT_BVH_WIDE, int(os.environ["LS_BENCH_BVH_WIDE"]))
     if args.no_cull or args.cull:
         tr.setOption(capi.LS_OPT_BLOCK_CULL, 1 if args.cull else 0)
     engine = "bvh" if args.engine == "bvh" else "projection"
@@ -1179,10 +1181,13 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
     if engine == "bvh":
         # k_trace: 64 B per node fetch + 48 B per triangle test + 8 B per ray written
         kernel = "k_trace_inst" if tr.info(capi.LS_INFO_BVH_INSTANCED) else "k_trace"
-        b_launch = RAY_OUT_BYTES * shard_rays + NODE_BYTES * n_node + TRI_BYTES * n_tri
+        wide_walk = bool(tr.info(capi.LS_INFO_BVH_WIDE))
+        node_bytes = 2 * NODE_BYTES if wide_walk else NODE_BYTES   # (a four-wide node is 128 bytes: four boxes + four references)
+        b_launch = RAY_OUT_BYTES * shard_rays + node_bytes * n_node + TRI_BYTES * n_tri
         b_frame = None
         units = {"rays_per_launch": shard_rays, "bytes_per_ray": b_launch / shard_rays,
-                 "nodes_per_ray": n_node / shard_rays, "tris_per_ray": n_tri / shard_rays,
+                 "nodes_per_ray": n_node / shard_rays, "tris_per_ray": n_tri / shard_rays, "node_bytes": node_bytes,
+                 "walk": "four-wide nodes (k_widen: a node's slots are its grandchildren)" if wide_walk else "binary nodes",
                  "wave_trips_mean": wave_trips / max(1, (shard_rays + 63) // 64), "wave_trips_max": max_trips}
     else:
         # k_project: every triangle is streamed once (12 B indices + 36 B vertex gather) and every hit folds 8 B into
@@ -1266,7 +1271,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
                                 "geometry resident in HBM, every mesh's pose restated per frame; cloud left in HBM -- the frame with vertices "
                                 "re-sent from host memory and the cloud delivered to PointCloud2::data is dropin_ms_per_step)",
                    "syn128x10m": "Mrays/s (LiDAR frame as above; 128ch x 4096az over 10M tris; geometry resident in HBM, cloud left in HBM)",
-                   "syn128x2m": "Mrays/s (LiDAR frame as above; 2M tris)", "syn128x3m": "Mrays/s (LiDAR frame as above; 3M tris)", "syn128x5m": "Mrays/s (LiDAR frame as above; 5M tris)",
+                   "syn128x1500k": "Mrays/s (LiDAR frame as above; 1.5M tris)", "syn128x2m": "Mrays/s (LiDAR frame as above; 2M tris)", "syn128x3m": "Mrays/s (LiDAR frame as above; 3M tris)", "syn128x5m": "Mrays/s (LiDAR frame as above; 5M tris)",
                    "cfg5": "Mrays/s (one 128ch x 4096az sensor per GPU over a shared 10M-tri scene + animated instance)",
                    "xt32": "Mrays/s (XT-32 over ground+ben)"}[args.workload],
         "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1274,6 +1279,7 @@ def measure(args, rank, world, device, dev_index, rehearsal, multi, force_group=
         "dtype": "f32", "data": "synthetic" + (" (LS_BENCH_SHIM: %d ranks on ONE device, collectives through tests/shim -- a test of semantics, not a measurement)" % world if SHIM else ""),
         "config": {"workload": {"syn128x1m": "SYN-128 (128ch x 4096az, pose lidar_0000) x SYN-1M (1,000,000 tris)",
                                 "syn128x10m": "SYN-128 x SYN-10M (9,998,244 tris)",
+                                "syn128x1500k": "SYN-128 x 1224 x 612-cell grid (1,498,176 tris)",
                                 "syn128x2m": "SYN-128 x 1414 x 707-cell grid (1,999,396 tris)", "syn128x3m": "SYN-128 x 1732 x 866-cell grid (2,999,824 tris)",
                                 "syn128x5m": "SYN-128 x 2236 x 1118-cell grid (4,999,696 tris)",
                                 "cfg5": "8-pose SYN-128 ring x (SYN-10M + ben.stl animated by trajectory.json), replicas only",

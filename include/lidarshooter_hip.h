@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* 4 (round 6): + ls_tracer_set_hit_buffers, ls_group_frame_status, LS_INFO_EMIT_POINTS, LS_INFO_FRAME_GRAPH_PATCH_WAITS,
- *    ls_source_hash, LS_GROUP_INFO_ARRANGEMENT_*; ls_tracer_set_sensor* is refused while external output buffers are
+ *    ls_source_hash, LS_OPT_BVH_WIDE / LS_INFO_BVH_WIDE, LS_GROUP_INFO_ARRANGEMENT_*; ls_tracer_set_sensor* is refused while external output buffers are
  *    installed; ls_commit_scene can return LS_ERR_OUT_OF_RANGE; the test hooks left this header for lidarshooter_hip_debug.h.
  *    The bindings (capi.py, groupapi.py, integration/HipTracer.hpp) check it against ls_abi_version() at load. */
 #define LS_ABI_VERSION 4
@@ -425,6 +425,7 @@ int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
 #define LS_INFO_FRAME_GRAPH_PATCHES 12  /* kernel nodes patched with new arguments before a replay                        */
 #define LS_INFO_FRAME_GRAPH_LAST_PATCHED 13 /* bit i: launch i of the frame replayed last went out with new arguments     */
 #define LS_INFO_EMIT_POINTS 14       /* the current LS_OPT_EMIT_POINTS                                            */
+#define LS_INFO_BVH_WIDE 16                /* 1: the committed BVH scene is walked through its four-wide nodes (LS_OPT_BVH_WIDE, instanced mode) */
 #define LS_INFO_FRAME_GRAPH_PATCH_WAITS 15 /* patches that first had to wait for the previous launch of their graph (the host ran more than three frames ahead) */
 long ls_get_info(ls_tracer *tr, int what);
 

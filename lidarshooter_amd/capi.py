@@ -26,6 +26,7 @@ LS_OPT_UPLOAD_MODE = 13
 LS_OPT_FRAME_GRAPH = 14
 LS_OPT_EMIT_POINTS = 15
 LS_OPT_BVH_WIDE = 16
+LS_INFO_BVH_WIDE = 16
 LS_INFO_FRAME_GRAPH_LAST_PATCHED = 13
 LS_INFO_EMIT_POINTS, LS_INFO_FRAME_GRAPH_PATCH_WAITS = 14, 15
 LS_INFO_NEXT_SLOT, LS_INFO_FRAME_GRAPH_STATE, LS_INFO_FRAME_GRAPH_CAPTURES, LS_INFO_FRAME_GRAPH_REPLAYS, LS_INFO_FRAME_GRAPH_PATCHES = 8, 9, 10, 11, 12

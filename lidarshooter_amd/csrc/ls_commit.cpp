@@ -33,21 +33,23 @@ int materialize_scene(ls_tracer *tr, bool with_maxabs, bool keep_indices)
     return LS_OK;
 }
 
-// When group culling pays (round 5's kernels, one MI355X, SYN-128; profiles/r05_*, EXPERIMENTS.md E7):
-//   * full raster, 10 M triangles: k_cull 14.6 + k_project<CULLED> 30.5 us against 84 us of frame without it -- on;
-//   * full raster, 1 M triangles: the cull pass and the dependent launch behind it cost more than the skipped triangles save,
-//     with the survivors dealt to the waves too (frame 16.8 us against 15.9 with three frames in flight, 29.3 against 25.8 with
-//     one) -- off;
-//   * an azimuth shard narrower than half a turn (what a rank of a sharded group traces): k_cull ends seven workgroups in eight
-//     at their block bounds and k_project reads the sector's survivors only -- an eighth of a turn at 1 M triangles streams in
-//     8.5 - 9.3 us per frame with it (k_cull 5.3 + k_project 8.6 us) against 8.2 - 12.6 without (k_project alone 11.5 us: it
-//     streams the whole mesh and throws seven triangles in eight away after their loads) -- on from 512 k triangles, below which
-//     a mesh is a handful of waves either way.
-// auto = geometries of 2 M triangles or more; of 512 k or more under such a shard.
+// When group culling pays: measured, not asserted (round 6; tools/cull_crossover.sh, profiles/r06_cull_crossover.txt, EXPERIMENTS.md
+// E8.4 -- one MI355X, SYN-128 over the BASELINE grid formula at other sizes, three frames in flight through the C++ loop, us per frame
+// culling off / on):
+//   full raster     1.0 M 13.3 / 16.7    1.5 M 17.3 / 18.2    2.0 M 21.9 / 19.2    3.0 M 29.7 / 22.1    5.0 M 45.0 / 27.2    10 M 81.4 / 38.8
+//   the same with 32 rings: 1 M 10.2 / 11.9, 2 M 17.0 / 11.8, 5 M 35.0 / 12.9;  64 rings: 1 M 11.3 / 15.3, 2 M 17.9 / 16.4, 5 M 38.4 / 16.8
+//   an eighth of a turn (what a rank of eight traces; frames as graphs, ranks 0 / 4):
+//                   1.0 M 8.9, 9.2 / 9.3, 9.0    1.5 M 9.8, 9.5 / 9.7, 9.9    2.0 M 11.6, 10.5 / 9.2, 9.4    3.0 M 15.4, 14.8 / 9.0, 9.3
+// Without culling a frame grows by 8.6 us per million triangles, with it by 2.5 (the survivors) on top of a fixed 3.4 us at 1 M -- the
+// cull pass and the dependent launch behind it: the lines cross between 1.5 M and 2 M whatever the ring spacing (32 rings: near
+// 1.2 M; 64 and 128: 1.6 - 1.8 M -- what moves the crossing is the fixed cost, which the rings do not change).  Under a narrow
+// shard both ways are bound by the host's 9 us per frame up to 1.5 M (a wash), culling wins from 2 M.
+// auto = geometries of 1.75 M triangles or more (round 5: 2 M, two data points); of 512 k or more under a shard narrower than half
+// a turn (unchanged: no worse anywhere, and a rank's GPU then reads its sector instead of the whole mesh).
 bool cull_enabled(const ls_tracer *tr, const Geometry &g)
 {
     if (tr->opt_block_cull != 2) return tr->opt_block_cull != 0;
-    if (g.n_tris >= 2000000u) return true;
+    if (g.n_tris >= 1750000u) return true;
     double lo, hi;
     return g.n_tris >= 524288u && shard_sector(tr, lo, hi);
 }
@@ -222,7 +224,7 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
         // a scene of one geometry: the top of its hierarchy for the trace grid's LDS (static with the hierarchy)
         tr->treelet_valid = false;
         static const bool no_treelet = tune_int("LS_TRACE_NO_TREELET", 0) != 0;
-        if (order.size() == 1 && tr->inst_layout[0].n_leaves > 1u && !no_treelet) {
+        if (order.size() == 1 && tr->inst_layout[0].n_leaves > 1u && !no_treelet && !tr->opt_bvh_wide) {   // (the binary walk's: the four-wide walk does not stage it)
             if ((rc = ensure(tr, tr->treelet, (size_t)ls::kTreeletNodes))) return rc;
             ls::launch_treelet(s, tr->nodes.p + tr->inst_layout[0].node_first, tr->inst_layout[0].n_leaves, tr->treelet.p);
             tr->treelet_valid = true;

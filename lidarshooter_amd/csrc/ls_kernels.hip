@@ -490,7 +490,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 {
     const int L = (int)L_;
     __shared__ uint32_t s_keys[kBlock + 2 * kKeyWindow];
-    __shared__ float4 s_out[kBlock / 64][256];
+    // (a wave's 64 nodes on their way out: quarter k of lane's node at [k * 68 + lane] -- lanes side by side when written, and
+    // the 16 consecutive quarters a store pass reads (4 lanes' nodes) land in 16 different 16-byte columns: 68 = 4 mod 16.  As
+    // [4 * lane + k] every write was a four-way bank conflict; the counters had LDS conflicts at 45 % of this kernel's LDS cycles)
+    __shared__ float4 s_out[kBlock / 64][4 * 68];
     const KeyWindow kw = {s_keys, (int)(blockIdx.x * kBlock) - kKeyWindow, (int)(kBlock + 2 * kKeyWindow)};
     for (int a = (int)threadIdx.x; a < kw.n; a += (int)kBlock) {
         const int j = kw.first + a;
@@ -570,11 +573,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     // storing its own node's four quarters writes 16 bytes of 64 different lines each time)
     float4 *mine = s_out[threadIdx.x >> 6];
     if (node) {
-        mine[4 * lane + 0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
-        mine[4 * lane + 1] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __uint_as_float(right));
+        mine[0 * 68 + lane] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __uint_as_float(left));
+        mine[1 * 68 + lane] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __uint_as_float(right));
         // (the fourth words of the right child's box: the node's leaf range, for k_refit_nodes)
-        mine[4 * lane + 2] = make_float4(br.lo[0], br.lo[1], br.lo[2], __uint_as_float((uint32_t)l));
-        mine[4 * lane + 3] = make_float4(br.hi[0], br.hi[1], br.hi[2], __uint_as_float((uint32_t)r));
+        mine[2 * 68 + lane] = make_float4(br.lo[0], br.lo[1], br.lo[2], __uint_as_float((uint32_t)l));
+        mine[3 * 68 + lane] = make_float4(br.hi[0], br.hi[1], br.hi[2], __uint_as_float((uint32_t)r));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int q = k * 64 + (int)lane;   // quarter q of the wave's 256
-        if (wave_first + (q >> 2) < L - 1) out[q] = mine[q];
+        if (wave_first + (q >> 2) < L - 1) out[q] = mine[(q & 3) * 68 + (q >> 2)];
     }
 }
 

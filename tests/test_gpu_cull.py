@@ -1,5 +1,5 @@
 """Culling in the projection engine (LS_OPT_BLOCK_CULL: Morton-ordered mesh; a bound per 4 triangles and k_cull, which
-drops groups no ring / no shard column can meet -- forced on here, auto takes it from 2 M triangles, and from 512 k under
+drops groups no ring / no shard column can meet -- forced on here, auto takes it from 1.75 M triangles (measured crossover, round 6), and from 512 k under
 an azimuth shard narrower than half a turn) must not change a
 single bit: culled == unculled == BVH
 engine on the headline-sized scene under moving transforms, vertex updates, azimuth shards and both frames-in-flight modes."""
@@ -30,7 +30,7 @@ def test_cull_equals_unculled_under_transforms_and_shards(oracle, capi, sensors)
     from lidarshooter_amd import synth
     v, t = synth.syn_1m()
     s = _syn_sensor(oracle, sensors, V=128, H=4096)
-    # on: group culling forced; auto: the size rule (from 2 M triangles: not here; from 512 k under a narrow shard: here); off
+    # on: group culling forced; auto: the size rule (from 1.75 M triangles: not here; from 512 k under a narrow shard: here); off
     on, auto, off = make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection")
     on.setOption(capi.LS_OPT_BLOCK_CULL, 1)
     off.setOption(capi.LS_OPT_BLOCK_CULL, 0)
@@ -335,3 +335,33 @@ def test_cull_when_nearly_everything_survives(oracle, capi, sensors):
     _same(_frame(pr), _frame(bvh))
     pr.close()
     bvh.close()
+
+
+def test_auto_rule_at_its_measured_threshold(oracle, capi, sensors):
+    """cull_enabled (ls_commit.cpp) since round 6: the full raster is culled from 1.75 M triangles -- where the measured lines cross
+    (tools/cull_crossover.sh: culling loses 0.8 us per frame at 1.5 M and wins 2.7 at 2 M) -- instead of round 5's 2 M.  A grid just
+    below (1 700 416 triangles) is not culled, one just above (1 800 964) is (k_cull's counters run); the cloud is the unculled
+    handle's either way."""
+    from lidarshooter_amd import synth
+    s = _syn_sensor(oracle, sensors, V=128, H=4096)
+    for cells, culls in (((1304, 652), False), ((1342, 671), True)):
+        v, t = synth.grid_mesh(*cells)
+        assert (t.shape[0] >= 1750000) == culls
+        auto, off = make_tracer(capi, s, "projection"), make_tracer(capi, s, "projection")
+        off.setOption(capi.LS_OPT_BLOCK_CULL, 0)
+        for tr in (auto, off):
+            tr.addGeometry("g", v.shape[0], t.shape[0])
+            tr.updateGeometry("g", oracle.IDENTITY_AFFINE, v, t)
+        ref = _frame(off)
+        _same(_frame(auto), ref)
+        auto.setOption(capi.LS_OPT_COUNT_VISITS, 1)
+        _frame(auto)
+        survivors, bounds_read = auto.visitStats()[2:4]
+        assert (survivors > 0 and bounds_read > 0) == culls, (t.shape[0], survivors, bounds_read)
+        auto.setOption(capi.LS_OPT_COUNT_VISITS, 0)
+        A = oracle.affine_from_components(np.array((4.0, -9.0, 0.3), np.float32), np.array((0.01, -0.02, 1.1), np.float32))
+        for tr in (auto, off):
+            tr.updateGeometryTransform("g", A)
+        _same(_frame(auto), _frame(off))
+        auto.close()
+        off.close()
