@@ -289,10 +289,12 @@ static int create_device_state(ls_tracer *tr, int hip_device, ls_tracer **out)
         // blocks per CU: 0.150 ms against 0.186.  The other direction, lowest ring first, takes 0.194 ms; tiles of
         // 4 x 16 or 8 x 8 rays instead of 64 x 1 take 0.156 / 0.159.
         auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+        // round 6: a wave refills only when ALL its lanes are idle (64; 56 until now): frame 138.5 -> 127.8 us with the four-wide
+        // walk at SYN-1M, 344.6 -> 339.1 at configs[4]'s size (tools/sweep_wide.sh, sweep_wide2.sh; 24 / 40 / 48: 141 / 138 / 134)
         tr->chan_mul = 1u;
-        tr->refill_min = 56u;
+        tr->refill_min = 64u;
         { const uint32_t v = (uint32_t)tune_int("LS_TRACE_CHAN_MUL", 1); if (v && gcd(v, tr->V) == 1u) tr->chan_mul = v; }
-        { const int v = tune_int("LS_TRACE_REFILL_MIN", 56); if (v >= 1 && v <= 64) tr->refill_min = (uint32_t)v; }
+        { const int v = tune_int("LS_TRACE_REFILL_MIN", 64); if (v >= 1 && v <= 64) tr->refill_min = (uint32_t)v; }
     }
     // (coherent and mapped, explicitly: the host polls these words while kernels are still running)
     constexpr unsigned kHostWords = hipHostMallocMapped | hipHostMallocCoherent;

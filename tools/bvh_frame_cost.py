@@ -9,15 +9,13 @@ from lidarshooter_amd import capi
 import bench
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 instanced = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-sensor, meshes = bench.build_workload("syn128x1m")
+sensor, meshes = bench.build_workload(os.environ.get("W", "syn128x1m"))
 dev = torch.device("cuda", 0)
 tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], int(sensor["h_count"]), sensor["Rinv"], sensor["t"])
 tr.setOption(capi.LS_OPT_ENGINE, 1)
 tr.setOption(capi.LS_OPT_BVH_INSTANCED, instanced)
 if os.environ.get("LS_BENCH_BVH_WIDE") is not None:
     tr.setOption(capi.LS_OPT_BVH_WIDE, int(os.environ["LS_BENCH_BVH_WIDE"]))
-if os.environ.get("W"):
-    sensor, meshes = bench.build_workload(os.environ["W"])
 keep = []
 for n, v, t in meshes:
     dv = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev)
