@@ -352,10 +352,12 @@ int ls_tracer_set_hit_buffers(ls_tracer *tr, void *d_hits, uint32_t *d_n_points,
 #define LS_OPT_ENGINE 5         /* closest-hit engine: 0 auto (default), 1 BVH traversal, 2 sensor-space
                                  *    projection (streams triangles over the ray raster); identical results.
                                  *    Takes effect at the next commit.                                      */
-#define LS_OPT_BVH_WIDE 16      /* BVH engine, instanced mode: 1 (default) the trace walks FOUR-wide nodes made of the binary hierarchy
-                                 *    after every build / refit (a node's slots are its grandchildren: half the trips per ray, four
-                                 *    slab tests in flight per trip; + 128 bytes per node); 0: the binary nodes.  Identical results.
-                                 *    Takes effect at the next commit.                                                              */
+#define LS_OPT_BVH_WIDE 16      /* BVH engine, instanced mode: 1 (default) the trace walks FOUR-wide nodes made of the binary hierarchy (a
+                                 *    node's slots are its grandchildren: half the trips per ray, four slab tests in flight per trip;
+                                 *    + 128 bytes per node) -- made at the commit for hierarchies of up to 65 536 leaves, and for bigger
+                                 *    ones by the second frame that finds them unchanged (34 us per million nodes: a hierarchy rebuilt
+                                 *    or refitted every frame never pays it and is walked through its binary nodes); 0: the binary
+                                 *    nodes always.  Identical results.  Takes effect at the next commit.                            */
 #define LS_OPT_EMIT_POINTS 15   /* ls_trace_scene_async: 1 (default) the pack pass writes the 32-byte points and the 16-byte hit
                                  *    records; 0: the hit records only (d_points32 stays untouched) -- for a consumer that
                                  *    rebuilds points from (ray, t) anyway: a sharded group gathers hit records and
@@ -425,7 +427,7 @@ int ls_parallel_copy(void *dst, const void *src, uint64_t bytes);
 #define LS_INFO_FRAME_GRAPH_PATCHES 12  /* kernel nodes patched with new arguments before a replay                        */
 #define LS_INFO_FRAME_GRAPH_LAST_PATCHED 13 /* bit i: launch i of the frame replayed last went out with new arguments     */
 #define LS_INFO_EMIT_POINTS 14       /* the current LS_OPT_EMIT_POINTS                                            */
-#define LS_INFO_BVH_WIDE 16                /* 1: the committed BVH scene is walked through its four-wide nodes (LS_OPT_BVH_WIDE, instanced mode) */
+#define LS_INFO_BVH_WIDE 16                /* 1: the last trace walked the four-wide nodes (LS_OPT_BVH_WIDE, instanced mode, every geometry's made) */
 #define LS_INFO_FRAME_GRAPH_PATCH_WAITS 15 /* patches that first had to wait for the previous launch of their graph (the host ran more than three frames ahead) */
 long ls_get_info(ls_tracer *tr, int what);
 

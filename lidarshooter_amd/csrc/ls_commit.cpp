@@ -141,6 +141,7 @@ bool inst_possible(const ls_tracer *tr, const std::vector<Geometry *> &order)
 // vertices as uploaded.  A commit after which only poses differ finds nothing to do here.
 int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool relayout)
 {
+    constexpr uint32_t kWidenAtOnceLeaves = 65536u;
     const uint32_t g = tr->leaf_size;
     const bool fresh = relayout || !tr->inst_valid || tr->inst_leaf_size != g || tr->inst_layout.size() != order.size() ||
                        (tr->opt_bvh_wide != 0) != tr->wide_valid;   // (the option changed: the twins are made with the hierarchies)
@@ -217,8 +218,18 @@ int commit_instanced(ls_tracer *tr, const std::vector<Geometry *> &order, bool r
             // (a refit finds the topology of these very keys in the nodes: fresh layouts and classic builds in between clear the condition)
             if (refit) ls::launch_refit_nodes(s, sl.n_leaves, sl.rt, rb, tr->nodes.p + sl.node_first);
             else ls::launch_hierarchy(s, kb, sl.n_leaves, g, sl.rt, rb, tr->nodes.p + sl.node_first);
-            // the four-wide twins the trace walks (LS_OPT_BVH_WIDE): after every build and every refit of this geometry
-            if (tr->opt_bvh_wide) ls::launch_widen(s, tr->nodes.p + sl.node_first, sl.n_leaves, tr->wide_nodes.p + sl.node_first);
+            // The four-wide twins the trace walks (LS_OPT_BVH_WIDE) follow every build and every refit of this geometry -- at
+            // once for a small hierarchy (a moving instance's refit: a few microseconds), LAZILY for a big one: k_widen costs 34 us
+            // per million nodes, the wide walk wins ~13 us per frame there, and a hierarchy that is rebuilt or refitted every frame
+            // would pay the first without ever collecting the second.  The trace makes them once a hierarchy has survived
+            // kWidenAfterFrames frames (ls_trace.cpp) and walks the binary nodes until then.
+            ls_tracer::InstSlot &slw = tr->inst_layout[i];
+            slw.wide_made = false;
+            slw.wide_age = 0;
+            if (tr->opt_bvh_wide && sl.n_leaves <= kWidenAtOnceLeaves) {
+                ls::launch_widen(s, tr->nodes.p + sl.node_first, sl.n_leaves, tr->wide_nodes.p + sl.node_first);
+                slw.wide_made = true;
+            }
         }
         tr->wide_valid = tr->opt_bvh_wide != 0;
         // a scene of one geometry: the top of its hierarchy for the trace grid's LDS (static with the hierarchy)

@@ -490,7 +490,7 @@ long ls_get_info(ls_tracer *tr, int what)
     case LS_INFO_FRAME_GRAPH_LAST_PATCHED: return (long)tr->fg_last_patched;
     case LS_INFO_EMIT_POINTS: return (long)tr->opt_emit_points;
     case LS_INFO_FRAME_GRAPH_PATCH_WAITS: return (long)tr->fg_patch_waits;
-    case LS_INFO_BVH_WIDE: return (tr->bvh_inst && tr->wide_valid) ? 1 : 0;
+    case LS_INFO_BVH_WIDE: return (tr->bvh_inst && tr->wide_valid && tr->wide_in_use) ? 1 : 0;
     default: return fail(tr, LS_ERR_INVALID_ARGUMENT, "unknown info key");
     }
 }

@@ -195,7 +195,12 @@ struct ls_tracer {
     bool inst_valid = false;     // records / nodes / inst_layout hold instanced hierarchies for the current layout and leaf size
     uint64_t key_scratch_epoch = 1;   // bumped whenever keys_b / vals_b are overwritten by something other than a geometry's own slice
     bool last_commit_built = false;
-    struct InstSlot { uint32_t node_first, rec_first, n_leaves, range_first; ls::RangeTree rt; };
+    struct InstSlot {
+        uint32_t node_first, rec_first, n_leaves, range_first;
+        ls::RangeTree rt;
+        bool wide_made = false;   // its four-wide twins (wide_nodes) are those of its current binary nodes
+        uint32_t wide_age = 0;    // frames traced over the current binary nodes while the twins were not made (kWidenAfterFrames)
+    };
     std::vector<InstSlot> inst_layout;   // per layout entry
     uint32_t inst_leaf_size = 0;
     lsi::DevBuf<float> inst_verts;    // packed mesh-space vertices of all geometries (build input)
@@ -203,7 +208,8 @@ struct ls_tracer {
     lsi::DevBuf<ls::FatNode> treelet; // one-geometry scenes: the top of that hierarchy, breadth-first (k_trace_inst stages it in LDS)
     bool treelet_valid = false;
     lsi::DevBuf<ls::WideNode> wide_nodes;   // instanced mode, LS_OPT_BVH_WIDE: the four-wide twins of `nodes` (k_widen), same indexing
-    bool wide_valid = false;
+    bool wide_valid = false;     // the twins' buffer exists and LS_OPT_BVH_WIDE was on at the last commit
+    bool wide_in_use = false;    // the last trace walked them (every geometry's were made)
     int opt_bvh_wide = 1;
     bool bvh_order_valid = false;   // keys_b / vals_b hold the sorted Morton keys / order of the scene's triangles
     bool tris_rebased = false;          // tr->tris holds the rebased indices of the current layout and index uploads

@@ -817,37 +817,53 @@ __global__ __launch_bounds__(kBlock) void k_trace(SensorTables tb, RayQueues rq,
 // children: the gathers mostly land in lines a neighbouring lane reads as its own node.
 __global__ __launch_bounds__(kBlock) void k_widen(const FatNode *__restrict__ nodes, uint32_t n_nodes, WideNode *__restrict__ wide)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_nodes) return;
-    const float4 *nd = nodes[i].q;
-    const float4 A = nd[0], B = nd[1], C = nd[2], D = nd[3];
-    const uint32_t left = __float_as_uint(A.w), right = __float_as_uint(B.w);
+    // a wave's 64 wide nodes are 8 KB in a row: they leave through LDS, so that every store instruction writes 1 KB
+    // contiguous (a lane storing its own node's eight quarters would write 16 bytes of 64 different lines each time).
+    // Quarter k of lane's node sits at [k * 66 + lane]: lanes side by side when written; read back as node-major
+    // quarters q = 8 * node + k, eight consecutive q of one node are 66 apart = 2 mod 16 sixteen-byte columns: two nodes'
+    // worth (16 quarters) touch every column pair once.
+    __shared__ float4 s_out[kBlock / 64][8 * 66];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63u;
     float4 lo[4], hi[4];
     const float4 none_lo = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(kInvalid)), none_hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
 #pragma unroll
     for (int c = 0; c < 4; ++c) { lo[c] = none_lo; hi[c] = none_hi; }
-    // slots 0, 1: the left child's side; 2, 3: the right child's
-    if (left & kLeafBit) {
-        lo[0] = make_float4(A.x, A.y, A.z, __uint_as_float(left));
-        hi[0] = make_float4(B.x, B.y, B.z, 0.0f);
-    } else {
-        const float4 *c = nodes[left].q;
-        const float4 a = c[0], b = c[1], cc = c[2], d = c[3];
-        lo[0] = make_float4(a.x, a.y, a.z, a.w); hi[0] = make_float4(b.x, b.y, b.z, 0.0f);
-        lo[1] = make_float4(cc.x, cc.y, cc.z, b.w); hi[1] = make_float4(d.x, d.y, d.z, 0.0f);
+    if (i < n_nodes) {
+        const float4 *nd = nodes[i].q;
+        const float4 A = nd[0], B = nd[1], C = nd[2], D = nd[3];
+        const uint32_t left = __float_as_uint(A.w), right = __float_as_uint(B.w);
+        // slots 0, 1: the left child's side; 2, 3: the right child's.  Both children's nodes are fetched before either is used.
+        const bool lin = !(left & kLeafBit), rin = !(right & kLeafBit);
+        float4 la = none_lo, lb = none_hi, lc = none_lo, ld = none_hi, ra = none_lo, rb = none_hi, rc = none_lo, rd = none_hi;
+        if (lin) { const float4 *c = nodes[left].q; la = c[0]; lb = c[1]; lc = c[2]; ld = c[3]; }
+        if (rin) { const float4 *c = nodes[right].q; ra = c[0]; rb = c[1]; rc = c[2]; rd = c[3]; }
+        if (lin) {
+            lo[0] = make_float4(la.x, la.y, la.z, la.w); hi[0] = make_float4(lb.x, lb.y, lb.z, 0.0f);
+            lo[1] = make_float4(lc.x, lc.y, lc.z, lb.w); hi[1] = make_float4(ld.x, ld.y, ld.z, 0.0f);
+        } else {
+            lo[0] = make_float4(A.x, A.y, A.z, __uint_as_float(left));
+            hi[0] = make_float4(B.x, B.y, B.z, 0.0f);
+        }
+        if (rin) {
+            lo[2] = make_float4(ra.x, ra.y, ra.z, ra.w); hi[2] = make_float4(rb.x, rb.y, rb.z, 0.0f);
+            lo[3] = make_float4(rc.x, rc.y, rc.z, rb.w); hi[3] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        } else {
+            lo[2] = make_float4(C.x, C.y, C.z, __uint_as_float(right));
+            hi[2] = make_float4(D.x, D.y, D.z, 0.0f);
+        }
     }
-    if (right & kLeafBit) {
-        lo[2] = make_float4(C.x, C.y, C.z, __uint_as_float(right));
-        hi[2] = make_float4(D.x, D.y, D.z, 0.0f);
-    } else {
-        const float4 *c = nodes[right].q;
-        const float4 a = c[0], b = c[1], cc = c[2], d = c[3];
-        lo[2] = make_float4(a.x, a.y, a.z, a.w); hi[2] = make_float4(b.x, b.y, b.z, 0.0f);
-        lo[3] = make_float4(cc.x, cc.y, cc.z, b.w); hi[3] = make_float4(d.x, d.y, d.z, 0.0f);
-    }
-    float4 *o = wide[i].q;
+    float4 *mine = s_out[threadIdx.x >> 6];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { o[c] = lo[c]; o[4 + c] = hi[c]; }
+    for (int c = 0; c < 4; ++c) { mine[c * 66 + lane] = lo[c]; mine[(4 + c) * 66 + lane] = hi[c]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t wave_first = i - lane;
+    float4 *out = reinterpret_cast<float4 *>(wide + wave_first);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t q = (uint32_t)k * 64u + lane;   // quarter q of the wave's 512: node q / 8, its quarter q % 8
+        if (wave_first + (q >> 3) < n_nodes) out[q] = mine[(q & 7u) * 66u + (q >> 3)];
+    }
 }
 
 // Top of a hierarchy in breadth-first order, for the LDS of k_trace_inst: slot 0 = the root; a node's child that is an

@@ -896,7 +896,24 @@ int trace_once(ls_tracer *tr, uint32_t frame, ls_frame *out, bool readback)
                 std::memcpy(ig.m.rinv, tr->rinv, sizeof(ig.m.rinv));
                 std::memcpy(ig.m.t, tr->t, sizeof(ig.m.t));
             }
-            ls::launch_trace_instanced(s, tr->trace_blocks, tb, rq, batch, tr->nodes.p, tr->wide_valid ? tr->wide_nodes.p : nullptr, tr->records.p, tr->inst_leaf_size,
+            // the four-wide twins of hierarchies that have stood for kWidenAfterFrames frames are made now (ls_commit.cpp: small ones
+            // were made at their commit); the wide walk needs every geometry's
+            bool all_wide = tr->wide_valid;
+            if (tr->wide_valid) {
+                constexpr uint32_t kWidenAfterFrames = 2u;
+                for (uint32_t i = 0; i < batch.n; ++i) {
+                    ls_tracer::InstSlot &sl = tr->inst_layout[i];
+                    if (sl.wide_made || sl.n_leaves < 2u) continue;
+                    if (++sl.wide_age >= kWidenAfterFrames) {
+                        ls::launch_widen(s, tr->nodes.p + sl.node_first, sl.n_leaves, tr->wide_nodes.p + sl.node_first);
+                        sl.wide_made = true;
+                    } else {
+                        all_wide = false;
+                    }
+                }
+            }
+            tr->wide_in_use = all_wide;
+            ls::launch_trace_instanced(s, tr->trace_blocks, tb, rq, batch, tr->nodes.p, all_wide ? tr->wide_nodes.p : nullptr, tr->records.p, tr->inst_leaf_size,
                                        (batch.n == 1u && tr->treelet_valid) ? tr->treelet.p : nullptr, tr->hit_t.p, tr->hit_gid.p, tr->spill.p, tr->opt_count ? tr->d_visits : nullptr);
         } else {
             ls::launch_trace(s, tr->trace_blocks, tb, rq, tr->nodes.p, tr->records.p, tr->n_leaves, tr->committed_leaf_size,

@@ -8,6 +8,10 @@
 //   C  one hipGraphLaunch of [3 kernels] per frame
 //   D  one hipGraphLaunch of [3 kernels + copy / all-gather + kernel] per frame, each set on its own stream
 //   E  D + hipGraphExecKernelNodeSetParams of the first kernel before every launch (a pose change)
+//   F  (round 6) ONE hipGraphLaunch for THREE frames -- captured from s[0], forked to the two other
+//      set streams by events and joined again: three parallel chains of [3 kernels] -- and G the same with two frames per
+//      chain (six frames per launch), H = G + SetParams of every frame's first kernel: can a launch per K frames get the host
+//      under 3 us per frame?
 // Kernels are one workgroup each: the loop is host-bound, microseconds per frame = host cost per frame.
 // build: hipcc --offload-arch=gfx950 -O3 -o graph_launch graph_launch.hip -ldl
 #include <hip/hip_runtime.h>
@@ -159,6 +163,83 @@ int main(int argc, char **argv)
         t1 = now_us();
         CK(hipDeviceSynchronize());
         if (rep) report("E  D + new arguments for the first kernel every frame (SetParams)", t0, t1, now_us());
+    }
+    // ---- F / G / H: several frames per graph launch
+    for (int per_chain = 1; per_chain <= 2; ++per_chain) {
+        hipEvent_t fork, join[kSets];
+        CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int b = 0; b < kSets; ++b) CK(hipEventCreateWithFlags(&join[b], hipEventDisableTiming));
+        hipGraph_t gm;
+        hipGraphExec_t xm;
+        CK(hipStreamBeginCapture(s[0], hipStreamCaptureModeThreadLocal));
+        CK(hipEventRecord(fork, s[0]));
+        for (int b = 1; b < kSets; ++b) CK(hipStreamWaitEvent(s[b], fork, 0));
+        for (int b = 0; b < kSets; ++b)
+            for (int k = 0; k < per_chain; ++k) tracer(b, s[b]);
+        for (int b = 1; b < kSets; ++b) {
+            CK(hipEventRecord(join[b], s[b]));
+            CK(hipStreamWaitEvent(s[0], join[b], 0));
+        }
+        CK(hipStreamEndCapture(s[0], &gm));
+        CK(hipGraphInstantiate(&xm, gm, nullptr, nullptr, 0));
+        size_t n = 0;
+        CK(hipGraphGetNodes(gm, nullptr, &n));
+        std::vector<hipGraphNode_t> nodes(n), firsts;
+        CK(hipGraphGetNodes(gm, nodes.data(), &n));
+        hipKernelNodeParams kpm;
+        for (auto nd : nodes) {
+            hipGraphNodeType ty;
+            CK(hipGraphNodeGetType(nd, &ty));
+            if (ty != hipGraphNodeTypeKernel) continue;
+            hipKernelNodeParams p;
+            CK(hipGraphKernelNodeGetParams(nd, &p));
+            if (p.func == reinterpret_cast<void *>(k_a)) { firsts.push_back(nd); kpm = p; }
+        }
+        const int frames_per_launch = kSets * per_chain;
+        printf("graph of %d frames has %zu nodes (%zu first kernels)\n", frames_per_launch, n, firsts.size());
+        for (int patch = 0; patch <= 1; ++patch)
+            for (int rep = 0; rep < 2; ++rep) {
+                double t0 = now_us();
+                for (int f = 0; f < kFrames; f += frames_per_launch) {
+                    if (patch)
+                        for (size_t k = 0; k < firsts.size(); ++k) {
+                            big.f[7] = (float)(f + (int)k);
+                            float *outp = buf[k % kSets];
+                            void *args[2] = {&big, &outp};
+                            hipKernelNodeParams p = kpm;
+                            p.kernelParams = args;
+                            p.extra = nullptr;
+                            CK(hipGraphExecKernelNodeSetParams(xm, firsts[k], &p));
+                        }
+                    CK(hipGraphLaunch(xm, s[0]));
+                }
+                double t1 = now_us();
+                CK(hipDeviceSynchronize());
+                char what[120];
+                snprintf(what, sizeof(what), "%s  one graph of %d frames ([3 kernels] x %d chains x %d)%s", patch ? "H" : (per_chain == 1 ? "F" : "G"), frames_per_launch, kSets, per_chain,
+                         patch ? " + SetParams per frame" : "");
+                if (rep) report(what, t0, t1, now_us());
+            }
+    }
+    // ---- I: K frames in a ROW per graph (no fork: a chain of 3 K kernels on the set's stream), the three sets' graphs rotating
+    for (int K : {2, 4, 8}) {
+        hipGraph_t gl[kSets];
+        hipGraphExec_t xl[kSets];
+        for (int b = 0; b < kSets; ++b) {
+            CK(hipStreamBeginCapture(s[b], hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < K; ++k) tracer(b, s[b]);
+            CK(hipStreamEndCapture(s[b], &gl[b]));
+            CK(hipGraphInstantiate(&xl[b], gl[b], nullptr, nullptr, 0));
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            double t0 = now_us();
+            for (int f = 0, l = 0; f < kFrames; f += K, ++l) CK(hipGraphLaunch(xl[l % kSets], s[l % kSets]));
+            double t1 = now_us();
+            CK(hipDeviceSynchronize());
+            char what[120];
+            snprintf(what, sizeof(what), "I  one graph of %d frames in a row ([3 kernels] x %d on one stream)", K, K);
+            if (rep) report(what, t0, t1, now_us());
+        }
     }
     // did E's arguments arrive?  k_a writes a.f[blockIdx % 600] + a.f[7]: block 0 of the last frame of set b
     for (int b = 0; b < kSets; ++b) {
