@@ -2,8 +2,9 @@
 # Everything profiles/ holds for a round (GPU box, repo root):  bash tools/final_measure.sh r05 [a|b|c|all]
 #   a: bench lines of the other workloads and modes, lsbench, the group through a one-rank communicator, shard costs, BVH at configs[4]
 #   b: the profiles (kernel stats, HBM bytes, SQ / TCC counters) and, behind them, the two headline lines that quote them
+#      (b1: kernel stats + HBM bytes; b2: the counters, the headline lines, SYN-10M, rebuild / refit -- two calls of at most 20 minutes)
 #   c: soaks
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
@@ -48,7 +49,7 @@ for ph in build poses refit_ben classic; do echo "== $ph"; PHASE=$ph bash tools/
 find gpurun_out/rp_cfg5_* -name "*kernel_trace.csv" -delete
 python bench.py --workload cfg5 --engine bvh --no-cpu-baseline --no-dropin > gpurun_out/final/bench_${TAG}_bvh_cfg5.json 2>> gpurun_out/final/bench.err
 fi
-if [ "$PART" = b ] || [ "$PART" = all ]; then
+if [ "$PART" = b ] || [ "$PART" = b1 ] || [ "$PART" = all ]; then
 bash tools_profile.sh ${TAG} > gpurun_out/final/profile.log 2>&1
 python tools/prof_summary.py gpurun_out/prof_${TAG} gpurun_out/final/${TAG}_projection > gpurun_out/final/prof_summary.log 2>&1
 python3 - gpurun_out/prof_${TAG}/stats_one gpurun_out/final/${TAG}_projection_kernel_stats_one_in_flight.csv <<'PY'
@@ -69,6 +70,8 @@ cp gpurun_out/prof_${TAG}/bench_stats.json gpurun_out/final/${TAG}_projection_be
 BENCH_ARGS="--engine bvh --no-dropin" bash tools_pmc.sh ${TAG}_bvh "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/final/pmc_bvh.log 2>&1
 bash tools/bvh_stats.sh ${TAG} > gpurun_out/final/bvh_stats.log 2>&1
 python tools/pmc_to_hbm.py gpurun_out/pmc_${TAG}_bvh/summary.txt gpurun_out/final/${TAG}_bvh_hbm.json "bench.py --engine bvh (instanced hierarchies: nothing built per frame)" >> gpurun_out/final/pmc_bvh.log 2>&1
+fi
+if [ "$PART" = b ] || [ "$PART" = b2 ] || [ "$PART" = all ]; then
 # what binds the kernels: SQ / TCC counters of the three per-frame paths and of an eighth-of-a-turn shard
 bash tools/sq_profile.sh ${TAG} > gpurun_out/final/sq_profile.log 2>&1
 cp gpurun_out/sq_${TAG}/*_sq.txt gpurun_out/sq_${TAG}/*_sq.json gpurun_out/final/ 2>/dev/null

@@ -4,7 +4,7 @@
 # engine -- each with ONE frame in flight (every dispatch alone).  Counters are collected in their own passes with
 # --kernel-trace only (8 SQ slots, 4 TCC slots per pass; MI355X_MICROARCH.md "rocprofv3 PMC slots").
 # usage (GPU box, repo root): bash tools/sq_profile.sh <tag>   ->  gpurun_out/sq_<tag>/{projection,projection_10m,bvh}_sq.txt
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/sq_$TAG
 mkdir -p "$OUT"

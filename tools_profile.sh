@@ -2,7 +2,7 @@
 # Profiling recipe used for profiles/: kernel trace + stats, then HBM counters in separate passes.
 # Usage (on the GPU box, from the repo root):  bash tools_profile.sh <tag> [bench args...]
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r06}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
