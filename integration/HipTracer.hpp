@@ -246,6 +246,9 @@ private:
     {
         if (const char* e = std::getenv("LIDARSHOOTER_HIP_SKIP_UNCHANGED"))
             if (e[0] == '1') _policy_ = MeshPolicy::SkipUnchanged;
+        // (the header this file was compiled against and the library it was linked with: the same ABI, or nothing is called)
+        if (ls_abi_version() != LS_ABI_VERSION)
+            throw TraceException(__FILE__, "liblidarshooter_hip.so speaks another ABI than the lidarshooter_hip.h this adapter was built with", ls_abi_version());
         SensorProbe probe(*_sensorConfig);
         const ls_sensor_tables tables = probe.tables();
         _sensorPrint = SensorFingerprint(*_sensorConfig);
