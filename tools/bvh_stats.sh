@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_${TAG}_bvh
 mkdir -p "$OUT" "$REPO/gpurun_out/final"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- python3 "$REPO/bench.py" --engine bvh --steps 50 --warmup 10 --no-cpu-baseline --no-dropin > "$OUT/bench_stats.json" 2> "$OUT/stats.err" || echo "stats pass failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- python3 "$REPO/bench.py" --engine bvh --steps 50 --warmup 10 --no-cpu-baseline --no-dropin > "$OUT/bench_stats.json" 2> "$OUT/stats.err" || echo "stats pass failed"
 cd "$REPO"
 python3 - "$OUT" "gpurun_out/final/${TAG}_bvh_kernel_stats.csv" <<'PY'
 import csv, glob, os, sys

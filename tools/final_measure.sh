@@ -10,8 +10,13 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
 mkdir -p gpurun_out/final
 : > gpurun_out/final/bench.err
+# (the profiler's passes write their files when they end: a line a minute tells the box's watchdog that this script is alive; every
+# pass has its own time limit inside the scripts it calls, and the call as a whole gpurun's)
+( while true; do date +"%T still measuring" >> gpurun_out/final/heartbeat.txt; sleep 60; done ) &
+HEARTBEAT=$!
+trap "kill $HEARTBEAT 2>/dev/null" EXIT
 if [ "$PART" = a ] || [ "$PART" = all ]; then
-python bench.py --no-cpu-baseline --no-dropin --pipeline 1 > gpurun_out/final/bench_${TAG}_projection_mode1.json 2>> gpurun_out/final/bench.err
+python bench.py --no-cpu-baseline --no-dropin --no-also --pipeline 1 > gpurun_out/final/bench_${TAG}_projection_mode1.json 2>> gpurun_out/final/bench.err
 python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m > gpurun_out/final/bench_${TAG}_projection_10m.json 2>> gpurun_out/final/bench.err
 python bench.py --no-cpu-baseline --no-dropin --workload syn128x10m --no-cull > gpurun_out/final/bench_${TAG}_projection_10m_nocull.json 2>> gpurun_out/final/bench.err
 python bench.py --no-cpu-baseline --no-dropin --workload cfg5 > gpurun_out/final/bench_${TAG}_projection_cfg5.json 2>> gpurun_out/final/bench.err

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$REPO/$1" "${@:2}" > "$OUT/p$i.out" 2> "$OUT/p$i.err" || echo "pass $i failed: $C"
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$REPO/$1" "${@:2}" > "$OUT/p$i.out" 2> "$OUT/p$i.err" || echo "pass $i failed: $C"
 done
 cd "$REPO"
 python3 - "$OUT" <<'PY'

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/rp_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python3 "$REPO/$1" "${@:2}" > "$OUT/stdout.log" 2> "$OUT/stderr.log"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python3 "$REPO/$1" "${@:2}" > "$OUT/stdout.log" 2> "$OUT/stderr.log"
 cd "$REPO"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys

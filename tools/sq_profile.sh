@@ -19,7 +19,7 @@ run() {   # name, then the program and its arguments (python3 directly behind --
     local i=0
     for C in "${PASSES[@]}"; do
         i=$((i+1))
-        ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D/p$i" -o pmc -- python3 "$@" > "$D/p$i.out" 2> "$D/p$i.err" ) || echo "$name: pass $i failed ($C)"
+        ( cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D/p$i" -o pmc -- python3 "$@" > "$D/p$i.out" 2> "$D/p$i.err" ) || echo "$name: pass $i failed ($C)"
     done
     python3 - "$D" "$name" "$sha" "$OUT/${name}_sq.json" > "$OUT/${name}_sq.txt" <<'PY'
 import csv, glob, json, sys, collections
@@ -77,7 +77,7 @@ PY
     find "$D" -name "*kernel_trace.csv" -delete; find "$D" -name "*counter_collection.csv" -size +20M -delete
 }
 cd "$REPO"
-run projection "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-dropin --no-pipeline
+run projection "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-dropin --no-also --no-pipeline
 W=syn128x10m MODES=one run projection_10m "$REPO/tools/shard_cost.py" 2 1
 run bvh "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-dropin --engine bvh
 W=syn128x1m MODES=one RANKS=4 run shard_1m "$REPO/tools/shard_cost.py" 2 8

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/p$i.json" 2> "$OUT/p$i.err" || echo "pass $i failed: $C"
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-also ${BENCH_ARGS:-} > "$OUT/p$i.json" 2> "$OUT/p$i.err" || echo "pass $i failed: $C"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
