@@ -14,7 +14,7 @@ SHIM = os.path.join(ROOT, "tests", "shim", "librccl_shim.so")
 
 PROG = r'''
 import ctypes as C, json, os, sys, time
-L = C.CDLL(sys.argv[1]); rank = int(sys.argv[2]); idf = sys.argv[3]
+L = C.CDLL(sys.argv[1]); rank = int(sys.argv[2]); idf = sys.argv[3]; world = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 class Id(C.Structure):
     _fields_ = [("b", C.c_char * 128)]
 L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Id, C.c_int]
@@ -38,10 +38,10 @@ def facts(c):
     return [n.value, r.value]
 out = {}
 c = C.c_void_p()
-out["init"] = L.ncclCommInitRank(C.byref(c), 2, u, rank)
+out["init"] = L.ncclCommInitRank(C.byref(c), world, u, rank)
 out["world"] = facts(c)
 d = C.c_void_p()
-out["split_same"] = L.ncclCommSplit(c, 0, 1 - rank, C.byref(d), None)       # one colour, keys reversed: the ranks swap
+out["split_same"] = L.ncclCommSplit(c, 0, world - 1 - rank, C.byref(d), None)       # one colour, keys reversed: the ranks swap
 out["same"] = facts(d) if d else None
 e = C.c_void_p()
 out["split_own"] = L.ncclCommSplit(c, 7 + rank, 0, C.byref(e), None)        # a colour per rank: two communicators of one
@@ -57,12 +57,12 @@ print(json.dumps(out))
 '''
 
 
-def _two(tmp_path, env_extra=None):
+def _two(tmp_path, env_extra=None, world=2):
     assert os.path.exists(SHIM), "make -C tests/shim (build() does it)"
     env = dict(os.environ, LS_SHIM_TIMEOUT_S="30")
     env.update(env_extra or {})
     idf = str(tmp_path / "id")
-    ps = [subprocess.Popen([sys.executable, "-c", PROG, SHIM, str(r), idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    ps = [subprocess.Popen([sys.executable, "-c", PROG, SHIM, str(r), idf, str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     res = []
     for p in ps:
         o, e = p.communicate(timeout=120)
@@ -91,3 +91,12 @@ def test_shim_split_that_fails_on_one_rank_only(tmp_path):
 def test_shim_split_refused_everywhere(tmp_path):
     r0, r1 = _two(tmp_path, {"LS_SHIM_NO_SPLIT": "1"})
     assert r0["split_same"] != 0 and r1["split_same"] != 0 and r0["world"] == [2, 0] and r1["world"] == [2, 1]
+
+
+def test_shim_eight_ranks(tmp_path):
+    """the world a node has: eight processes meet, split with reversed keys (rank r becomes 7 - r), and split into singletons"""
+    res = _two(tmp_path, world=8)
+    for r, v in enumerate(res):
+        assert v["init"] == 0 and v["world"] == [8, r]
+        assert v["split_same"] == 0 and v["same"] == [8, 7 - r]
+        assert v["split_own"] == 0 and v["own"] == [1, 0] and v["none_is_null"]
