@@ -1705,8 +1705,6 @@ uint32_t trace_grid_blocks(int device)
         cus = (uint32_t)prop.multiProcessorCount;
     uint32_t per_cu = 2u;
     per_cu = (uint32_t)max(1, lsi::tune_int("LS_TRACE_BLOCKS_PER_CU", (int)per_cu));
-    const int absolute = lsi::tune_int("LS_TRACE_GRID_BLOCKS", 0);   // (experiment: grids that are not a multiple of the CUs)
-    if (absolute > 0) return (uint32_t)absolute;
     return cus * per_cu;
 }
 
