@@ -918,8 +918,8 @@ __global__ __launch_bounds__(kBlock) void k_treelet(const FatNode *__restrict__ 
 // WIDE (round 6, the default): the nodes are the FOUR-wide ones k_widen makes of the same hierarchy -- a node's slots are its
 // grandchildren (a child that is a leaf keeps its slot), 128 bytes: one fetch resolves four boxes and a trip goes down two
 // levels of the binary tree.  The kernel is bound by what a trip costs a wave in latency (EXPERIMENTS.md E4): half the trips,
-// each with four independent slab tests in flight instead of two.  The hit children are ordered nearest first (a five-
-// comparator network on (t_near, reference) pairs), the nearest is walked on, the others are pushed far to near.  The same
+// each with four independent slab tests in flight instead of two.  The nearest hit child is walked on, the other hits are
+// pushed as they stand (three stores whatever they hold; the stack pointer counts the hits).  The same
 // boxes, leaves and exact test as the binary walk: a grandchild is visited when ITS box is hit (the binary walk also asks
 // its parent's, which contains it: the wide walk visits a superset), so the closest hit and its tie-break are the same bits.
 template <bool COUNT, bool SINGLE /* one geometry (the usual scene): its descriptor is wave-uniform, scalar registers */, bool WIDE>
@@ -1043,24 +1043,36 @@ __global__ __launch_bounds__(kBlock) void k_trace_inst(SensorTables tb, RayQueue
                 uint32_t r0 = __float_as_uint(l0.w), r1 = __float_as_uint(l1.w), r2 = __float_as_uint(l2.w), r3 = __float_as_uint(l3.w);
                 k0 = b0 ? k0 : INFINITY; k1 = b1 ? k1 : INFINITY; k2 = b2 ? k2 : INFINITY; k3 = b3 ? k3 : INFINITY;
                 r0 = b0 ? r0 : kInvalid; r1 = b1 ? r1 : kInvalid; r2 = b2 ? r2 : kInvalid; r3 = b3 ? r3 : kInvalid;
-                // ascending t_near, missed slots last (t_near of a hit is finite: best caps the far bound it is compared with)
+                // The nearest hit child comes to the front (three comparators; a missed slot never wins: its key is +inf, and among
+                // equal keys a hit goes before a miss) and is walked on; the other hits are pushed as they stand.  Sorting all four
+                // (a five-comparator network) was measured: the same cloud, 0.6 % slower at SYN-1M, 4 % at configs[4]'s size -- a trip
+                // is a chain of dependent instructions at two waves per SIMD, and the order of what waits on the stack matters less
+                // than the twenty instructions it costs (EXPERIMENTS.md E8.3).
                 auto cswap = [](float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
                     const bool sw = kb < ka || (ra == kInvalid && rb != kInvalid);
                     const float kt = sw ? kb : ka; kb = sw ? ka : kb; ka = kt;
                     const uint32_t rt = sw ? rb : ra; rb = sw ? ra : rb; ra = rt;
                 };
-                cswap(k0, r0, k1, r1); cswap(k2, r2, k3, r3); cswap(k0, r0, k2, r2); cswap(k1, r1, k3, r3); cswap(k1, r1, k2, r2);
-                auto push = [&](uint32_t ref) {
-                    if (sp < (uint32_t)kStackLds) s_stack[sp][tid] = ref;
-                    else if (sp < (uint32_t)(kStackLds + kStackSpill)) my_spill[sp - kStackLds] = ref;
-                    ++sp;
-                };
+                cswap(k0, r0, k1, r1); cswap(k0, r0, k2, r2); cswap(k0, r0, k3, r3);
                 if (r0 == kInvalid) {
                     advance();
                 } else {
-                    if (r3 != kInvalid) push(r3);
-                    if (r2 != kInvalid) push(r2);
-                    if (r1 != kInvalid) push(r1);
+                    const uint32_t v3 = r3 != kInvalid ? 1u : 0u, v2 = r2 != kInvalid ? 1u : 0u, v1 = r1 != kInvalid ? 1u : 0u;
+                    if (sp + 3u <= (uint32_t)kStackLds) {   // the usual case: three stores, whatever they hold; the pointer counts the hits
+                        s_stack[sp][tid] = r3;
+                        s_stack[sp + v3][tid] = r2;
+                        s_stack[sp + v3 + v2][tid] = r1;
+                        sp += v3 + v2 + v1;
+                    } else {
+                        auto push = [&](uint32_t ref) {
+                            if (sp < (uint32_t)kStackLds) s_stack[sp][tid] = ref;
+                            else if (sp < (uint32_t)(kStackLds + kStackSpill)) my_spill[sp - kStackLds] = ref;
+                            ++sp;
+                        };
+                        if (v3) push(r3);
+                        if (v2) push(r2);
+                        if (v1) push(r1);
+                    }
                     cur = r0;
                 }
             }
