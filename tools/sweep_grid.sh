@@ -1,5 +1,7 @@
 #!/bin/bash
-# experimental build: the persistent trace grid at sizes between two and three blocks per CU (E8.3: 2.07 heavy batches per wave)
+# experimental build: the persistent trace grid at sizes between two and three blocks per CU (E8.3: 2.07 heavy batches per wave).
+# NEEDS a knob that was not kept: in trace_grid_blocks (ls_kernels.hip), `const int absolute = lsi::tune_int("LS_TRACE_GRID_BLOCKS", 0);
+# if (absolute > 0) return (uint32_t)absolute;` -- the sweep was flat (profiles/r06_bvh_grid_sweep.txt)
 set -u
 export LS_LIB_PATH=$(pwd)/build/exp/base/liblidarshooter_hip.so
 for WL in syn128x1m cfg5; do

@@ -1,5 +1,7 @@
 #!/bin/bash
-# experimental builds of the four-wide walk side by side (build/exp/<name>; LS_LIB_PATH)
+# experimental builds side by side (tools/exp_build.sh <name> "<-D flags>" -> build/exp/<name>; selected through LS_LIB_PATH):
+# VARIANTS="base other base other" bash tools/sweep_variants.sh -- the BVH engine's frame by the host clock + the cloud's hash, SYN-1M and configs[4].
+# (Round 6 compared the five-comparator sort, nearest-only ordering and a leaf-record prefetch this way: EXPERIMENTS.md E8.3.)
 set -u
 for WL in syn128x1m cfg5; do
   for V in ${VARIANTS:-base nearest base nearest}; do
