@@ -9,7 +9,8 @@ from lidarshooter_amd import capi, hostapi
 import bench
 bench.pin_to_gpu_numa_node(0)
 nh = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-sensor, meshes = bench.build_workload("syn128x1m")
+sensor, meshes = bench.build_workload(os.environ.get("W", "syn128x1m"))
+shard = [int(x) for x in os.environ["SHARD"].split(",")] if os.environ.get("SHARD") else None   # "first,n": an azimuth shard (what a rank of a group traces)
 dev = torch.device("cuda", 0)
 HL = hostapi.load()
 f32p = C.POINTER(C.c_float)
@@ -28,6 +29,8 @@ handles = []
 for k in range(nh):
     tr = capi.Tracer(sensor["vertical"], sensor["h_begin"], sensor["h_end"], H, sensor["Rinv"], sensor["t"])
     tr.setOption(capi.LS_OPT_ENGINE, 2)
+    if shard:
+        tr.setShard(*shard)
     for n, dv, dt, nv, nt in keep:
         tr.addGeometry(n, nv, nt)
         tr.updateGeometryDeviceShared(n, capi.IDENTITY_AFFINE, dv.data_ptr(), 12, dt.data_ptr())
