@@ -193,3 +193,13 @@ def test_given_sensor_tables_are_checked_before_anything_touches_a_device(capi, 
     assert create(s.vertical, s.h_begin + np.float32(0.01), s.step()) == -2
     assert create(s.vertical, s.h_begin, s.step(), sin_theta=st * np.float32(1.01)) == -2   # not a sine and a cosine of one angle
     assert create(s.vertical, s.h_begin + np.float32(360.0), s.step()) == ok      # azimuths compare modulo a turn
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_the_library_the_gpu_box_loads_was_built_from_these_sources(capi):
+    """the same check where the parity tests run: the GPU box executes binaries built elsewhere (they travel with the snapshot), and
+    every `-m gpu` verdict speaks for the sources only if the loaded library carries their hash"""
+    test_library_was_built_from_these_sources(capi)
