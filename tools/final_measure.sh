@@ -41,6 +41,7 @@ LS_BENCH_FORCE_GROUP=1 python bench.py --no-cpu-baseline --no-dropin --group-fla
 (cd tools/micro && ./loads_probe) > gpurun_out/final/${TAG}_loads_probe_micro.txt 2>&1
 (cd tools/micro && ./atomic_rate) > gpurun_out/final/${TAG}_atomic_rate_micro.txt 2>&1
 (cd tools/micro && ./strided_h2d) > gpurun_out/final/${TAG}_strided_h2d_micro.txt 2>&1
+(cd tools/micro && timeout -k 10 200 ./node_fetch 400) > gpurun_out/final/${TAG}_node_fetch_micro.txt 2>&1   # (second form of the probe; profiles/r06_node_fetch_micro.txt holds both)
 # what ONE of eight ranks does per frame (no collective): every rank of an eighth-of-a-turn split, SYN-1M and SYN-10M, streamed
 # through the C++ loop (one / three frames in flight / three as frame graphs); then the shard's kernels under rocprofv3
 python tools/shard_cost.py 2 1,8 all > gpurun_out/final/${TAG}_shard_cost_1m.txt 2>> gpurun_out/final/bench.err
